@@ -1,0 +1,137 @@
+/*
+ * libital_hip.so -- C ABI of the MI355X (gfx950) hot path of ITAL's GP-based mutual-information
+ * candidate selection.  Plain pointers and sizes only: every pointer is a *borrowed device pointer*
+ * (the caller owns the memory, e.g. through torch tensors), every call is asynchronous on the given
+ * HIP stream, returns 0 or a negative errno-style code (message: ital_last_error()).  No allocation
+ * crosses the ABI, nothing synchronises the device, so a whole fetch_unlabelled(k) round can be
+ * enqueued (or graph-captured) without host round trips.
+ *
+ * The reference (cvjena/ITAL) is pure Python and has no FFI; each entry point below replaces the native
+ * numerical routine the reference reaches at the cited place.  INTEGRATION.md shows the ctypes binding
+ * a maintainer of the reference would add.
+ */
+#ifndef ITAL_HIP_H
+#define ITAL_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct ihipStream_t* hipStream_t; /* same declaration as hip_runtime_api.h */
+
+#define ITAL_MAX_T 8        /* largest batch dimension with full sign-pattern enumeration on the device */
+#define ITAL_REC_HEADER 8   /* doubles in front of the feature row inside a selection record */
+#define ITAL_JUMP_BITS 48
+
+/* Library identification / error reporting. */
+const char* ital_version(void);
+const char* ital_last_error(void);
+
+/* ---- GP core ------------------------------------------------------------------------------------------
+ * Feature rows are fp64, row-major, leading dimension ldx = d rounded up to a multiple of 16 (zero padded).
+ */
+
+/* |x_i|^2 for every row.  Replaces np.sum(a**2, axis=-1), reference ital/gp.py:411,414-415. */
+int ital_row_norms(const double* X, int64_t n, int ldx, double* xnorm, hipStream_t stream);
+
+/* out[j][i] = var*exp(-|xs_j - x_i|^2 / (2 l^2)) for c <= 16 selected rows against all n rows.
+ * Replaces GaussianProcess.kernel (np.dot + numexpr exp), reference ital/gp.py:390-416, for the columns
+ * the streaming formulation needs (the reference forms the full N x N matrix at gp.py:128). */
+int ital_rbf_cols(const double* X, const double* xnorm, int64_t n, int ldx, const double* Xs, const double* sn,
+                  int c, double var, double length_scale, double* out, int64_t ldo, hipStream_t stream);
+
+/* out[j][i] = k(xs_j, x_i) - sum_r W[j][r] V[r][i]: posterior cross-covariance of c points with all rows
+ * (W[j] = whitened column of point j).  Replaces predict_cov_batch's cov_base_test, reference ital/gp.py:250-256. */
+int ital_cross_cov_cols(const double* X, const double* xnorm, int64_t n, int ldx, const double* Xs,
+                        const double* sn, int c, const double* W, int ldw, const double* V, int64_t ldv, int m,
+                        double var, double length_scale, double* out, int64_t ldo, hipStream_t stream);
+
+/* Rank-c Cholesky append of K[T,T] + noise*I (rows m..m+c-1 of L, alpha = L^-1 y).  XT rows m..m+c-1 must
+ * hold the new feature rows, XTn their squared norms.  status |= 1 when the matrix is not positive definite.
+ * Replaces invh / GaussianProcess.fit / update (dpotrf + dpotri from scratch), reference ital/gp.py:8-37,
+ * :141-161, :164-200. */
+int ital_chol_append(const double* XT, const double* XTn, int ldx, double* L, int ldl, double* alpha,
+                     const double* ynew, int m, int c, double var, double length_scale, double noise, int* status,
+                     hipStream_t stream);
+
+/* Appends the c whitened rows V[m..m+c-1][:] = L22^-1 (K[new,:] - L21 V) and refreshes the predictive mean
+ * mu += V_new^T alpha_new and variance s2 -= colsum(V_new^2) of every row.  L21 = &L[m][0] (ld ldw),
+ * L22 = &L[m][m] (ld ldw).  Replaces predict_stored after an update, reference ital/gp.py:203-232 as called from
+ * ital/retrieval_base.py:120 and ital/ital.py:558. */
+int ital_whiten_append(const double* X, const double* xnorm, int64_t n, int ldx, const double* Xnew,
+                       const double* snew, int c, const double* L21, int ldw, const double* L22,
+                       const double* alpha_new, double* V, int64_t ldv, int m, double var, double length_scale,
+                       double* mu, double* s2, hipStream_t stream);
+
+/* Predictive mean (and variance, if pvar != NULL, clamped at 0) at nt external points.
+ * Replaces GaussianProcess.predict, reference ital/gp.py:264-292. */
+int ital_predict(const double* Xt, int64_t nt, int ldx, const double* XT, const double* XTn, int m, const double* L,
+                 int ldl, const double* alpha, double var, double length_scale, double* mean, double* pvar,
+                 hipStream_t stream);
+
+/* ---- greedy batch construction ------------------------------------------------------------------------
+ * Batch state, replicated on every rank, updated only by ital_select_resolve (device side, no host sync). */
+typedef struct ital_batch {
+    int kmax;          /* capacity (max batch size) */
+    int ldx;           /* padded feature dimension */
+    int ldw;           /* leading dimension of VB (>= labelled-set capacity) */
+    int64_t* bidx;     /* [kmax] data index of each member, selection order */
+    int64_t* bgpos;    /* [kmax] candidate-list position each member was picked from */
+    int32_t* bsort;    /* [kmax] member slots ordered by data index */
+    double* bmu;       /* [kmax] predictive means */
+    double* sig;       /* [kmax][kmax] posterior covariance among the members */
+    double* XB;        /* [kmax][ldx] feature rows */
+    double* XBn;       /* [kmax] squared norms */
+    double* VB;        /* [kmax][ldw] whitened columns */
+} ital_batch;
+
+typedef struct ital_score_desc {
+    int t;                  /* batch dimension of this greedy step: members so far + 1 */
+    int64_t n_cand;         /* candidate-list positions held by this rank */
+    const int32_t* cand;    /* [n_cand] local row of each position (list order) */
+    const uint8_t* alive;   /* [n_cand] 0 once picked */
+    const double* mu;       /* [rows] predictive mean (rel_mean) */
+    const double* s2;       /* [rows] predictive variance, NOT clamped */
+    const double* C;        /* [t-1][ldc] cross-covariance of member b with every row */
+    int64_t ldc;
+    int64_t row_offset;     /* data index of local row 0 */
+    int64_t pos_offset;     /* list position of local position 0 */
+    ital_batch batch;
+    double noise, eps;
+    int label_mode;         /* 0 'mean', 1 'optimistic', 2 'pessimistic' (reference ital/ital.py:210-219) */
+    double* mi;             /* [n_cand] out */
+    /* t >= 3: replay of SciPy mvndst's MVNUNI stream (serial evaluation order of the reference) */
+    int seed[6];            /* generator state before the first call of this greedy step */
+    const long long* jump;  /* [ITAL_JUMP_BITS][18] transition matrices for 2^b calls of dimension t */
+    const double* vk;       /* [t-1] Korobov generator vector of this dimension */
+    int* status;            /* |= 2: singular conditional covariance met */
+} ital_score_desc;
+
+/* Scores every live candidate position: mi[p] = MI(batch + candidate p).
+ * Replaces the Pool.map over AppendedMutualInformation.__call__, reference ital/ital.py:124-128, :504-529,
+ * with MutualInformation._call_iter_all (:183-224), prob_rel (:345-383, scipy mvndst / norm.cdf) and
+ * updated_prob_rel (:432-450, gp.updated_prediction / extend_inv). */
+int ital_score_step(const ital_score_desc* d, hipStream_t stream);
+
+/* Local arg-extreme over the live positions + selection record for the exchange between ranks.
+ * mode 0: first maximum, NaN wins (np.argmax, reference ital/ital.py:130); mode 1: first minimum (np.argmin,
+ * ital/mcmi.py:77).  record = [value, list position, data index, mu, s2, |x|^2, rank, local position,
+ * x[ldx], V column[ldw], cross-covariances with the members[kmax]]; value = NaN-free sentinel when the rank has
+ * no live candidate (record[1] < 0).  work: >= 2*1024 doubles. */
+int ital_select_local(const double* mi, const int32_t* cand, const uint8_t* alive, int64_t n_cand, int64_t pos_offset,
+                      int64_t row_offset, int rank, int mode, const double* mu, const double* s2, const double* X,
+                      const double* xnorm, int ldx, const double* V, int64_t ldv, int m, int ldw, const double* C,
+                      int64_t ldc, int nprev, int kmax, double* work, double* record, hipStream_t stream);
+
+/* Picks the winner among `world` records (same rule, lowest list position on ties), appends it to the batch
+ * state as member `slot`, clears its alive flag on the owning rank and stores its data index in ret[slot].
+ * Replaces mutual_information.append + del candidates[max_ind], reference ital/ital.py:131-132, :561-586. */
+int ital_select_resolve(const double* records, int world, int rec_len, int rank, int mode, int slot,
+                        ital_batch batch, uint8_t* alive, int64_t* ret, hipStream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ITAL_HIP_H */

@@ -1,0 +1,85 @@
+"""ctypes binding of libital_hip.so (the C ABI declared in include/ital_hip.h).
+
+The product path has no CPU fallback: if the HIP library is missing this module raises at import.
+"""
+import ctypes
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libital_hip.so")
+
+c_void_p, c_int, c_int64, c_double = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_double
+
+ITAL_MAX_T = 8
+ITAL_REC_HEADER = 8
+ITAL_JUMP_BITS = 48
+
+
+class ItalBatch(ctypes.Structure):
+    _fields_ = [("kmax", c_int), ("ldx", c_int), ("ldw", c_int), ("bidx", c_void_p), ("bgpos", c_void_p),
+                ("bsort", c_void_p), ("bmu", c_void_p), ("sig", c_void_p), ("XB", c_void_p), ("XBn", c_void_p),
+                ("VB", c_void_p)]
+
+
+class ItalScoreDesc(ctypes.Structure):
+    _fields_ = [("t", c_int), ("n_cand", c_int64), ("cand", c_void_p), ("alive", c_void_p), ("mu", c_void_p),
+                ("s2", c_void_p), ("C", c_void_p), ("ldc", c_int64), ("row_offset", c_int64),
+                ("pos_offset", c_int64), ("batch", ItalBatch), ("noise", c_double), ("eps", c_double),
+                ("label_mode", c_int), ("mi", c_void_p), ("seed", c_int * 6), ("jump", c_void_p), ("vk", c_void_p),
+                ("status", c_void_p)]
+
+
+SIGNATURES = {
+    "ital_version": (ctypes.c_char_p, []),
+    "ital_last_error": (ctypes.c_char_p, []),
+    "ital_row_norms": (c_int, [c_void_p, c_int64, c_int, c_void_p, c_void_p]),
+    "ital_rbf_cols": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_void_p, c_void_p, c_int, c_double, c_double,
+                              c_void_p, c_int64, c_void_p]),
+    "ital_cross_cov_cols": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_void_p, c_void_p, c_int, c_void_p, c_int,
+                                    c_void_p, c_int64, c_int, c_double, c_double, c_void_p, c_int64, c_void_p]),
+    "ital_chol_append": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_int, c_int,
+                                 c_double, c_double, c_double, c_void_p, c_void_p]),
+    "ital_whiten_append": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_void_p, c_void_p, c_int, c_void_p, c_int,
+                                   c_void_p, c_void_p, c_void_p, c_int64, c_int, c_double, c_double, c_void_p,
+                                   c_void_p, c_void_p]),
+    "ital_predict": (c_int, [c_void_p, c_int64, c_int, c_void_p, c_void_p, c_int, c_void_p, c_int, c_void_p,
+                             c_double, c_double, c_void_p, c_void_p, c_void_p]),
+    "ital_score_step": (c_int, [ctypes.POINTER(ItalScoreDesc), c_void_p]),
+    "ital_select_local": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int64, c_int, c_int, c_void_p,
+                                  c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int64, c_int, c_int, c_void_p,
+                                  c_int64, c_int, c_int, c_void_p, c_void_p, c_void_p]),
+    "ital_select_resolve": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, ItalBatch, c_void_p, c_void_p,
+                                    c_void_p]),
+}
+
+
+class ItalHipError(RuntimeError):
+    pass
+
+
+def load(path=LIB_PATH):
+    if not os.path.exists(path):
+        raise ImportError(
+            f"{path} not found: build it with `python -m ital_amd.build` (hipcc, gfx950). "
+            "ital_amd has no CPU fallback.")
+    lib = ctypes.CDLL(path)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the library does not export what the header declares
+        fn.restype = res
+        fn.argtypes = args
+    return lib
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        _lib = load()
+    return _lib
+
+
+def check(rc):
+    if rc != 0:
+        raise ItalHipError(f"libital_hip: error {rc}: {lib().ital_last_error().decode()}")

@@ -1,0 +1,227 @@
+// Device-side scalar math for the ITAL hot path on gfx950 (fp64 throughout).
+//
+// Phi / Phi^-1 / bivariate-normal routines follow the published algorithms that SciPy's
+// `mvndst` (A. Genz) is built from, because the reference's orthant probabilities are defined by
+// them (reference ital/ital.py:380-381 -> scipy.stats.mvn.mvndst):
+//   mvn_phi   : Hart et al. algorithm 5666 (rational, |z| < 10/sqrt2; continued fraction beyond)
+//   mvn_phinv : Wichura AS241 PPND16
+//   mvn_bvu   : Genz BVU, Gauss-Legendre 6/12/20 point rules
+//   ndtr      : erfc form of the normal cdf used by scipy.stats.norm.cdf (ital.py:367-369)
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace ital {
+
+__device__ __forceinline__ double mvn_phi(double z) {
+    const double P0 = 220.2068679123761, P1 = 221.2135961699311, P2 = 112.0792914978709, P3 = 33.91286607838300,
+                 P4 = 6.373962203531650, P5 = .7003830644436881, P6 = .03526249659989109;
+    const double Q0 = 440.4137358247522, Q1 = 793.8265125199484, Q2 = 637.3336333788311, Q3 = 296.5642487796737,
+                 Q4 = 86.78073220294608, Q5 = 16.06417757920695, Q6 = 1.755667163182642, Q7 = .08838834764831844;
+    const double ROOTPI = 2.506628274631001, CUTOFF = 7.071067811865475;
+    double zabs = fabs(z);
+    double p;
+    if (zabs > 37.0) {
+        p = 0.0;
+    } else {
+        double expntl = exp(-zabs * zabs / 2);
+        if (zabs < CUTOFF) {
+            double num = ((((((P6 * zabs + P5) * zabs + P4) * zabs + P3) * zabs + P2) * zabs + P1) * zabs + P0);
+            double den = (((((((Q7 * zabs + Q6) * zabs + Q5) * zabs + Q4) * zabs + Q3) * zabs + Q2) * zabs + Q1) * zabs + Q0);
+            p = expntl * num / den;
+        } else {
+            p = expntl / (zabs + 1 / (zabs + 2 / (zabs + 3 / (zabs + 4 / (zabs + 0.65))))) / ROOTPI;
+        }
+    }
+    if (z > 0) p = 1 - p;
+    return p;
+}
+
+__device__ __forceinline__ double mvn_phinv(double p) {
+    const double SPLIT1 = 0.425, SPLIT2 = 5, CONST1 = 0.180625, CONST2 = 1.6;
+    double q = (2 * p - 1) / 2;
+    if (fabs(q) <= SPLIT1) {
+        const double A0 = 3.3871328727963666080E0, A1 = 1.3314166789178437745E+2, A2 = 1.9715909503065514427E+3,
+                     A3 = 1.3731693765509461125E+4, A4 = 4.5921953931549871457E+4, A5 = 6.7265770927008700853E+4,
+                     A6 = 3.3430575583588128105E+4, A7 = 2.5090809287301226727E+3, B1 = 4.2313330701600911252E+1,
+                     B2 = 6.8718700749205790830E+2, B3 = 5.3941960214247511077E+3, B4 = 2.1213794301586595867E+4,
+                     B5 = 3.9307895800092710610E+4, B6 = 2.8729085735721942674E+4, B7 = 5.2264952788528545610E+3;
+        double r = CONST1 - q * q;
+        return q * (((((((A7 * r + A6) * r + A5) * r + A4) * r + A3) * r + A2) * r + A1) * r + A0) /
+               (((((((B7 * r + B6) * r + B5) * r + B4) * r + B3) * r + B2) * r + B1) * r + 1);
+    }
+    double r = fmin(p, 1 - p);
+    double v;
+    if (r > 0) {
+        r = sqrt(-log(r));
+        if (r <= SPLIT2) {
+            const double C0 = 1.42343711074968357734E0, C1 = 4.63033784615654529590E0, C2 = 5.76949722146069140550E0,
+                         C3 = 3.64784832476320460504E0, C4 = 1.27045825245236838258E0, C5 = 2.41780725177450611770E-1,
+                         C6 = 2.27238449892691845833E-2, C7 = 7.74545014278341407640E-4, D1 = 2.05319162663775882187E0,
+                         D2 = 1.67638483018380384940E0, D3 = 6.89767334985100004550E-1, D4 = 1.48103976427480074590E-1,
+                         D5 = 1.51986665636164571966E-2, D6 = 5.47593808499534494600E-4, D7 = 1.05075007164441684324E-9;
+            r = r - CONST2;
+            v = (((((((C7 * r + C6) * r + C5) * r + C4) * r + C3) * r + C2) * r + C1) * r + C0) /
+                (((((((D7 * r + D6) * r + D5) * r + D4) * r + D3) * r + D2) * r + D1) * r + 1);
+        } else {
+            const double E0 = 6.65790464350110377720E0, E1 = 5.46378491116411436990E0, E2 = 1.78482653991729133580E0,
+                         E3 = 2.96560571828504891230E-1, E4 = 2.65321895265761230930E-2, E5 = 1.24266094738807843860E-3,
+                         E6 = 2.71155556874348757815E-5, E7 = 2.01033439929228813265E-7, F1 = 5.99832206555887937690E-1,
+                         F2 = 1.36929880922735805310E-1, F3 = 1.48753612908506148525E-2, F4 = 7.86869131145613259100E-4,
+                         F5 = 1.84631831751005468180E-5, F6 = 1.42151175831644588870E-7, F7 = 2.04426310338993978564E-15;
+            r = r - SPLIT2;
+            v = (((((((E7 * r + E6) * r + E5) * r + E4) * r + E3) * r + E2) * r + E1) * r + E0) /
+                (((((((F7 * r + F6) * r + F5) * r + F4) * r + F3) * r + F2) * r + F1) * r + 1);
+        }
+    } else {
+        v = 9;
+    }
+    return q < 0 ? -v : v;
+}
+
+// scipy.special.ndtr (Cephes): the function behind scipy.stats.norm.cdf.
+__device__ __forceinline__ double ndtr(double a) {
+    const double SQRTH = 7.07106781186547524401E-1;
+    if (isnan(a)) return a;
+    double x = a * SQRTH;
+    double z = fabs(x);
+    double y;
+    if (z < SQRTH) {
+        y = 0.5 + 0.5 * erf(x);
+    } else {
+        y = 0.5 * erfc(z);
+        if (x > 0) y = 1.0 - y;
+    }
+    return y;
+}
+
+// norm.cdf(0, mean, sd): NaN unless sd > 0 (scipy's scale check).
+__device__ __forceinline__ double norm_cdf0(double mean, double sd) {
+    if (!(sd > 0)) return __builtin_nan("");
+    return ndtr((0.0 - mean) / sd);
+}
+
+// P(X > sh, Y > sk), correlation r.
+__device__ inline double mvn_bvu(double sh, double sk, double r) {
+    const double W6[3] = {0.1713244923791705, 0.3607615730481384, 0.4679139345726904};
+    const double X6[3] = {-0.9324695142031522, -0.6612093864662647, -0.2386191860831970};
+    const double W12[6] = {0.4717533638651177e-01, 0.1069393259953183, 0.1600783285433464,
+                           0.2031674267230659, 0.2334925365383547, 0.2491470458134029};
+    const double X12[6] = {-0.9815606342467191, -0.9041172563704750, -0.7699026741943050,
+                           -0.5873179542866171, -0.3678314989981802, -0.1252334085114692};
+    const double W20[10] = {0.1761400713915212e-01, 0.4060142980038694e-01, 0.6267204833410906e-01,
+                            0.8327674157670475e-01, 0.1019301198172404, 0.1181945319615184, 0.1316886384491766,
+                            0.1420961093183821, 0.1491729864726037, 0.1527533871307259};
+    const double X20[10] = {-0.9931285991850949, -0.9639719272779138, -0.9122344282513259, -0.8391169718222188,
+                            -0.7463319064601508, -0.6360536807265150, -0.5108670019508271, -0.3737060887154196,
+                            -0.2277858511416451, -0.7652652113349733e-01};
+    const double TWOPI = 6.283185307179586;
+    int lg;
+    const double *W, *X;
+    if (fabs(r) < 0.3) { lg = 3; W = W6; X = X6; }
+    else if (fabs(r) < 0.75) { lg = 6; W = W12; X = X12; }
+    else { lg = 10; W = W20; X = X20; }
+    double h = sh, k = sk, hk = h * k, bvn = 0;
+    if (fabs(r) < 0.925) {
+        double hs = (h * h + k * k) / 2;
+        double asr = asin(r);
+        for (int i = 0; i < lg; i++) {
+            double sn = sin(asr * (X[i] + 1) / 2);
+            bvn += W[i] * exp((sn * hk - hs) / (1 - sn * sn));
+            sn = sin(asr * (-X[i] + 1) / 2);
+            bvn += W[i] * exp((sn * hk - hs) / (1 - sn * sn));
+        }
+        bvn = bvn * asr / (2 * TWOPI) + mvn_phi(-h) * mvn_phi(-k);
+    } else {
+        if (r < 0) { k = -k; hk = -hk; }
+        if (fabs(r) < 1) {
+            double as = (1 - r) * (1 + r);
+            double a = sqrt(as);
+            double bs = (h - k) * (h - k);
+            double c = (4 - hk) / 8;
+            double d = (12 - hk) / 16;
+            double asr = -(bs / as + hk) / 2;
+            if (asr > -100) bvn = a * exp(asr) * (1 - c * (bs - as) * (1 - d * bs / 5) / 3 + c * d * as * as / 5);
+            if (-hk < 100) {
+                double b = sqrt(bs);
+                bvn = bvn - exp(-hk / 2) * sqrt(TWOPI) * mvn_phi(-b / a) * b * (1 - c * bs * (1 - d * bs / 5) / 3);
+            }
+            a = a / 2;
+            for (int i = 0; i < lg; i++) {
+                for (int is = -1; is <= 1; is += 2) {
+                    double xs = (a + a * is * X[i]) * (a + a * is * X[i]);
+                    double rs = sqrt(1 - xs);
+                    double asr2 = -(bs / xs + hk) / 2;
+                    if (asr2 > -100) {
+                        double sp = (1 + c * xs * (1 + d * xs));
+                        double ep = exp(-hk * (1 - rs) / (2 * (1 + rs))) / rs;
+                        bvn = bvn + a * W[i] * exp(asr2) * (ep - sp);
+                    }
+                }
+            }
+            bvn = -bvn / TWOPI;
+        }
+        if (r > 0) {
+            bvn = bvn + mvn_phi(-fmax(h, k));
+        } else {
+            bvn = -bvn;
+            if (k > h) {
+                if (h < 0) bvn = bvn + mvn_phi(k) - mvn_phi(h);
+                else bvn = bvn + mvn_phi(-h) - mvn_phi(-k);
+            }
+        }
+    }
+    return bvn;
+}
+
+// Orthant probability of a standardised bivariate normal: variable j is > pivot_j when rel_j, else <= pivot_j.
+__device__ inline double bvn_orthant(double p0, double p1, bool rel0, bool rel1, double r) {
+    if (rel0 && rel1) return mvn_bvu(p0, p1, r);
+    if (!rel0 && rel1) return mvn_bvu(-p0, p1, -r);
+    if (rel0 && !rel1) return mvn_bvu(p0, -p1, -r);
+    return mvn_bvu(-p0, -p1, r);
+}
+
+// ---------------------------------------------------------------------------------------------
+// MVNUNI: L'Ecuyer (1996) combined multiple-recursive generator, the stream SciPy's mvndst draws
+// its lattice shifts from.  State = (x10,x11,x12 mod m1; x20,x21,x22 mod m2).
+struct MrgState {
+    int x10, x11, x12, x20, x21, x22;
+};
+constexpr long long MRG_M1 = 2147483647LL, MRG_M2 = 2145483479LL;
+
+__device__ __forceinline__ double mrg_next(MrgState& s) {
+    // x12' = (63308*x11 - 183326*x10) mod m1 ; x22' = (86098*x22 - 539608*x20) mod m2
+    long long p1 = (63308LL * s.x11 - 183326LL * s.x10) % MRG_M1;
+    if (p1 < 0) p1 += MRG_M1;
+    long long p2 = (86098LL * s.x22 - 539608LL * s.x20) % MRG_M2;
+    if (p2 < 0) p2 += MRG_M2;
+    s.x10 = s.x11; s.x11 = s.x12; s.x12 = (int)p1;
+    s.x20 = s.x21; s.x21 = s.x22; s.x22 = (int)p2;
+    int z = s.x12 - s.x22;
+    if (z <= 0) z += (int)MRG_M1;
+    return z * 4.656612873077392578125e-10;
+}
+
+// state <- J * state, J = two 3x3 matrices (row-major, entries already reduced): jump-ahead by a fixed count.
+__device__ __forceinline__ void mrg_apply(MrgState& s, const long long* __restrict__ J) {
+    unsigned long long a0 = s.x10, a1 = s.x11, a2 = s.x12;
+    unsigned long long b0 = s.x20, b1 = s.x21, b2 = s.x22;
+    unsigned long long r[3], q[3];
+#pragma unroll
+    for (int i = 0; i < 3; i++) {
+        r[i] = ((unsigned long long)J[3 * i] * a0 % MRG_M1 + (unsigned long long)J[3 * i + 1] * a1 % MRG_M1 +
+                (unsigned long long)J[3 * i + 2] * a2 % MRG_M1) % MRG_M1;
+        q[i] = ((unsigned long long)J[9 + 3 * i] * b0 % MRG_M2 + (unsigned long long)J[9 + 3 * i + 1] * b1 % MRG_M2 +
+                (unsigned long long)J[9 + 3 * i + 2] * b2 % MRG_M2) % MRG_M2;
+    }
+    s.x10 = (int)r[0]; s.x11 = (int)r[1]; s.x12 = (int)r[2];
+    s.x20 = (int)q[0]; s.x21 = (int)q[1]; s.x22 = (int)q[2];
+}
+
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+
+}  // namespace ital

@@ -1,0 +1,279 @@
+// RBF kernel columns + whitened posterior updates, streaming over the rows of X (never N x N).
+//
+// Roles: R1 RBF kernel (reference ital/gp.py:390-416), R3 posterior mean/variance
+// (gp.py:221-232) and R4 batch cross-covariances (gp.py:235-261), in the Cholesky-whitened form
+//     G = L L^T,  V = L^-1 K[T,:],  mu = V^T alpha,  s2 = v - colsum(V^2),  Cov(i,b) = K(i,b) - V[:,i].V[:,b].
+//
+// One kernel does all of it.  For a 16-row tile of X per wave it forms, on the FP64 matrix cores
+// (v_mfma_f64_16x16x4_f64),
+//     dot[j][i] = <xs_j, x_i>            (the -2 X Xs^T term; K-dimension = d, 16 k-values per step)
+//     S[j][i]   = sum_r W[j][r] V[r][i]  (K-dimension = m)
+// and then R[j][i] = var * exp((|x_i|^2 + |xs_j|^2 - 2 dot)/(-2 l^2)) - S[j][i] with the row norms fused in
+// the epilogue.  Epilogues:
+//   MODE_RAW    out[j][i] = R[j][i]                        (kernel columns; greedy cross-covariance column)
+//   MODE_WHITEN V_new = L22^-1 R (forward substitution through an LDS transpose), appended as rows m..m+c-1
+//               of V; s2 -= colsum(V_new^2); mu += V_new^T alpha_new   (GP update, rank-c Cholesky append)
+//   MODE_PREDICT out_mean[i] += ..., used for gp.predict on external points (see predict kernel below)
+//
+// Data layout: X row-major [n][ldx] fp64, ldx = d padded to a multiple of 16 with zeros (rows 128-B aligned);
+// V row-major [m_max][ldv] (one contiguous n-vector per labelled point, coalesced across candidates).
+// HBM-bound: algorithmic bytes per row = 8*(d + m) read + 8*c written; the MFMA pipe has ~3x headroom.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "device_math.h"
+#include "ital_internal.h"
+
+namespace ital {
+
+typedef double d4 __attribute__((ext_vector_type(4)));
+
+__global__ __launch_bounds__(256) void row_norms_kernel(const double* __restrict__ X, int64_t n, int ldx,
+                                                        double* __restrict__ xnorm) {
+    // one wave per row, 16-B loads, wave reduction
+    int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    int lane = threadIdx.x & 63;
+    int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+    for (int64_t i = wave; i < n; i += nwaves) {
+        const double* row = X + i * ldx;
+        double acc = 0;
+        for (int k = lane * 2; k < ldx; k += 128) {
+            double2 v = *reinterpret_cast<const double2*>(row + k);
+            acc += v.x * v.x + v.y * v.y;
+        }
+        acc = wave_sum(acc);
+        if (lane == 0) xnorm[i] = acc;
+    }
+}
+
+struct KcolsArgs {
+    const double* X;      // [n][ldx]
+    const double* xnorm;  // [n]
+    int64_t n;
+    int ldx;              // padded feature dim, multiple of 16
+    const double* Xs;     // [c][ldx] selected rows (replicated)
+    const double* sn;     // [c] their squared norms
+    int c;                // 1..16
+    const double* W;      // [c][ldw] coefficients against V rows (L21, or a V column); may be null when m == 0
+    int ldw;
+    const double* V;      // [m_max][ldv]
+    int64_t ldv;
+    int m;                // rows of V in use
+    double var, s;        // kernel variance; s = -2 l^2
+    int mode;
+    double* out;          // MODE_RAW: [c][ldo]
+    int64_t ldo;
+    // MODE_WHITEN
+    const double* L22;    // [c][ldw] lower (rows m.. of L, columns m..)
+    const double* alpha_new;  // [c]
+    double* Vw;           // writable V (same buffer as V)
+    double* mu;           // [n]
+    double* s2;           // [n]
+};
+
+enum { MODE_RAW = 0, MODE_WHITEN = 1 };
+
+__global__ __launch_bounds__(256) void kcols_kernel(KcolsArgs a) {
+    __shared__ double tile[4][16][17];  // per wave: R[j][i] transpose buffer for the whitening epilogue
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int col = lane & 15;   // MFMA: A row / B column / D column
+    const int kg = lane >> 4;    // MFMA: k index / D row group
+    const int64_t i0 = ((int64_t)blockIdx.x * 4 + wave) * 16;
+    if (i0 >= a.n) return;
+    const int64_t irow = i0 + col;            // data row this lane feeds as B column
+    const bool row_ok = irow < a.n;
+    const bool sel_ok = col < a.c;            // selected point this lane feeds as A row
+    const double* xrow = a.X + (row_ok ? irow : 0) * a.ldx;
+    const double* srow = a.Xs + (sel_ok ? col : 0) * (int64_t)a.ldx;
+
+    d4 acc_dot = {0, 0, 0, 0};
+    // ---- dot products over the feature dimension: 16 k-values per step, 32 B per lane per operand
+    for (int k0 = 0; k0 < a.ldx; k0 += 16) {
+        const int kk = k0 + 4 * kg;
+        double2 b01 = {0, 0}, b23 = {0, 0}, a01 = {0, 0}, a23 = {0, 0};
+        if (row_ok) {
+            b01 = *reinterpret_cast<const double2*>(xrow + kk);
+            b23 = *reinterpret_cast<const double2*>(xrow + kk + 2);
+        }
+        if (sel_ok) {
+            a01 = *reinterpret_cast<const double2*>(srow + kk);
+            a23 = *reinterpret_cast<const double2*>(srow + kk + 2);
+        }
+        acc_dot = __builtin_amdgcn_mfma_f64_16x16x4f64(a01.x, b01.x, acc_dot, 0, 0, 0);
+        acc_dot = __builtin_amdgcn_mfma_f64_16x16x4f64(a01.y, b01.y, acc_dot, 0, 0, 0);
+        acc_dot = __builtin_amdgcn_mfma_f64_16x16x4f64(a23.x, b23.x, acc_dot, 0, 0, 0);
+        acc_dot = __builtin_amdgcn_mfma_f64_16x16x4f64(a23.y, b23.y, acc_dot, 0, 0, 0);
+    }
+    // ---- S = W V over the labelled dimension: A[j][r] = W[j][r], B[r][i] = V[r][i]
+    d4 acc_s = {0, 0, 0, 0};
+    for (int r0 = 0; r0 < a.m; r0 += 4) {
+        const int r = r0 + kg;
+        double av = 0, bv = 0;
+        if (r < a.m) {
+            if (sel_ok) av = a.W[(int64_t)col * a.ldw + r];
+            if (row_ok) bv = a.V[(int64_t)r * a.ldv + irow];
+        }
+        acc_s = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc_s, 0, 0, 0);
+    }
+    // ---- epilogue.  D layout (f64 16x16x4): element reg -> row j = kg + 4*reg, column i = col.
+    const double xn = row_ok ? a.xnorm[irow] : 0.0;
+    double R[4];
+#pragma unroll
+    for (int reg = 0; reg < 4; reg++) {
+        const int j = kg + 4 * reg;
+        double v = 0;
+        if (j < a.c) {
+            const double snj = a.sn[j];
+            v = a.var * exp((snj + xn - 2 * acc_dot[reg]) / a.s) - acc_s[reg];
+        }
+        R[reg] = v;
+    }
+    if (a.mode == MODE_RAW) {
+#pragma unroll
+        for (int reg = 0; reg < 4; reg++) {
+            const int j = kg + 4 * reg;
+            if (j < a.c && row_ok) a.out[(int64_t)j * a.ldo + irow] = R[reg];
+        }
+        return;
+    }
+    // MODE_WHITEN: transpose through LDS so that one lane owns all c values of a data row
+#pragma unroll
+    for (int reg = 0; reg < 4; reg++) tile[wave][kg + 4 * reg][col] = R[reg];
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    if (lane < 16 && row_ok) {
+        double vn[16];
+        double dvar = 0, dmu = 0;
+#pragma unroll
+        for (int j = 0; j < 16; j++) {
+            if (j < a.c) {
+                double acc = tile[wave][j][lane];
+#pragma unroll
+                for (int q = 0; q < j; q++) acc -= a.L22[j * a.ldw + q] * vn[q];
+                vn[j] = acc / a.L22[j * a.ldw + j];
+                dvar += vn[j] * vn[j];
+                dmu += vn[j] * a.alpha_new[j];
+                a.Vw[(int64_t)(a.m + j) * a.ldv + irow] = vn[j];
+            } else {
+                vn[j] = 0;
+            }
+        }
+        a.s2[irow] -= dvar;
+        a.mu[irow] += dmu;
+    }
+}
+
+// gp.predict on external points (reference ital/gp.py:264-292): mean = w^T k(T, x), var = max(0, v - |L^-1 k|^2).
+// Small (the harness calls it once per round on the test split); one wave per test point, k vector in LDS.
+__global__ __launch_bounds__(256) void predict_kernel(const double* __restrict__ Xt, int64_t nt, int ldx,
+                                                      const double* __restrict__ XT, const double* __restrict__ XTn,
+                                                      int m, const double* __restrict__ L, int ldl,
+                                                      const double* __restrict__ alpha, double var, double s,
+                                                      double* __restrict__ mean, double* __restrict__ pvar) {
+    extern __shared__ double kv_all[];  // [4][m]
+    const int lane = threadIdx.x & 63;
+    const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    if (wave >= nt) return;
+    const double* x = Xt + wave * ldx;
+    double* kv = kv_all + (threadIdx.x >> 6) * m;
+    double xn = 0;
+    for (int k = lane; k < ldx; k += 64) xn += x[k] * x[k];
+    xn = wave_sum(xn);
+    for (int r = 0; r < m; r++) {
+        const double* t = XT + (int64_t)r * ldx;
+        double dot = 0;
+        for (int k = lane; k < ldx; k += 64) dot += x[k] * t[k];
+        dot = wave_sum(dot);
+        if (lane == 0) kv[r] = var * exp((XTn[r] + xn - 2 * dot) / s);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    // forward substitution u = L^-1 k (serial over r, dot products across lanes)
+    double mu = 0, nrm = 0;
+    for (int r = 0; r < m; r++) {
+        double acc = 0;
+        for (int q = lane; q < r; q += 64) acc += L[(int64_t)r * ldl + q] * kv[q];
+        acc = wave_sum(acc);
+        double u = (kv[r] - acc) / L[(int64_t)r * ldl + r];
+        __builtin_amdgcn_wave_barrier();
+        if (lane == 0) kv[r] = u;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        mu += u * alpha[r];
+        nrm += u * u;
+    }
+    if (lane == 0) {
+        mean[wave] = mu;
+        if (pvar) pvar[wave] = fmax(0.0, var - nrm);
+    }
+}
+
+}  // namespace ital
+
+using namespace ital;
+
+extern "C" int ital_row_norms(const double* X, int64_t n, int ldx, double* xnorm, hipStream_t stream) {
+    if (n <= 0) return 0;
+    if (ldx % 16 != 0) return ital_fail(-22, "ital_row_norms: ldx must be a multiple of 16");
+    int64_t blocks = (n + 3) / 4;
+    if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(row_norms_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, X, n, ldx, xnorm);
+    return ital_check_launch("ital_row_norms");
+}
+
+static int launch_kcols(KcolsArgs& a, hipStream_t stream, const char* who) {
+    if (a.n <= 0) return 0;
+    if (a.ldx % 16 != 0) return ital_fail(-22, "kcols: ldx must be a multiple of 16");
+    if (a.c < 1 || a.c > 16) return ital_fail(-22, "kcols: c must be in 1..16");
+    if (a.m < 0 || (a.m > 0 && (!a.W || !a.V))) return ital_fail(-22, "kcols: W/V missing");
+    int64_t blocks = (a.n + 63) / 64;
+    hipLaunchKernelGGL(kcols_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, a);
+    return ital_check_launch(who);
+}
+
+extern "C" int ital_rbf_cols(const double* X, const double* xnorm, int64_t n, int ldx, const double* Xs,
+                             const double* sn, int c, double var, double length_scale, double* out, int64_t ldo,
+                             hipStream_t stream) {
+    KcolsArgs a = {};
+    a.X = X; a.xnorm = xnorm; a.n = n; a.ldx = ldx; a.Xs = Xs; a.sn = sn; a.c = c;
+    a.m = 0; a.var = var; a.s = -2.0 * length_scale * length_scale; a.mode = MODE_RAW; a.out = out; a.ldo = ldo;
+    return launch_kcols(a, stream, "ital_rbf_cols");
+}
+
+extern "C" int ital_cross_cov_cols(const double* X, const double* xnorm, int64_t n, int ldx, const double* Xs,
+                                   const double* sn, int c, const double* W, int ldw, const double* V, int64_t ldv,
+                                   int m, double var, double length_scale, double* out, int64_t ldo,
+                                   hipStream_t stream) {
+    KcolsArgs a = {};
+    a.X = X; a.xnorm = xnorm; a.n = n; a.ldx = ldx; a.Xs = Xs; a.sn = sn; a.c = c;
+    a.W = W; a.ldw = ldw; a.V = V; a.ldv = ldv; a.m = m;
+    a.var = var; a.s = -2.0 * length_scale * length_scale; a.mode = MODE_RAW; a.out = out; a.ldo = ldo;
+    return launch_kcols(a, stream, "ital_cross_cov_cols");
+}
+
+extern "C" int ital_whiten_append(const double* X, const double* xnorm, int64_t n, int ldx, const double* Xnew,
+                                  const double* snew, int c, const double* L21, int ldw, const double* L22,
+                                  const double* alpha_new, double* V, int64_t ldv, int m, double var,
+                                  double length_scale, double* mu, double* s2, hipStream_t stream) {
+    KcolsArgs a = {};
+    a.X = X; a.xnorm = xnorm; a.n = n; a.ldx = ldx; a.Xs = Xnew; a.sn = snew; a.c = c;
+    a.W = L21; a.ldw = ldw; a.V = V; a.Vw = V; a.ldv = ldv; a.m = m;
+    a.var = var; a.s = -2.0 * length_scale * length_scale; a.mode = MODE_WHITEN;
+    a.L22 = L22; a.alpha_new = alpha_new; a.mu = mu; a.s2 = s2;
+    return launch_kcols(a, stream, "ital_whiten_append");
+}
+
+extern "C" int ital_predict(const double* Xt, int64_t nt, int ldx, const double* XT, const double* XTn, int m,
+                            const double* L, int ldl, const double* alpha, double var, double length_scale,
+                            double* mean, double* pvar, hipStream_t stream) {
+    if (nt <= 0) return 0;
+    if (m <= 0) return ital_fail(-22, "ital_predict: GP is not fitted");
+    int64_t blocks = (nt + 3) / 4;
+    hipLaunchKernelGGL(predict_kernel, dim3((unsigned)blocks), dim3(256), (size_t)4 * m * sizeof(double), stream, Xt, nt,
+                       ldx, XT, XTn, m, L, ldl, alpha, var, -2.0 * length_scale * length_scale, mean, pvar);
+    return ital_check_launch("ital_predict");
+}

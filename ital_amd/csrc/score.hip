@@ -1,0 +1,519 @@
+// Mutual-information candidate scorer (reference ital/ital.py:183-224 `_call_iter_all`, :345-383 `prob_rel`,
+// :432-450 `updated_prob_rel`; perfect-user feedback model ital.py:313-315).
+//
+//   MI(i) = sum_{r in {F,T}^t} w(r) * ( log(p'(r) + eps) - log(p(r) + eps) )
+//     p (r) = P(sign pattern r) under N(mu_S, Sigma_S),  S = (batch so far, candidate i)   [natural order]
+//     p'(r) = same after a simulated GP update with the labels r                         [sorted by data index]
+//   label_estimation 'mean': w = p(r) and the terms are summed; 'optimistic': max term; 'pessimistic': min term.
+//
+// The simulated update is the closed form on the t x t block:
+//     A = Sigma + noise*I,  W = A^-1,  G = Sigma W = I - noise*W,  mu' = mu + G (f - mu),  Sigma' = noise*G.
+//
+//   t = 1 : Phi closed form                     (one thread per candidate, HBM-bound)
+//   t = 2 : Genz bivariate closed form          (one lane per (candidate, pattern))
+//   t >= 3: Genz MVNDST randomised Korobov lattice (one wave per candidate, lattice points across the 64 lanes,
+//           COVSRT variable re-ordering per call by one lane each, FP64-VALU bound).  The lattice shifts replay
+//           MVNUNI's stream at the offset the reference's *serial* loop would reach for this (candidate, pattern,
+//           call): jump-ahead by 3x3 matrix powers, so the scores - and the argmax - match the reference's.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "device_math.h"
+#include "ital_hip.h"
+#include "ital_internal.h"
+
+namespace ital {
+
+struct ScoreArgs {
+    int t;
+    int64_t n_cand;
+    const int32_t* cand;    // local row per list position
+    const uint8_t* alive;   // position still a candidate
+    const double* mu;       // [n_rows]
+    const double* s2;       // [n_rows] unclamped posterior variance
+    const double* C;        // [t-1][ldc] cross-covariance columns of the batch members
+    int64_t ldc;
+    int64_t row_offset;     // global data index of local row 0
+    int64_t pos_offset;     // global list position of local position 0
+    ital_batch b;
+    double noise, eps;
+    int label_mode;         // 0 mean, 1 optimistic, 2 pessimistic
+    double* mi;             // [n_cand]
+    // MVNUNI replay
+    int seed[6];            // generator state at the first call of this greedy step
+    const long long* jump;  // [48][18]: transition matrices for 2^b calls (of this step's dimension)
+    const double* vk;       // [t-1] Korobov generators
+    int* status;
+};
+
+__device__ __forceinline__ double log_eps(double p, double eps) { return log(p + eps); }
+
+__device__ __forceinline__ void mi_accumulate(double& mi, double pr, double pu, double eps, int mode) {
+    double cur = log_eps(pu, eps) - log_eps(pr, eps);  // perfect user: likelihood weight 1 (ital.py:208, fb_mc_num = 1)
+    if (mode == 1) {
+        if (cur > mi) mi = cur;
+    } else if (mode == 2) {
+        if (mi == 0 || cur < mi) mi = cur;
+    } else {
+        mi += cur * pr;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ t = 1
+__global__ __launch_bounds__(256) void score_t1_kernel(ScoreArgs a) {
+    int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= a.n_cand) return;
+    if (!a.alive[p]) return;
+    const int row = a.cand[p];
+    const double mu = a.mu[row];
+    const double su = a.s2[row];               // unclamped: what the simulated update sees (gp.py:334)
+    const double sc = fmax(0.0, su);           // clamped: predict_stored(cov_mode='diag') (gp.py:229, ital.py:558)
+    const double p_irr = norm_cdf0(mu, sqrt(sc));
+    const double w = 1.0 / (su + a.noise);
+    const double g = su * w;
+    const double s_upd = a.noise * g;
+    double mi = 0.0;
+#pragma unroll
+    for (int r = 0; r < 2; r++) {
+        const double f = r ? 1.0 : -1.0;
+        const double mu_upd = mu + g * (f - mu);
+        const double q = norm_cdf0(mu_upd, sqrt(s_upd));
+        const double pr = r ? 1.0 - p_irr : p_irr;
+        const double pu = r ? 1.0 - q : q;
+        mi_accumulate(mi, pr, pu, a.eps, a.label_mode);
+    }
+    a.mi[p] = mi;
+}
+
+// ------------------------------------------------------------------------------------------------ t = 2
+__global__ __launch_bounds__(256) void score_t2_kernel(ScoreArgs a) {
+    const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t p = gid >> 2;
+    const int r = (int)(gid & 3);  // pattern index in itertools.product order: bit1 = batch member, bit0 = candidate
+    const bool valid = p < a.n_cand && a.alive[p];
+    double pr = 0, pu = 1;
+    if (valid) {
+        const int row = a.cand[p];
+        const double m0 = a.b.bmu[0], m1 = a.mu[row];
+        const double s00 = a.b.sig[0], s11 = a.s2[row], s01 = a.C[row];
+        const bool rel0 = (r >> 1) & 1, rel1 = r & 1;
+        // prior
+        const double sd0 = sqrt(s00), sd1 = sqrt(s11);
+        pr = bvn_orthant(-m0 / sd0, -m1 / sd1, rel0, rel1, s01 / (sd0 * sd1));
+        // simulated update, closed form
+        const double a00 = s00 + a.noise, a11 = s11 + a.noise, a01 = s01;
+        const double det = a00 * a11 - a01 * a01;
+        const double w00 = a11 / det, w11 = a00 / det, w01 = -a01 / det;
+        const double g00 = 1.0 - a.noise * w00, g11 = 1.0 - a.noise * w11, g01 = -a.noise * w01;
+        const double f0 = rel0 ? 1.0 : -1.0, f1 = rel1 ? 1.0 : -1.0;
+        const double u0 = m0 + g00 * (f0 - m0) + g01 * (f1 - m1);
+        const double u1 = m1 + g01 * (f0 - m0) + g11 * (f1 - m1);
+        const double c00 = a.noise * g00, c11 = a.noise * g11, c01 = a.noise * g01;
+        const double t0 = sqrt(c00), t1 = sqrt(c11);
+        double h = -u0 / t0, k = -u1 / t1;
+        const double rho = c01 / (t0 * t1);
+        // variables sorted by data index (ital.py:448): symmetric for the closed form, kept for the bookkeeping
+        const int64_t gi = a.row_offset + row;
+        if (gi < a.b.bidx[0]) pu = bvn_orthant(k, h, rel1, rel0, rho);
+        else pu = bvn_orthant(h, k, rel0, rel1, rho);
+    }
+    // combine the four patterns in product order on the first lane of each quad
+    const int lane = threadIdx.x & 63;
+    const int base = lane & ~3;
+    double mi = 0.0;
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+        const double prq = __shfl(pr, base + q, 64);
+        const double puq = __shfl(pu, base + q, 64);
+        mi_accumulate(mi, prq, puq, a.eps, a.label_mode);
+    }
+    if (valid && r == 0) a.mi[p] = mi;
+}
+
+// ------------------------------------------------------------------------------------------------ t >= 3
+constexpr int P_TAB[10] = {31, 47, 73, 113, 173, 263, 397, 593, 907, 1361};
+
+template <int T>
+struct Qmc {
+    static constexpr int NDIM = T - 1;
+    static constexpr int NP = NDIM < 10 ? NDIM : 10;
+    static constexpr int PRIME = P_TAB[NP - 1];
+    static constexpr int NCOV = T * (T + 1) / 2;
+    static constexpr int SLAB_RAW = NCOV + 2 * T;            // packed factor, limits, expected values
+    static constexpr int SLAB = SLAB_RAW | 1;                 // odd stride: conflict-free per-lane slabs
+    static constexpr int NCALLS = 2 << T;                     // 2 * 2^T
+    static constexpr int CHUNK = T <= 5 ? (NCALLS < 64 ? NCALLS : 64) : 16;
+    static constexpr int NCOR = T * (T - 1) / 2;
+    // wave-shared candidate area (doubles): pivot, correl, mu0', G, sd', then ints perm
+    static constexpr int A_PIVOT = 0, A_COR = A_PIVOT + T, A_MU0 = A_COR + NCOR, A_G = A_MU0 + T, A_SD = A_G + T * T,
+                         A_SIZE = A_SD + T;
+    static constexpr int LAT = 8 * NDIM * 2;                  // per call: permuted generators + shifts, 8 shifts
+    static constexpr int WAVE_DOUBLES = CHUNK * SLAB + A_SIZE + LAT + NDIM + T;  // + running vk + perm
+};
+
+__device__ __forceinline__ int pidx(int i, int j) { return i * (i + 1) / 2 + j; }  // packed lower, 0-based, j <= i
+
+// Swap rows/columns p < q of the packed lower-triangular matrix, the limits and the limit-type bits (RCSWP).
+template <int T>
+__device__ void rcswp(int p, int q, double* cov, double* lim, unsigned& infi) {
+    double tmp = lim[p]; lim[p] = lim[q]; lim[q] = tmp;
+    unsigned bp = (infi >> p) & 1u, bq = (infi >> q) & 1u;
+    infi = (infi & ~((1u << p) | (1u << q))) | (bq << p) | (bp << q);
+    tmp = cov[pidx(p, p)]; cov[pidx(p, p)] = cov[pidx(q, q)]; cov[pidx(q, q)] = tmp;
+    for (int j = 0; j < p; j++) { tmp = cov[pidx(p, j)]; cov[pidx(p, j)] = cov[pidx(q, j)]; cov[pidx(q, j)] = tmp; }
+    for (int i = p + 1; i < q; i++) { tmp = cov[pidx(i, p)]; cov[pidx(i, p)] = cov[pidx(q, i)]; cov[pidx(q, i)] = tmp; }
+    for (int i = q + 1; i < T; i++) { tmp = cov[pidx(i, p)]; cov[pidx(i, p)] = cov[pidx(i, q)]; cov[pidx(i, q)] = tmp; }
+}
+
+// COVSRT: order the variables by increasing expected interval probability, build the (row-scaled) Cholesky factor.
+// Limit types are one-sided here (bit = 1: [lim, inf), bit = 0: (-inf, lim]).  Returns false on a singular factor.
+template <int T>
+__device__ bool covsrt(double* cov, double* lim, double* y, unsigned& infi) {
+    const double SQTWPI = 2.506628274631001, EPS = 1e-10;
+    bool ok = true;
+    for (int i = 0; i < T; i++) {
+        double dmin = 0, emin = 1, zmin = 0, cvdiag = 0;
+        int jmin = i;
+        for (int j = i; j < T; j++) {
+            const double cjj = cov[pidx(j, j)];
+            if (cjj > EPS) {
+                const double sumsq = sqrt(cjj);
+                double sum = 0;
+                for (int k = 0; k < i; k++) sum += cov[pidx(j, k)] * y[k];
+                const double z = (lim[j] - sum) / sumsq;
+                const double ph = mvn_phi(z);
+                const bool lower = (infi >> j) & 1u;
+                const double d = lower ? ph : 0.0;
+                const double e = lower ? 1.0 : fmax(ph, 0.0);
+                if (emin + d >= e + dmin) { jmin = j; zmin = z; dmin = d; emin = e; cvdiag = sumsq; }
+            }
+        }
+        if (jmin > i) rcswp<T>(i, jmin, cov, lim, infi);
+        cov[pidx(i, i)] = cvdiag;
+        if (cvdiag > 0) {
+            for (int l = i + 1; l < T; l++) {
+                cov[pidx(l, i)] = cov[pidx(l, i)] / cvdiag;
+                for (int j = i + 1; j <= l; j++) cov[pidx(l, j)] -= cov[pidx(l, i)] * cov[pidx(j, i)];
+            }
+            const bool lower = (infi >> i) & 1u;
+            if (emin > dmin + EPS) {
+                const double dens = -exp(-zmin * zmin / 2) / SQTWPI;
+                const double yl = lower ? dens : 0.0, yu = lower ? 0.0 : dens;
+                y[i] = (yu - yl) / (emin - dmin);
+            } else {
+                y[i] = zmin;
+            }
+            for (int j = 0; j <= i; j++) cov[pidx(i, j)] = cov[pidx(i, j)] / cvdiag;
+            lim[i] = lim[i] / cvdiag;
+        } else {
+            ok = false;
+            y[i] = 0;
+        }
+    }
+    return ok;
+}
+
+template <int T>
+__global__ __launch_bounds__(256) void score_qmc_kernel(ScoreArgs a) {
+    using Q = Qmc<T>;
+    extern __shared__ double lds_all[];
+    const int lane = threadIdx.x & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int64_t p = (int64_t)blockIdx.x * 4 + wid;  // list position handled by this wave
+    if (p >= a.n_cand) return;
+    if (!a.alive[p]) return;
+    double* W = lds_all + (size_t)wid * Q::WAVE_DOUBLES;
+    double* slabs = W;
+    double* area = W + Q::CHUNK * Q::SLAB;
+    double* lat = area + Q::A_SIZE;          // [8][NDIM] generators, then [8][NDIM] shifts
+    double* vkrun = lat + Q::LAT;            // running (shuffled) generator vector
+    int* perm = reinterpret_cast<int*>(vkrun + Q::NDIM);  // T ints: natural index held at each sorted slot
+
+    const int row = a.cand[p];
+    const int64_t gi = a.row_offset + row;
+
+    // ---------------- Phase A: candidate-level quantities (identical in every lane)
+    {
+        double mean[T], Sg[T][T];
+#pragma unroll
+        for (int i = 0; i < T - 1; i++) {
+            mean[i] = a.b.bmu[i];
+#pragma unroll
+            for (int j = 0; j < T - 1; j++) Sg[i][j] = a.b.sig[i * a.b.kmax + j];
+            const double c = a.C[(int64_t)i * a.ldc + row];
+            Sg[i][T - 1] = c;
+            Sg[T - 1][i] = c;
+        }
+        mean[T - 1] = a.mu[row];
+        Sg[T - 1][T - 1] = a.s2[row];  // not clamped (gp.py:254)
+        double sd[T];
+#pragma unroll
+        for (int i = 0; i < T; i++) {
+            sd[i] = sqrt(Sg[i][i]);
+            area[Q::A_PIVOT + i] = -mean[i] / sd[i];
+        }
+#pragma unroll
+        for (int i = 1; i < T; i++)
+#pragma unroll
+            for (int j = 0; j < i; j++) area[Q::A_COR + i * (i - 1) / 2 + j] = Sg[i][j] / (sd[i] * sd[j]);
+        // W = (Sigma + noise I)^-1 through its Cholesky factor, G = I - noise W
+        double Lc[T][T];
+#pragma unroll
+        for (int i = 0; i < T; i++)
+#pragma unroll
+            for (int j = 0; j <= i; j++) {
+                double v = Sg[i][j] + (i == j ? a.noise : 0.0);
+#pragma unroll
+                for (int q = 0; q < j; q++) v -= Lc[i][q] * Lc[j][q];
+                Lc[i][j] = (i == j) ? sqrt(v) : v / Lc[j][j];
+            }
+        double Li[T][T];  // inverse of the factor (lower)
+#pragma unroll
+        for (int j = 0; j < T; j++) {
+#pragma unroll
+            for (int i = 0; i < T; i++) {
+                if (i < j) { Li[i][j] = 0; continue; }
+                double v = (i == j) ? 1.0 : 0.0;
+#pragma unroll
+                for (int q = j; q < i; q++) v -= Lc[i][q] * Li[q][j];
+                Li[i][j] = v / Lc[i][i];
+            }
+        }
+        double G[T][T];
+#pragma unroll
+        for (int i = 0; i < T; i++)
+#pragma unroll
+            for (int j = 0; j <= i; j++) {
+                double w = 0;
+#pragma unroll
+                for (int q = i; q < T; q++) w += Li[q][i] * Li[q][j];
+                const double gij = (i == j ? 1.0 : 0.0) - a.noise * w;
+                G[i][j] = gij;
+                G[j][i] = gij;
+            }
+#pragma unroll
+        for (int i = 0; i < T; i++) {
+            double gm = 0;
+#pragma unroll
+            for (int j = 0; j < T; j++) {
+                gm += G[i][j] * mean[j];
+                area[Q::A_G + i * T + j] = G[i][j];
+            }
+            area[Q::A_MU0 + i] = mean[i] - gm;
+            area[Q::A_SD + i] = sqrt(a.noise * G[i][i]);
+        }
+        // sorted-by-data-index order of (batch members, candidate)
+        int rank = 0;
+#pragma unroll
+        for (int i = 0; i < T - 1; i++) rank += (a.b.bidx[i] < gi) ? 1 : 0;
+#pragma unroll
+        for (int s = 0; s < T; s++) {
+            int src;
+            if (s < rank) src = a.b.bsort[s];
+            else if (s == rank) src = T - 1;
+            else src = a.b.bsort[s - 1];
+            perm[s] = src;
+        }
+    }
+    // ---------------- stream position of this candidate: rank among the positions still alive
+    MrgState rng = {a.seed[0], a.seed[1], a.seed[2], a.seed[3], a.seed[4], a.seed[5]};
+    {
+        int64_t gpos = a.pos_offset + p;
+        int64_t before = gpos;
+        for (int i = 0; i < T - 1; i++) before -= (a.b.bgpos[i] < gpos) ? 1 : 0;
+        uint64_t calls_before = (uint64_t)before * (uint64_t)Q::NCALLS;
+        for (int bit = 0; calls_before != 0; bit++, calls_before >>= 1)
+            if (calls_before & 1) mrg_apply(rng, a.jump + bit * 18);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+
+    double mi = 0.0;
+    double pr_cur = 0.0;
+    for (int chunk = 0; chunk < Q::NCALLS; chunk += Q::CHUNK) {
+        // ---------------- Phase B: lane l prepares call chunk + l (limits, pattern bits, COVSRT) in its LDS slab
+        bool sat = false, okc = true;
+        unsigned infi = 0;
+        if (lane < Q::CHUNK) {
+            const int call = chunk + lane;
+            const int r = call >> 1;
+            double* cov = slabs + lane * Q::SLAB;
+            double* lim = cov + Q::NCOV;
+            double* y = lim + T;
+            if ((call & 1) == 0) {
+                for (int i = 0; i < T; i++) {
+                    lim[i] = area[Q::A_PIVOT + i];
+                    infi |= (unsigned)((r >> (T - 1 - i)) & 1) << i;
+                    for (int j = 0; j < i; j++) cov[pidx(i, j)] = area[Q::A_COR + i * (i - 1) / 2 + j];
+                    cov[pidx(i, i)] = 1.0;
+                }
+            } else {
+                for (int s = 0; s < T; s++) {
+                    const int nat = perm[s];
+                    double mu_u = area[Q::A_MU0 + nat];
+                    for (int j = 0; j < T; j++) {
+                        const double f = ((r >> (T - 1 - j)) & 1) ? 1.0 : -1.0;
+                        mu_u += area[Q::A_G + nat * T + j] * f;
+                    }
+                    const double sds = area[Q::A_SD + nat];
+                    lim[s] = -mu_u / sds;
+                    infi |= (unsigned)((r >> (T - 1 - nat)) & 1) << s;
+                    for (int s2 = 0; s2 < s; s2++) {
+                        const int nat2 = perm[s2];
+                        cov[pidx(s, s2)] = (a.noise * area[Q::A_G + nat * T + nat2]) / (sds * area[Q::A_SD + nat2]);
+                    }
+                    cov[pidx(s, s)] = 1.0;
+                }
+            }
+            okc = covsrt<T>(cov, lim, y, infi);
+            // integrand identically 1?  every conditional limit stays beyond +-37 for any |y| <= 9
+            sat = okc;
+            for (int i = 0; i < T; i++) {
+                double bound = 0;
+                for (int j = 0; j < i; j++) bound += fabs(cov[pidx(i, j)]) * 9.0;
+                const bool lower = (infi >> i) & 1u;
+                if (lower) { if (!(lim[i] + bound < -37.0)) sat = false; }
+                else { if (!(lim[i] - bound > 37.0)) sat = false; }
+            }
+        }
+        if (!okc) atomicOr(a.status, 2);  // singular conditional covariance: not supported by this kernel
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+
+        // ---------------- Phase C: the wave evaluates the calls of this chunk one after the other
+        for (int cl = 0; cl < Q::CHUNK; cl++) {
+            const int call = chunk + cl;
+            const bool sat_c = __shfl((int)sat, cl, 64) != 0;
+            const unsigned infi_c = (unsigned)__shfl((int)infi, cl, 64);
+            double value;
+            if (sat_c) {
+                value = 1.0;
+                mrg_apply(rng, a.jump);  // skip this call's draws
+            } else {
+                // lattice generators for this dimension (floating-point Korobov recurrence, as SciPy's mvndst.f)
+                // and the 8 random shifts; every lane computes the same values
+                for (int j = 0; j < Q::NDIM; j++) vkrun[j] = a.vk[j];
+                for (int sft = 0; sft < 8; sft++) {
+                    for (int j = 1; j <= Q::NDIM - 1; j++) {
+                        const double u = mrg_next(rng);
+                        const int jp = (int)(j + u * (Q::NDIM + 1 - j));
+                        const double xt = vkrun[j - 1];
+                        vkrun[j - 1] = vkrun[jp - 1];
+                        vkrun[jp - 1] = xt;
+                    }
+                    for (int j = 0; j < Q::NDIM; j++) lat[sft * Q::NDIM + j] = vkrun[j];
+                    for (int j = 0; j < Q::NDIM; j++) lat[8 * Q::NDIM + sft * Q::NDIM + j] = mrg_next(rng);
+                }
+                // per-call constants out of the preparing lane's slab
+                const double* cov = slabs + cl * Q::SLAB;
+                double cf[Q::NCOV > 1 ? Q::NCOR : 1], lm[T];
+#pragma unroll
+                for (int i = 0; i < T; i++) {
+                    lm[i] = cov[Q::NCOV + i];
+#pragma unroll
+                    for (int j = 0; j < i; j++) cf[i * (i - 1) / 2 + j] = cov[pidx(i, j)];
+                }
+                double acc = 0.0;
+                for (int item = lane; item < 8 * Q::PRIME; item += 64) {
+                    const int sft = item / Q::PRIME;
+                    const int k = item - sft * Q::PRIME + 1;
+                    double x0[Q::NDIM], x1[Q::NDIM];
+#pragma unroll
+                    for (int j = 0; j < Q::NDIM; j++) {
+                        const double v = k * lat[sft * Q::NDIM + j] + lat[8 * Q::NDIM + sft * Q::NDIM + j];
+                        const double fr = v - floor(v);
+                        x0[j] = fabs(2 * fr - 1);
+                        x1[j] = 1 - x0[j];
+                    }
+                    // MVNDFN on the point and its antithetic partner, interleaved for ILP
+                    double f0 = 1.0, f1 = 1.0, y0[T], y1[T];
+                    bool z0 = false, z1 = false;
+#pragma unroll
+                    for (int i = 0; i < T; i++) {
+                        double s0 = 0, s1 = 0;
+#pragma unroll
+                        for (int j = 0; j < i; j++) {
+                            s0 += cf[i * (i - 1) / 2 + j] * y0[j];
+                            s1 += cf[i * (i - 1) / 2 + j] * y1[j];
+                        }
+                        const bool lower = (infi_c >> i) & 1u;
+                        const double p0 = mvn_phi(lm[i] - s0), p1 = mvn_phi(lm[i] - s1);
+                        const double d0 = lower ? p0 : 0.0, d1 = lower ? p1 : 0.0;
+                        const double w0 = lower ? 1.0 - p0 : p0, w1 = lower ? 1.0 - p1 : p1;
+                        z0 = z0 || !(w0 > 0);
+                        z1 = z1 || !(w1 > 0);
+                        f0 *= w0;
+                        f1 *= w1;
+                        if (i < T - 1) {
+                            y0[i] = mvn_phinv(d0 + x0[i] * w0);
+                            y1[i] = mvn_phinv(d1 + x1[i] * w1);
+                        }
+                    }
+                    acc += (z0 ? 0.0 : f0) + (z1 ? 0.0 : f1);
+                }
+                value = wave_sum(acc) / (16.0 * Q::PRIME);
+            }
+            if ((call & 1) == 0) {
+                pr_cur = value;
+            } else {
+                mi_accumulate(mi, pr_cur, value, a.eps, a.label_mode);
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
+    if (lane == 0) a.mi[p] = mi;
+}
+
+template <int T>
+static int launch_qmc(const ScoreArgs& a, hipStream_t stream) {
+    using Q = Qmc<T>;
+    const size_t lds = (size_t)4 * Q::WAVE_DOUBLES * sizeof(double);
+    const int64_t blocks = (a.n_cand + 3) / 4;
+    static bool attr_done = false;
+    if (!attr_done && lds > 48 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&score_qmc_kernel<T>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return ital_fail(-12, "score_qmc: cannot raise the dynamic LDS limit");
+        attr_done = true;
+    }
+    hipLaunchKernelGGL(score_qmc_kernel<T>, dim3((unsigned)blocks), dim3(256), lds, stream, a);
+    return ital_check_launch("ital_score_step(qmc)");
+}
+
+}  // namespace ital
+
+using namespace ital;
+
+extern "C" int ital_score_step(const ital_score_desc* d, hipStream_t stream) {
+    if (!d) return ital_fail(-22, "ital_score_step: null descriptor");
+    if (d->n_cand <= 0) return 0;
+    if (d->t < 1 || d->t > ITAL_MAX_T) return ital_fail(-22, "ital_score_step: batch dimension outside 1..ITAL_MAX_T");
+    if (d->t > d->batch.kmax) return ital_fail(-22, "ital_score_step: t exceeds the batch capacity");
+    ScoreArgs a = {};
+    a.t = d->t; a.n_cand = d->n_cand; a.cand = d->cand; a.alive = d->alive; a.mu = d->mu; a.s2 = d->s2; a.C = d->C;
+    a.ldc = d->ldc; a.row_offset = d->row_offset; a.pos_offset = d->pos_offset; a.b = d->batch; a.noise = d->noise;
+    a.eps = d->eps; a.label_mode = d->label_mode; a.mi = d->mi; a.jump = d->jump; a.vk = d->vk; a.status = d->status;
+    for (int i = 0; i < 6; i++) a.seed[i] = d->seed[i];
+    if (d->t == 1) {
+        hipLaunchKernelGGL(score_t1_kernel, dim3((unsigned)((d->n_cand + 255) / 256)), dim3(256), 0, stream, a);
+        return ital_check_launch("ital_score_step(t=1)");
+    }
+    if (d->t == 2) {
+        hipLaunchKernelGGL(score_t2_kernel, dim3((unsigned)((d->n_cand * 4 + 255) / 256)), dim3(256), 0, stream, a);
+        return ital_check_launch("ital_score_step(t=2)");
+    }
+    if (!d->jump || !d->vk) return ital_fail(-22, "ital_score_step: jump table / generators missing for t >= 3");
+    switch (d->t) {
+        case 3: return launch_qmc<3>(a, stream);
+        case 4: return launch_qmc<4>(a, stream);
+        case 5: return launch_qmc<5>(a, stream);
+        case 6: return launch_qmc<6>(a, stream);
+        case 7: return launch_qmc<7>(a, stream);
+        case 8: return launch_qmc<8>(a, stream);
+    }
+    return ital_fail(-22, "ital_score_step: unsupported batch dimension");
+}

@@ -1,0 +1,195 @@
+// Arg-extreme over the scored candidates and the batch bookkeeping of a greedy step (role R9/R10).
+//
+// np.argmax / np.argmin semantics of the reference (ital/ital.py:130, ital/mcmi.py:77): the FIRST extreme in
+// candidate-list order wins, and a NaN beats every number (first NaN wins).  Each rank reduces its own live
+// positions and packs a fixed-size record (score, list position, data index, mean, variance, the feature row,
+// the whitened column and the cross-covariances with the members so far); after the records of all ranks have
+// been gathered, every rank runs the same resolve step and appends the winner to the replicated batch state.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "device_math.h"
+#include "ital_hip.h"
+#include "ital_internal.h"
+
+namespace ital {
+
+struct Best {
+    double val;
+    int64_t pos;  // global list position, < 0: nothing
+};
+
+// true if a precedes b under "first extreme, NaN wins"
+__device__ __forceinline__ bool better(const Best& a, const Best& b, int mode) {
+    if (a.pos < 0) return false;
+    if (b.pos < 0) return true;
+    const bool an = isnan(a.val), bn = isnan(b.val);
+    if (an != bn) return an;
+    if (an) return a.pos < b.pos;
+    if (a.val != b.val) return mode == 0 ? a.val > b.val : a.val < b.val;
+    return a.pos < b.pos;
+}
+
+__device__ __forceinline__ Best wave_best(Best v, int mode) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        Best o;
+        o.val = __shfl_xor(v.val, off, 64);
+        o.pos = __shfl_xor(v.pos, off, 64);
+        if (better(o, v, mode)) v = o;
+    }
+    return v;
+}
+
+__device__ Best block_best(Best v, int mode) {
+    __shared__ double sval[16];
+    __shared__ int64_t spos[16];
+    v = wave_best(v, mode);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    __syncthreads();
+    if (lane == 0) { sval[wave] = v.val; spos[wave] = v.pos; }
+    __syncthreads();
+    Best r = {0.0, -1};
+    if (wave == 0) {
+        if (lane < nw) { r.val = sval[lane]; r.pos = spos[lane]; }
+        r = wave_best(r, mode);
+    }
+    return r;  // valid in wave 0
+}
+
+__global__ __launch_bounds__(256) void select_partial_kernel(const double* __restrict__ mi, const uint8_t* __restrict__ alive,
+                                                             int64_t n_cand, int64_t pos_offset, int mode,
+                                                             double* __restrict__ work) {
+    Best v = {0.0, -1};
+    for (int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < n_cand; p += (int64_t)gridDim.x * blockDim.x) {
+        if (!alive[p]) continue;
+        Best c = {mi[p], pos_offset + p};
+        if (better(c, v, mode)) v = c;
+    }
+    v = block_best(v, mode);
+    if (threadIdx.x == 0) {
+        work[2 * blockIdx.x] = v.val;
+        work[2 * blockIdx.x + 1] = (double)v.pos;
+    }
+}
+
+struct RecordArgs {
+    const int32_t* cand; int64_t pos_offset, row_offset; int rank, mode, nparts;
+    const double *mu, *s2, *X, *xnorm; int ldx; const double* V; int64_t ldv; int m, ldw;
+    const double* C; int64_t ldc; int nprev, kmax;
+    const double* work; double* record;
+};
+
+__global__ __launch_bounds__(256) void select_record_kernel(RecordArgs a) {
+    __shared__ int64_t s_pos;
+    __shared__ double s_val;
+    Best v = {0.0, -1};
+    for (int i = threadIdx.x; i < a.nparts; i += blockDim.x) {
+        Best c = {a.work[2 * i], (int64_t)a.work[2 * i + 1]};
+        if (better(c, v, a.mode)) v = c;
+    }
+    v = block_best(v, a.mode);
+    if (threadIdx.x == 0) { s_pos = v.pos; s_val = v.val; }
+    __syncthreads();
+    const int64_t gpos = s_pos;
+    double* rec = a.record;
+    const int rec_len = ITAL_REC_HEADER + a.ldx + a.ldw + a.kmax;
+    if (gpos < 0) {
+        for (int i = threadIdx.x; i < rec_len; i += blockDim.x) rec[i] = (i == 1) ? -1.0 : 0.0;
+        return;
+    }
+    const int64_t lp = gpos - a.pos_offset;
+    const int row = a.cand[lp];
+    if (threadIdx.x == 0) {
+        rec[0] = s_val;
+        rec[1] = (double)gpos;
+        rec[2] = (double)(a.row_offset + row);
+        rec[3] = a.mu[row];
+        rec[4] = a.s2[row];
+        rec[5] = a.xnorm[row];
+        rec[6] = (double)a.rank;
+        rec[7] = (double)lp;
+    }
+    for (int k = threadIdx.x; k < a.ldx; k += blockDim.x) rec[ITAL_REC_HEADER + k] = a.X[(int64_t)row * a.ldx + k];
+    for (int r = threadIdx.x; r < a.ldw; r += blockDim.x)
+        rec[ITAL_REC_HEADER + a.ldx + r] = r < a.m ? a.V[(int64_t)r * a.ldv + row] : 0.0;
+    for (int b = threadIdx.x; b < a.kmax; b += blockDim.x)
+        rec[ITAL_REC_HEADER + a.ldx + a.ldw + b] = b < a.nprev ? a.C[(int64_t)b * a.ldc + row] : 0.0;
+}
+
+__global__ __launch_bounds__(256) void select_resolve_kernel(const double* __restrict__ records, int world, int rec_len,
+                                                             int rank, int mode, int slot, ital_batch b,
+                                                             uint8_t* __restrict__ alive, int64_t* __restrict__ ret) {
+    __shared__ int s_win;
+    if (threadIdx.x == 0) {
+        Best v = {0.0, -1};
+        int win = -1;
+        for (int w = 0; w < world; w++) {
+            const double* r = records + (int64_t)w * rec_len;
+            Best c = {r[0], (int64_t)r[1]};
+            if (better(c, v, mode)) { v = c; win = w; }
+        }
+        s_win = win;
+    }
+    __syncthreads();
+    const int win = s_win;
+    if (win < 0) {
+        if (threadIdx.x == 0) ret[slot] = -1;
+        return;
+    }
+    const double* r = records + (int64_t)win * rec_len;
+    const int64_t gidx = (int64_t)r[2];
+    if (threadIdx.x == 0) {
+        b.bidx[slot] = gidx;
+        b.bgpos[slot] = (int64_t)r[1];
+        b.bmu[slot] = r[3];
+        b.XBn[slot] = r[5];
+        b.sig[slot * b.kmax + slot] = r[4];
+        for (int q = 0; q < slot; q++) {
+            const double c = r[ITAL_REC_HEADER + b.ldx + b.ldw + q];
+            b.sig[slot * b.kmax + q] = c;
+            b.sig[q * b.kmax + slot] = c;
+        }
+        // insert the new member into the order-by-data-index list
+        int at = slot;
+        while (at > 0 && b.bidx[b.bsort[at - 1]] > gidx) { b.bsort[at] = b.bsort[at - 1]; at--; }
+        b.bsort[at] = slot;
+        ret[slot] = gidx;
+        if ((int)r[6] == rank) alive[(int64_t)r[7]] = 0;
+    }
+    for (int k = threadIdx.x; k < b.ldx; k += blockDim.x) b.XB[(int64_t)slot * b.ldx + k] = r[ITAL_REC_HEADER + k];
+    for (int q = threadIdx.x; q < b.ldw; q += blockDim.x) b.VB[(int64_t)slot * b.ldw + q] = r[ITAL_REC_HEADER + b.ldx + q];
+}
+
+}  // namespace ital
+
+using namespace ital;
+
+extern "C" int ital_select_local(const double* mi, const int32_t* cand, const uint8_t* alive, int64_t n_cand,
+                                 int64_t pos_offset, int64_t row_offset, int rank, int mode, const double* mu,
+                                 const double* s2, const double* X, const double* xnorm, int ldx, const double* V,
+                                 int64_t ldv, int m, int ldw, const double* C, int64_t ldc, int nprev, int kmax,
+                                 double* work, double* record, hipStream_t stream) {
+    if (mode != 0 && mode != 1) return ital_fail(-22, "ital_select_local: mode must be 0 (argmax) or 1 (argmin)");
+    if (m > ldw) return ital_fail(-22, "ital_select_local: m exceeds ldw");
+    int nparts = (int)((n_cand + 255) / 256);
+    if (nparts > 1024) nparts = 1024;
+    if (nparts < 1) nparts = 1;
+    hipLaunchKernelGGL(select_partial_kernel, dim3(nparts), dim3(256), 0, stream, mi, alive, n_cand, pos_offset, mode, work);
+    int rc = ital_check_launch("ital_select_local(partial)");
+    if (rc) return rc;
+    RecordArgs a = {cand, pos_offset, row_offset, rank, mode, nparts, mu, s2, X, xnorm, ldx, V, ldv, m, ldw,
+                    C, ldc, nprev, kmax, work, record};
+    hipLaunchKernelGGL(select_record_kernel, dim3(1), dim3(256), 0, stream, a);
+    return ital_check_launch("ital_select_local(record)");
+}
+
+extern "C" int ital_select_resolve(const double* records, int world, int rec_len, int rank, int mode, int slot,
+                                   ital_batch batch, uint8_t* alive, int64_t* ret, hipStream_t stream) {
+    if (slot < 0 || slot >= batch.kmax) return ital_fail(-22, "ital_select_resolve: slot outside the batch capacity");
+    if (rec_len != ITAL_REC_HEADER + batch.ldx + batch.ldw + batch.kmax)
+        return ital_fail(-22, "ital_select_resolve: record length does not match the batch layout");
+    hipLaunchKernelGGL(select_resolve_kernel, dim3(1), dim3(256), 0, stream, records, world, rec_len, rank, mode, slot,
+                       batch, alive, ret);
+    return ital_check_launch("ital_select_resolve");
+}

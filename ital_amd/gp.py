@@ -1,0 +1,271 @@
+"""Streaming Gaussian process on MI355X: host-side mirror of reference ital/gp.py `GaussianProcess`.
+
+Same public surface for the hot path (fit / update / reset / predict_stored / predict, attributes
+ind, y, X, length_scale, var, noise) but a different state: the reference stores the dense N x N kernel
+`K_all` (gp.py:128) and an explicit inverse re-computed at every update (gp.py:194); this class keeps, per
+GPU, the row shard of X and the Cholesky-whitened block
+
+    L L^T = K[T,T] + noise*I,   V = L^-1 K[T,:]  (m x n, one contiguous n-vector per labelled point),
+    mu = V^T alpha (alpha = L^-1 y),   s2 = var - colsum(V^2)          
+
+so an update appends c rows (rank-c Cholesky append) and N never appears squared.  All arithmetic runs in
+the HIP kernels of libital_hip.so; torch only owns the device buffers and the stream.
+"""
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import check
+
+
+def _pad16(v):
+    return (int(v) + 15) // 16 * 16
+
+
+def _ptr(t):
+    return 0 if t is None else t.data_ptr()
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+class GaussianProcess(object):
+    """GP on a row shard of `data` (rows [row0, row1) on this rank).
+
+    # Arguments (as reference ital/gp.py:103-120, plus keyword-only placement):
+    - data: n-by-d array of all samples.
+    - length_scale, var, noise: kernel hyper-parameters.
+    - device: torch device of this rank.
+    - rank / world / group: row sharding over `world` processes (torch.distributed group for the exchange).
+    """
+
+    def __init__(self, data, length_scale, var=1.0, noise=1e-6, pdist=None, *, device=None, rank=0, world=1,
+                 group=None, capacity=64):
+        if pdist is not None:
+            raise NotImplementedError("pre-computed distances are a dense-kernel feature of the reference (gp.py:116-128)")
+        if not torch.cuda.is_available():
+            raise RuntimeError("ital_amd.GaussianProcess needs a HIP device (no CPU fallback)")
+        self._lib = _lib.lib()
+        self.device = torch.device(device if device is not None else "cuda:0")
+        self.rank, self.world, self.group = int(rank), int(world), group
+        data = np.asarray(data, dtype=np.float64)
+        if data.ndim != 2:
+            raise ValueError("data must be an n-by-d array")
+        self.n_total, self.d = data.shape
+        self.row0 = self.n_total * self.rank // self.world
+        self.row1 = self.n_total * (self.rank + 1) // self.world
+        self.n = self.row1 - self.row0
+        self.ldx = _pad16(self.d)
+        self.ldv = _pad16(max(self.n, 1))
+        self.length_scale = length_scale
+        self.length_scale_sq = length_scale * length_scale
+        self.var = var
+        self.noise = noise
+        self.X_host = data  # the reference keeps a copy too (gp.py:122)
+        with torch.cuda.device(self.device):
+            Xp = torch.zeros((max(self.n, 1), self.ldx), dtype=torch.float64, device=self.device)
+            if self.n:
+                Xp[: self.n, : self.d] = torch.from_numpy(np.ascontiguousarray(data[self.row0:self.row1])).to(self.device)
+            self.Xd = Xp
+            self.xnorm = torch.empty(max(self.n, 1), dtype=torch.float64, device=self.device)
+            check(self._lib.ital_row_norms(_ptr(self.Xd), self.n, self.ldx, _ptr(self.xnorm), _stream()))
+            self.status = torch.zeros(1, dtype=torch.int32, device=self.device)
+            self._alloc(capacity)
+        self.reset()
+
+    # ------------------------------------------------------------------ storage
+    def _alloc(self, cap):
+        cap = _pad16(cap)
+        dev = self.device
+        old = getattr(self, "cap", 0)
+        V = torch.zeros((cap, self.ldv), dtype=torch.float64, device=dev)
+        L = torch.zeros((cap, cap), dtype=torch.float64, device=dev)
+        alpha = torch.zeros(cap, dtype=torch.float64, device=dev)
+        XT = torch.zeros((cap, self.ldx), dtype=torch.float64, device=dev)
+        XTn = torch.zeros(cap, dtype=torch.float64, device=dev)
+        if old:
+            V[:old] = self.V
+            L[:old, :old] = self.L
+            alpha[:old] = self.alpha
+            XT[:old] = self.XT
+            XTn[:old] = self.XTn
+        self.V, self.L, self.alpha, self.XT, self.XTn, self.cap = V, L, alpha, XT, XTn, cap
+
+    @property
+    def X(self):
+        return self.X_host
+
+    @property
+    def K_all(self):
+        raise AttributeError("the dense N x N kernel matrix is never formed by ital_amd (reference gp.py:128 is "
+                             "replaced by column streaming); use rbf_cols()")
+
+    def reset(self):
+        """Back to the state right after __init__ (reference gp.py:132-138)."""
+        self.ind = []
+        self.y = None
+        self.m = 0
+        self.mu = torch.zeros(max(self.n, 1), dtype=torch.float64, device=self.device)
+        self.s2 = torch.full((max(self.n, 1),), float(self.var), dtype=torch.float64, device=self.device)
+        self.status.zero_()
+
+    # ------------------------------------------------------------------ fitting
+    def fit(self, ind, y):
+        """Fits to a subset of the data (reference gp.py:141-161)."""
+        self.reset()
+        return self.update(ind, y)
+
+    def update(self, ind, y):
+        """Adds labelled samples (reference gp.py:164-200), as a rank-c Cholesky append."""
+        ind = [int(i) for i in ind]
+        y = np.asarray(y, dtype=np.float64).reshape(-1)
+        if len(ind) != len(y):
+            raise ValueError("ind and y differ in length")
+        if len(ind) == 0:
+            return self
+        rows = self._gather_rows(ind)
+        self._append(rows, y)
+        self.ind += ind
+        self.y = y.copy() if self.y is None else np.concatenate((self.y, y))
+        return self
+
+    def update_points(self, points, y, ind=None):
+        """Adds labelled feature vectors that are not rows of the data matrix (the reference appends queries as
+        extra rows, ital/retrieval_base.py:40,56-58)."""
+        pts = np.atleast_2d(np.asarray(points, dtype=np.float64))
+        y = np.asarray(y, dtype=np.float64).reshape(-1)
+        rows = torch.zeros((len(pts), self.ldx), dtype=torch.float64, device=self.device)
+        rows[:, : self.d] = torch.from_numpy(np.ascontiguousarray(pts)).to(self.device)
+        self._append(rows, y)
+        self.ind += list(ind) if ind is not None else list(range(self.n_total + self.m - len(y), self.n_total + self.m))
+        self.y = y.copy() if self.y is None else np.concatenate((self.y, y))
+        return self
+
+    def _gather_rows(self, ind):
+        """Feature rows of global indices, replicated on every rank (owners contribute, the rest adds zeros)."""
+        idx = torch.as_tensor(ind, dtype=torch.int64, device=self.device)
+        rows = torch.zeros((len(ind), self.ldx), dtype=torch.float64, device=self.device)
+        own = (idx >= self.row0) & (idx < self.row1)
+        if bool(own.any()):
+            rows[own] = self.Xd.index_select(0, idx[own] - self.row0)
+        if self.world > 1:
+            import torch.distributed as dist
+            dist.all_reduce(rows, op=dist.ReduceOp.SUM, group=self.group)
+        return rows
+
+    def _append(self, rows, y):
+        lib, st = self._lib, _stream()
+        c_total = rows.shape[0]
+        if self.m + c_total > self.cap:
+            self._alloc(max(2 * self.cap, self.m + c_total))
+        yd = torch.from_numpy(np.ascontiguousarray(y)).to(self.device)
+        for c0 in range(0, c_total, 16):
+            c = min(16, c_total - c0)
+            m = self.m
+            self.XT[m:m + c] = rows[c0:c0 + c]
+            check(lib.ital_row_norms(_ptr(self.XT[m:m + c]), c, self.ldx, _ptr(self.XTn[m:m + c]), st))
+            check(lib.ital_chol_append(_ptr(self.XT), _ptr(self.XTn), self.ldx, _ptr(self.L), self.cap, _ptr(self.alpha),
+                                       _ptr(yd[c0:c0 + c]), m, c, float(self.var), float(self.length_scale),
+                                       float(self.noise), _ptr(self.status), st))
+            L21 = self.L[m:]
+            check(lib.ital_whiten_append(_ptr(self.Xd), _ptr(self.xnorm), self.n, self.ldx, _ptr(self.XT[m:m + c]),
+                                         _ptr(self.XTn[m:m + c]), c, _ptr(L21), self.cap,
+                                         L21.data_ptr() + 8 * m, _ptr(self.alpha[m:m + c]), _ptr(self.V), self.ldv, m,
+                                         float(self.var), float(self.length_scale), _ptr(self.mu), _ptr(self.s2), st))
+            self.m += c
+
+    def check_status(self):
+        """Raises if a kernel flagged a numerical failure (synchronises)."""
+        s = int(self.status.item())
+        if s & 1:
+            raise np.linalg.LinAlgError("kernel matrix of the labelled samples is not positive definite "
+                                        "(the reference would warn at gp.py:31)")
+        if s & 2:
+            raise np.linalg.LinAlgError("singular conditional covariance in the orthant integrator "
+                                        "(duplicate samples in the batch?)")
+
+    # ------------------------------------------------------------------ prediction
+    def _full(self, t):
+        """Local shard vector -> full-length numpy array (all ranks)."""
+        loc = t[: self.n]
+        if self.world == 1:
+            return loc.cpu().numpy()
+        import torch.distributed as dist
+        sizes = [self.n_total * (r + 1) // self.world - self.n_total * r // self.world for r in range(self.world)]
+        parts = [torch.empty(s, dtype=loc.dtype, device=self.device) for s in sizes]
+        dist.all_gather(parts, loc.contiguous(), group=self.group)
+        return torch.cat(parts).cpu().numpy()
+
+    def predict_stored(self, ind=None, cov_mode=None):
+        """Predictive mean / variance / covariance of samples of the data matrix (reference gp.py:203-232)."""
+        if self.m == 0:
+            raise RuntimeError("the GP has not been fitted: call fit()/update() first "
+                               "(the reference fails with an AttributeError at gp.py:222)")
+        mean = self._full(self.mu)
+        if ind is not None:
+            ind = np.asarray(ind, dtype=np.int64)
+            mean = mean[ind]
+        if cov_mode is None:
+            return mean
+        if cov_mode == "diag":
+            var = np.maximum(0, self._full(self.s2))
+            return mean, (var if ind is None else var[ind])
+        if cov_mode == "full":
+            if ind is None:
+                raise ValueError("full covariance of all samples is an N x N matrix; pass `ind`")
+            return mean, self._cov_full(ind)
+        raise ValueError("cov_mode must be None, 'diag' or 'full'")
+
+    def _cov_full(self, ind):
+        """K[S,S] - V[:,S]^T V[:,S] for a short index list S (single-rank helper, not on the hot path)."""
+        if self.world != 1:
+            raise NotImplementedError("full covariance blocks are only provided on a single rank")
+        out = np.empty((len(ind), len(ind)))
+        rows = self._gather_rows([int(i) for i in ind])
+        norms = torch.empty(len(ind), dtype=torch.float64, device=self.device)
+        check(self._lib.ital_row_norms(_ptr(rows), len(ind), self.ldx, _ptr(norms), _stream()))
+        idx = torch.as_tensor(ind, dtype=torch.int64, device=self.device)
+        Vs = self.V[: self.m].index_select(1, idx).contiguous()  # m x |S|
+        for c0 in range(0, len(ind), 16):
+            c = min(16, len(ind) - c0)
+            W = Vs[:, c0:c0 + c].t().contiguous()
+            buf = torch.empty((c, self.ldv), dtype=torch.float64, device=self.device)
+            check(self._lib.ital_cross_cov_cols(_ptr(self.Xd), _ptr(self.xnorm), self.n, self.ldx, _ptr(rows[c0:c0 + c]),
+                                                _ptr(norms[c0:c0 + c]), c, _ptr(W), max(self.m, 1), _ptr(self.V), self.ldv,
+                                                self.m, float(self.var), float(self.length_scale), _ptr(buf), self.ldv,
+                                                _stream()))
+            out[c0:c0 + c] = buf[:, : self.n].index_select(1, idx).cpu().numpy()
+        return out
+
+    def rbf_cols(self, ind):
+        """Kernel columns k(x_j, X) for a short index list (what replaces slicing K_all)."""
+        rows = self._gather_rows([int(i) for i in ind])
+        norms = torch.empty(len(ind), dtype=torch.float64, device=self.device)
+        check(self._lib.ital_row_norms(_ptr(rows), len(ind), self.ldx, _ptr(norms), _stream()))
+        out = torch.empty((len(ind), self.ldv), dtype=torch.float64, device=self.device)
+        for c0 in range(0, len(ind), 16):
+            c = min(16, len(ind) - c0)
+            check(self._lib.ital_rbf_cols(_ptr(self.Xd), _ptr(self.xnorm), self.n, self.ldx, _ptr(rows[c0:c0 + c]),
+                                          _ptr(norms[c0:c0 + c]), c, float(self.var), float(self.length_scale),
+                                          _ptr(out[c0:c0 + c]), self.ldv, _stream()))
+        return out[:, : self.n]
+
+    def predict(self, X, cov_mode=None):
+        """Predictive mean (and variance) for external samples (reference gp.py:264-292)."""
+        if self.m == 0:
+            raise RuntimeError("the GP has not been fitted")
+        if cov_mode == "full":
+            raise NotImplementedError("full predictive covariance of external samples is not on the hot path")
+        X = np.atleast_2d(np.asarray(X, dtype=np.float64))
+        nt = X.shape[0]
+        Xt = torch.zeros((nt, self.ldx), dtype=torch.float64, device=self.device)
+        Xt[:, : self.d] = torch.from_numpy(np.ascontiguousarray(X)).to(self.device)
+        mean = torch.empty(nt, dtype=torch.float64, device=self.device)
+        pvar = torch.empty(nt, dtype=torch.float64, device=self.device) if cov_mode == "diag" else None
+        check(self._lib.ital_predict(_ptr(Xt), nt, self.ldx, _ptr(self.XT), _ptr(self.XTn), self.m, _ptr(self.L), self.cap,
+                                     _ptr(self.alpha), float(self.var), float(self.length_scale), _ptr(mean), _ptr(pvar),
+                                     _stream()))
+        if cov_mode == "diag":
+            return mean.cpu().numpy(), pvar.cpu().numpy()
+        return mean.cpu().numpy()

@@ -1,0 +1,105 @@
+"""Host bookkeeping of SciPy mvndst's internal random stream (MVNUNI, L'Ecuyer 1996 combined MRG).
+
+The reference draws its lattice shifts from a process-global, un-seedable generator inside
+scipy.stats.mvn.mvndst (reference ital/ital.py:380).  The device scorer replays that
+stream: this module knows where the stream stands (one global position per process, like the Fortran SAVE
+state), how many uniforms a call of dimension n consumes, and builds the jump-ahead matrices the kernel
+applies to reach the offset of a given (candidate, pattern, call) in the reference's serial order.
+Pure integer arithmetic, no GPU needed.
+"""
+import numpy as np
+
+M1, M2 = 2147483647, 2145483479
+SEED = (15485857, 17329489, 36312197, 55911127, 75906931, 96210113)
+# one step of each component as a matrix acting on (x_{n-3}, x_{n-2}, x_{n-1})^T
+A1 = ((0, 1, 0), (0, 0, 1), ((-183326) % M1, 63308, 0))
+A2 = ((0, 1, 0), (0, 0, 1), ((-539608) % M2, 0, 86098))
+
+PRIMES = (31, 47, 73, 113, 173, 263, 397, 593, 907, 1361)
+# Keast's optimal Korobov generators C(NP, NDIM-1), NP = min(NDIM, 10), for NDIM = 2..12 (Genz, MVNDST)
+KOROBOV_C = {2: 13, 3: 28, 4: 27, 5: 28, 6: 20, 7: 92, 8: 102, 9: 339, 10: 206, 11: 422, 12: 134}
+
+
+def _matmul(a, b, m):
+    return tuple(tuple(sum(a[i][k] * b[k][j] for k in range(3)) % m for j in range(3)) for i in range(3))
+
+
+def _matpow(a, e, m):
+    r = ((1, 0, 0), (0, 1, 0), (0, 0, 1))
+    while e:
+        if e & 1:
+            r = _matmul(a, r, m)
+        a = _matmul(a, a, m)
+        e >>= 1
+    return r
+
+
+def _apply(mat, vec, m):
+    return tuple(sum(mat[i][k] * vec[k] for k in range(3)) % m for i in range(3))
+
+
+def draws_per_call(n):
+    """Uniforms consumed by one mvndst call with n finite-limit variables (8 shifts x (NDIM-1 shuffle draws +
+    NDIM shifts), NDIM = n-1); the closed forms n <= 2 draw nothing."""
+    return 0 if n <= 2 else 8 * (2 * (n - 1) - 1)
+
+
+def korobov_vk(n):
+    """Generator vector of the lattice rule used for n variables: VK(1) = 1/P, VK(i) = frac(C * VK(i-1)),
+    evaluated in floating point exactly as SciPy's mvndst.f does."""
+    ndim = n - 1
+    p = PRIMES[min(ndim, 10) - 1]
+    vk = np.empty(ndim, dtype=np.float64)
+    vk[0] = 1.0 / p
+    c = float(KOROBOV_C[ndim]) if ndim >= 2 else 0.0
+    for i in range(1, ndim):
+        vk[i] = np.fmod(c * vk[i - 1], 1.0)
+    return vk
+
+
+class MvnStream:
+    """Position of the MVNUNI stream; `state` is the generator state after `draws` uniforms."""
+
+    def __init__(self):
+        self.reset()
+
+    def reset(self):
+        self.state = SEED
+        self.draws = 0
+
+    def advance(self, n):
+        n = int(n)
+        if n <= 0:
+            return
+        s1 = _apply(_matpow(A1, n, M1), self.state[:3], M1)
+        s2 = _apply(_matpow(A2, n, M2), self.state[3:], M2)
+        self.state = s1 + s2
+        self.draws += n
+
+    def peek(self, n):
+        """State after n more draws, without moving."""
+        s1 = _apply(_matpow(A1, int(n), M1), self.state[:3], M1)
+        s2 = _apply(_matpow(A2, int(n), M2), self.state[3:], M2)
+        return s1 + s2
+
+
+_jump_cache = {}
+
+
+def jump_table(n, bits=48):
+    """int64 [bits][18]: transition matrices of both components for 2^b calls of dimension n."""
+    key = (n, bits)
+    if key not in _jump_cache:
+        d = draws_per_call(n)
+        j1, j2 = _matpow(A1, d, M1), _matpow(A2, d, M2)
+        out = np.empty((bits, 18), dtype=np.int64)
+        for b in range(bits):
+            out[b, :9] = np.array(j1, dtype=np.int64).ravel()
+            out[b, 9:] = np.array(j2, dtype=np.int64).ravel()
+            j1, j2 = _matmul(j1, j1, M1), _matmul(j2, j2, M2)
+        _jump_cache[key] = out
+    return _jump_cache[key]
+
+
+#: the process-global stream (one per process, as in the reference)
+GLOBAL = MvnStream()

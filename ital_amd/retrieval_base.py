@@ -1,0 +1,101 @@
+"""Learner API -- the drop-in boundary (mirror of reference ital/retrieval_base.py `ActiveRetrievalBase`).
+
+Same constructor arguments, methods (fit / reset / top_results / get_unseen / fetch_unlabelled / update /
+partition_feedback), attributes (gp, rel_mean, relevant_ids, irrelevant_ids, unnameable_ids, rounds, data,
+queries) and error behaviour; the GP behind it is the streaming MI355X one (ital_amd.gp).
+Keyword-only extras: device, rank, world, group (row sharding over GPUs).
+"""
+import numpy as np
+
+from .gp import GaussianProcess
+
+
+class ActiveRetrievalBase(object):
+
+    def __init__(self, data=None, queries=[], length_scale=0.1, var=1.0, noise=1e-6, *, device=None, rank=0,
+                 world=1, group=None):
+        self.length_scale = length_scale
+        self.var = var
+        self.noise = noise
+        self.device, self.rank, self.world, self.group = device, rank, world, group
+        self.fit(data, queries)
+
+    def fit(self, data, queries=[]):
+        """reference retrieval_base.py:34-45"""
+        self.data = data
+        self.queries = queries
+        if self.data is not None:
+            self.gp = GaussianProcess(self.data, self.length_scale, self.var, self.noise, device=self.device,
+                                      rank=self.rank, world=self.world, group=self.group)
+            self.reset()
+        else:
+            self.gp = None
+
+    def reset(self):
+        """reference retrieval_base.py:48-61"""
+        self.rounds = 0
+        self.relevant_ids = set()
+        self.irrelevant_ids = set()
+        self.unnameable_ids = set()
+        self._rel_mean = None
+        self.gp.reset()
+        if len(self.queries) > 0:
+            n = len(self.data)
+            self.gp.update_points(self.queries, [1] * len(self.queries), ind=list(range(n, n + len(self.queries))))
+            self._rel_mean_dirty = True
+        else:
+            self._rel_mean_dirty = False
+
+    @property
+    def rel_mean(self):
+        """Predictive mean of every sample (numpy), refreshed lazily from the device after an update."""
+        if self._rel_mean_dirty:
+            self._rel_mean = self.gp.predict_stored()
+            self._rel_mean_dirty = False
+        return self._rel_mean
+
+    def top_results(self, k=None):
+        """reference retrieval_base.py:64-75"""
+        ind = np.argsort(self.rel_mean)[::-1]
+        return ind[:k] if k is not None else ind
+
+    def get_unseen(self):
+        """reference retrieval_base.py:78-87 (ascending sample indices)."""
+        seen = self.relevant_ids | self.irrelevant_ids | self.unnameable_ids
+        if not seen:
+            return list(range(len(self.data)))
+        mask = np.ones(len(self.data), dtype=bool)
+        mask[np.fromiter(seen, dtype=np.int64, count=len(seen))] = False
+        return np.flatnonzero(mask).tolist()
+
+    def fetch_unlabelled(self, k):
+        raise NotImplementedError('fetch_unlabelled() has to be implemented in a derived class.')
+
+    def update(self, feedback):
+        """reference retrieval_base.py:105-126"""
+        rel, irr, unnameable = self.partition_feedback(feedback)
+        if len(rel) + len(irr) > 0:
+            self.gp.update(rel + irr, np.concatenate((np.ones(len(rel)), -1 * np.ones(len(irr)))))
+            self._rel_mean_dirty = True
+            self.relevant_ids.update(rel)
+            self.irrelevant_ids.update(irr)
+            self.rounds += 1
+        self.unnameable_ids.update(unnameable)
+
+    def partition_feedback(self, feedback):
+        """reference retrieval_base.py:167-193"""
+        rel, irr, unnameable = [], [], []
+        for i, fb in feedback.items():
+            if fb > 0:
+                if i in self.irrelevant_ids:
+                    raise RuntimeError('Cannot change feedback once given.')
+                elif i not in self.relevant_ids:
+                    rel.append(i)
+            elif fb < 0:
+                if i in self.relevant_ids:
+                    raise RuntimeError('Cannot change feedback once given.')
+                elif i not in self.irrelevant_ids:
+                    irr.append(i)
+            else:
+                unnameable.append(i)
+        return rel, irr, unnameable
