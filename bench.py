@@ -1,0 +1,187 @@
+#!/usr/bin/env python3
+"""Benchmark of the ITAL hot path on MI355X: MI-scored candidates/sec per fetch_unlabelled(k) round.
+
+    python bench.py --gpus 1 --steps 10 --warmup 2
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+
+One "step" = one round of the reference's retrieval loop (run_experiment.py:160-164): fetch_unlabelled(k) on the
+current relevance model followed by update() with the simulated feedback for the fetched batch (the update is
+inside the timed region: nothing is skipped).  Workload (BASELINE.json configs[1], SURVEY.md section 8d C2'):
+synthetic USPS-shaped features, 9298 x 256 fp64 in [0,1], length_scale 3.0, k = 4, perfect user; with N > 1 every
+rank holds 9298 rows (weak scaling) and the greedy steps exchange one record per rank over RCCL.
+A scored candidate = one (candidate, greedy step) MI evaluation with full 2^t sign-pattern enumeration.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+ROWS_PER_GPU = 9298
+DIM = 256
+BATCH = 4
+LENGTH_SCALE = 3.0
+FP64_VALU_PEAK_TFLOPS = 78.6   # MI355X vector FP64 (= half the 157.3 TF FP32 vector rate of MI355X_MICROARCH.md)
+HBM_PEAK_GBS = 8000.0
+PRIMES = (31, 47, 73, 113, 173, 263, 397, 593, 907, 1361)
+# FP64 VALU flops per (Phi, Phi^-1) pair of the lattice integrand, counted from the gfx950 ISA of
+# score_qmc_kernel<4> (DESIGN.md section "Kernels": FMA = 2 flops)
+FLOP_PER_PAIR = 2.0 * 118
+
+
+def make_data(n, d, seed):
+    rng = np.random.default_rng(seed)
+    return rng.random((n, d))
+
+
+def qmc_pairs(t, n_cand):
+    """(Phi, Phi^-1) evaluations the scorer of greedy step t performs: 2^t prior orthant probabilities per candidate,
+    16*P lattice evaluations each, t variables (the 2^t post-update probabilities are provably 1 and cost none)."""
+    p = PRIMES[min(t - 1, 10) - 1]
+    return n_cand * (2 ** t) * 16 * p * t
+
+
+def cpu_baseline(X, cores):
+    """The oracle (CPU restatement of the reference, oracle/) in the reference's parallel mode on a bounded sample."""
+    from oracle.ital import OracleITAL
+    from oracle.parallel import fetch_unlabelled_parallel
+    n = int(min(len(X), max(512, 600 * cores)))
+    learner = OracleITAL(X[:n], length_scale=LENGTH_SCALE)
+    learner.update({0: 1})
+    t0 = time.time()
+    _, scored = fetch_unlabelled_parallel(learner, BATCH, processes=cores)
+    dt = time.time() - t0
+    return {"value": scored / dt, "unit": "candidates/s", "cores": cores, "kind": "port",
+            "sample": "one fetch_unlabelled(%d) round on the first %d rows of the workload (%d scored candidates, "
+                      "%.1f s), fork pool per greedy step as reference ital/ital.py:124-126" % (BATCH, n, scored, dt)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    cpu_base = None
+    if world == 1 and not args.no_cpu_baseline:
+        # before anything touches the GPU: the baseline forks worker pools
+        cpu_base = cpu_baseline(make_data(ROWS_PER_GPU, DIM, seed=0), os.cpu_count() or 1)
+    import torch
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node %d for --gpus %d" % (args.gpus, args.gpus))
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    group = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        group = dist.group.WORLD
+
+    from ital_amd import ITAL, mvn_stream
+
+    n_total = ROWS_PER_GPU * world
+    X = make_data(n_total, DIM, seed=0)
+    rel = np.where(X[:, 0] > 0.5, 1.0, -1.0)
+    learner = ITAL(X, length_scale=LENGTH_SCALE, device=device, rank=rank, world=world, group=group)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            import torch.distributed as dist
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    def one_round():
+        ret = learner.fetch_unlabelled(BATCH)
+        learner.update({int(i): float(rel[i]) for i in ret})
+        return ret
+
+    def restart():
+        learner.reset()
+        mvn_stream.GLOBAL.reset()
+        learner.update({0: 1})
+
+    restart()
+    for _ in range(args.warmup):
+        one_round()
+    restart()
+    learner.profile = []
+    scored = 0
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        n_cand = n_total - len(learner.relevant_ids) - len(learner.irrelevant_ids)
+        one_round()
+        scored += sum(n_cand - t for t in range(BATCH))
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        import torch.distributed as dist
+        tt = torch.tensor([dt], dtype=torch.float64, device=device)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+
+    # per-kernel durations from the HIP events recorded on the launch stream during the timed region
+    prof = {}
+    for name, t, n_c, e0, e1 in learner.profile:
+        prof.setdefault((name, t), []).append((e0.elapsed_time(e1) * 1e-3, n_c))
+    out = None
+    if rank == 0:
+        qm = prof.get(("score", BATCH), [])
+        roof = None
+        if qm:
+            avg_s = float(np.mean([d for d, _ in qm]))
+            avg_c = float(np.mean([c for _, c in qm]))
+            flops = qmc_pairs(BATCH, avg_c) * FLOP_PER_PAIR
+            ach = flops / avg_s / 1e12
+            roof = {"bound": "fp64-valu", "kernel": "score_qmc_kernel<%d>" % BATCH, "achieved": ach,
+                    "peak": FP64_VALU_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach / FP64_VALU_PEAK_TFLOPS,
+                    "traffic": None, "avg_launch_ms": avg_s * 1e3,
+                    "pairs_per_s": qmc_pairs(BATCH, avg_c) / avg_s,
+                    "note": "transcendental FP64 chains (Phi, Phi^-1): neither HBM nor MFMA bounds this kernel "
+                            "(SURVEY.md 8d S-qmc); HBM-bound streaming kernel reported in roofline_hbm"}
+        cc = prof.get(("cross_cov", 1), []) + prof.get(("cross_cov", 2), []) + prof.get(("cross_cov", 3), [])
+        roof_hbm = None
+        if cc:
+            avg_s = float(np.mean([d for d, _ in cc]))
+            m_avg = float(np.mean([c for _, c in cc]))
+            bytes_alg = learner.gp.n * 8.0 * (DIM + m_avg + 1)
+            ach = bytes_alg / avg_s / 1e9
+            roof_hbm = {"bound": "hbm", "kernel": "kcols_kernel (cross-covariance column)", "achieved": ach,
+                        "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": None,
+                        "avg_launch_ms": avg_s * 1e3,
+                        "note": "19 MB per launch at this size: launch-latency bound, see DESIGN.md for the large-N figure"}
+        out = {"metric": "MI-scored candidates/sec per fetch_unlabelled(k) round", "value": scored / dt,
+               "unit": "candidates/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+               "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+               "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+               "config": {"workload": "USPS-shaped synthetic %dx%d per GPU, k=%d, perfect user, full 2^t enumeration, "
+                                      "fetch_unlabelled + update per step" % (ROWS_PER_GPU, DIM, BATCH),
+                          "n": n_total, "d": DIM, "k": BATCH, "length_scale": LENGTH_SCALE,
+                          "parallelism": "candidate rows sharded over %d GPU(s), 1 record all-gather per greedy step" % world},
+               "roofline": roof, "roofline_hbm": roof_hbm,
+               "kernel_ms": {"%s_t%d" % k: float(np.mean([d for d, _ in v])) * 1e3 for k, v in sorted(prof.items())}}
+        out["cpu_baseline"] = cpu_base
+        if cpu_base:
+            out["speedup_vs_cpu_baseline"] = out["value"] / cpu_base["value"]
+        print(json.dumps(out))
+    if world > 1:
+        import torch.distributed as dist
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

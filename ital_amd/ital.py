@@ -51,6 +51,7 @@ class ITAL(ActiveRetrievalBase):
         self.eps = 1e-12  # reference ital/ital.py:144
         self.last_scores = None  # per greedy step: device tensor of MI per list position (diagnostics/tests)
         self.keep_scores = False
+        self.profile = None      # list to receive (stage, t, size, start_event, end_event) per launch (bench.py)
         self._fetch_bufs = None
 
     # ------------------------------------------------------------------ helpers
@@ -66,6 +67,16 @@ class ITAL(ActiveRetrievalBase):
         if self.label_estimation not in _LABEL_MODES:
             return "label_estimation=%r" % (self.label_estimation,)
         return None
+
+    def _mark(self, stage=None, t=0, size=0, start=None):
+        """HIP event on the launch stream (only when bench.py asked for per-kernel timings)."""
+        if self.profile is None:
+            return None
+        ev = torch.cuda.Event(enable_timing=True)
+        ev.record()
+        if start is not None:
+            self.profile.append((stage, t, size, start, ev))
+        return ev
 
     def _buffers(self, kmax):
         gp = self.gp
@@ -173,7 +184,9 @@ class ITAL(ActiveRetrievalBase):
                     desc.jump, desc.vk = _ptr(b["jump"][t]), _ptr(b["vk"][t])
                     for j in range(6):
                         desc.seed[j] = stream.state[j]
+                ev0 = self._mark()
                 check(lib.ital_score_step(ctypes.byref(desc), st))
+                self._mark("score", t, n_alive, ev0)
                 if self.keep_scores:
                     self.last_scores.append(mi.clone())
                 check(lib.ital_select_local(_ptr(mi), _ptr(cand_d), _ptr(alive), n_loc, pos_offset, gp.row0, gp.rank, 0,
@@ -190,10 +203,12 @@ class ITAL(ActiveRetrievalBase):
                                               _ptr(alive), _ptr(b["ret"]), st))
                 if t < k:
                     slot = t - 1
+                    ev0 = self._mark()
                     check(lib.ital_cross_cov_cols(_ptr(gp.Xd), _ptr(gp.xnorm), gp.n, gp.ldx, _ptr(b["XB"][slot]),
                                                   _ptr(b["XBn"][slot:]), 1, _ptr(b["VB"][slot]), gp.cap, _ptr(gp.V),
                                                   gp.ldv, gp.m, float(self.var), float(self.length_scale),
                                                   _ptr(b["C"][slot]), gp.ldv, st))
+                    self._mark("cross_cov", t, gp.m, ev0)
                 # the reference's serial loop has now consumed this many uniforms of mvndst's stream
                 stream.advance(n_alive * (2 << t) * mvn_stream.draws_per_call(t))
                 n_alive -= 1

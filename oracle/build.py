@@ -11,7 +11,7 @@ LIB = os.path.join(OUT, "libmvndst_oracle.so")
 def build(force=False):
     os.makedirs(OUT, exist_ok=True)
     if force or not os.path.exists(LIB) or os.path.getmtime(LIB) < os.path.getmtime(SRC):
-        subprocess.check_call(["gcc", "-O2", "-ffp-contract=off", "-fPIC", "-shared", "-o", LIB, SRC, "-lm"])
+        subprocess.check_call(["gcc", "-O3", "-ffp-contract=off", "-fPIC", "-shared", "-o", LIB, SRC, "-lm"])
     return LIB
 
 

@@ -96,14 +96,17 @@ class OracleGP:
         """Posterior at pred_ind after a simulated update with (ind, y) (gp.py:295-344).  The reference
         extends its stored inverse with a Woodbury step (extend_inv, gp.py:40-87); the matrix it obtains
         is inv(K[T+new, T+new] + noise*I), formed here directly."""
-        ext = self.ind + [int(i) for i in ind]
+        ext = np.array(self.ind + [int(i) for i in ind], dtype=np.int64)
+        pred = np.asarray(pred_ind, dtype=np.int64)
         y_ext = np.concatenate((self.y, np.asarray(y, dtype=np.float64)))
-        K_ext = self.K_all[np.ix_(ext, ext)] + self.noise * np.eye(len(ext))
-        k_test = self.K_all[np.ix_(ext, pred_ind)]
+        rows = self.K_all[ext]
+        K_ext = rows[:, ext]
+        K_ext[np.diag_indices_from(K_ext)] += self.noise
+        k_test = rows[:, pred]
         sol = np.linalg.solve(K_ext, np.column_stack((y_ext, k_test)))
         mean = sol[:, 0] @ k_test
         if cov_mode == "full":
-            return mean, self.K_all[np.ix_(pred_ind, pred_ind)] - k_test.T @ sol[:, 1:]
+            return mean, self.K_all[pred][:, pred] - k_test.T @ sol[:, 1:]
         if cov_mode == "diag":
             return mean, np.maximum(0, self.var - np.sum(k_test * sol[:, 1:], axis=0))
         return mean

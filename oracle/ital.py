@@ -121,6 +121,15 @@ def group_cov(corr, th):
     return groups
 
 
+_TRIL = {}
+
+
+def _tril(n):
+    if n not in _TRIL:
+        _TRIL[n] = np.tril_indices(n, -1)
+    return _TRIL[n]
+
+
 def _mvn_call(pivot, infin, correl, n):
     return mvn.mvndst(pivot, pivot, infin, correl, maxpts=100 * n, abseps=1e-4, releps=1e-4)[1]
 
@@ -136,7 +145,7 @@ def prob_rel(rel, mean, cov, clip_cov=0):
         return 1.0 - p_irr if rel[0] else p_irr
     sd = np.sqrt(np.diag(cov))
     pivot = -np.asarray(mean, dtype=np.float64) / sd
-    i, j = np.tril_indices(n, -1)
+    i, j = _tril(n)
     correl = cov[i, j] / (sd[i] * sd[j])
     return _mvn_call(pivot, np.asarray(rel, dtype=np.int32), correl, n)
 

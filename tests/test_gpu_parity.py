@@ -1,0 +1,223 @@
+"""Parity of the HIP path (through the C ABI) with the oracle and with the reference's golden vectors.
+Run on the GPU box: python -m pytest tests -m gpu."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+torch = pytest.importorskip("torch")
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"))
+import make_golden  # noqa: E402  (fixture table only)
+
+
+@pytest.fixture(scope="module")
+def dev():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    return "cuda:0"
+
+
+def _learners():
+    from ital_amd import ITAL, GaussianProcess, mvn_stream
+    return ITAL, GaussianProcess, mvn_stream
+
+
+# ------------------------------------------------------------------------------------------ kernels vs oracle
+@pytest.mark.parametrize("n,d,c", [(1, 4, 1), (63, 16, 3), (64, 17, 16), (1000, 50, 5), (4097, 256, 16), (333, 100, 1)])
+def test_rbf_cols(dev, n, d, c):
+    from oracle.gp import rbf_kernel
+    _, GP, _ = _learners()
+    rng = np.random.default_rng(n + d)
+    X = rng.random((n, d))
+    gp = GP(X, 0.9 * np.sqrt(d / 12.0), var=1.3, device=dev)
+    idx = rng.integers(0, n, size=c).tolist()
+    got = gp.rbf_cols(idx).cpu().numpy()
+    want = rbf_kernel(X[idx], X, gp.length_scale, 1.3)
+    np.testing.assert_allclose(got, want, rtol=1e-12, atol=1e-15)
+
+
+def test_gp_update_predict_vs_oracle(dev):
+    from oracle.gp import OracleGP
+    _, GP, _ = _learners()
+    rng = np.random.default_rng(5)
+    X = rng.random((700, 33))
+    ls = 0.8 * np.sqrt(33 / 12.0)
+    gp = GP(X, ls, device=dev, capacity=16)
+    ref = OracleGP(X, ls)
+    perm = rng.permutation(700)
+    at = 0
+    for c in (1, 4, 17, 3, 40):  # crosses the 16-row chunking and the capacity growth
+        idx = perm[at:at + c].tolist()
+        y = np.where(rng.random(c) > 0.5, 1.0, -1.0)
+        at += c
+        gp.update(idx, y)
+        ref.update(idx, y)
+        m, v = gp.predict_stored(cov_mode="diag")
+        mr, vr = ref.predict_stored(cov_mode="diag")
+        np.testing.assert_allclose(m, mr, rtol=0, atol=2e-9)
+        np.testing.assert_allclose(v, vr, rtol=0, atol=2e-9)
+    gp.check_status()
+    assert gp.ind == ref.ind
+    Xt = rng.random((37, 33))
+    pm, pv = gp.predict(Xt, cov_mode="diag")
+    pmr, pvr = ref.predict(Xt, cov_mode="diag")
+    np.testing.assert_allclose(pm, pmr, rtol=0, atol=2e-9)
+    np.testing.assert_allclose(pv, pvr, rtol=0, atol=2e-9)
+    sub = perm[500:507].tolist()
+    mf, cf = gp.predict_stored(sub, cov_mode="full")
+    mfr, cfr = ref.predict_stored(sub, cov_mode="full")
+    np.testing.assert_allclose(cf, cfr, rtol=0, atol=2e-9)
+
+
+# ------------------------------------------------------------------------------------------ golden vectors
+def _run_fixture(dev, golden_dir, name, rounds=None, mi_atol=1e-10):
+    ITAL, _, mvn_stream = _learners()
+    z = np.load(os.path.join(golden_dir, name + ".npz"))
+    spec = make_golden.FIXTURES[name]
+    mvn_stream.GLOBAL.reset()
+    L = ITAL(z["X"], length_scale=float(z["length_scale"]), device=dev, **spec["kw"])
+    L.keep_scores = True
+    L.update({int(z["query"]): 1})
+    rel = z["rel"]
+    for r in range(int(z["rounds"]) if rounds is None else rounds):
+        m, v = L.gp.predict_stored(cov_mode="diag")
+        np.testing.assert_allclose(m, z[f"r{r}_rel_mean"], rtol=0, atol=1e-10)
+        np.testing.assert_allclose(v, z[f"r{r}_var"], rtol=0, atol=1e-9)
+        ret = L.fetch_unlabelled(int(z["k"]))
+        cand0 = z[f"r{r}_s0_cand"].tolist()
+        pos = {c: i for i, c in enumerate(cand0)}
+        for t in range(len(ret)):
+            cand = z[f"r{r}_s{t}_cand"].tolist()
+            mine = L.last_scores[t].cpu().numpy()[[pos[c] for c in cand]]
+            np.testing.assert_allclose(mine, z[f"r{r}_s{t}_mi"], rtol=1e-8, atol=mi_atol, err_msg=f"{name} r{r} step {t}")
+        assert ret == z[f"r{r}_ret"].tolist(), (name, r)   # selected indices bit-exact
+        L.update({int(i): float(rel[i]) for i in ret})
+    np.testing.assert_allclose(L.rel_mean, z["final_rel_mean"] if rounds is None else L.rel_mean, rtol=0, atol=1e-9)
+    return L, z
+
+
+@pytest.mark.parametrize("name", ["usps500", "butterflies", "synth300", "synth96_k6", "usps2007",
+                                  "synth200_optimistic", "synth200_topcand"])
+def test_golden_fixture(dev, golden_dir, name):
+    L, z = _run_fixture(dev, golden_dir, name)
+    assert L.top_results(10).tolist() == z["top_results_10"].tolist()
+    pm, pv = L.gp.predict(z["predict_X"], cov_mode="diag")
+    np.testing.assert_allclose(pm, z["predict_mean"], rtol=0, atol=1e-9)
+    np.testing.assert_allclose(pv, z["predict_var"], rtol=0, atol=1e-9)
+
+
+# ------------------------------------------------------------------------------------------ HIP vs oracle, seeded
+@pytest.mark.parametrize("seed,n,d,k,mode", [(0, 150, 8, 4, "mean"), (1, 257, 20, 5, "mean"), (2, 90, 3, 3, "pessimistic"),
+                                             (3, 120, 40, 4, "optimistic")])
+def test_against_oracle(dev, seed, n, d, k, mode):
+    from oracle import mvn as omvn
+    from oracle.ital import OracleITAL
+    ITAL, _, mvn_stream = _learners()
+    rng = np.random.default_rng(seed)
+    X = rng.random((n, d))
+    ls = float(np.sqrt(d / 12.0))
+    labels = {int(i): (1 if X[i, 0] > 0.5 else -1) for i in rng.choice(n, 5, replace=False)}
+    mvn_stream.GLOBAL.reset()
+    omvn.rng_reset()
+    A = ITAL(X, length_scale=ls, label_estimation=mode, device=dev)
+    A.keep_scores = True
+    B = OracleITAL(X, length_scale=ls, label_estimation=mode)
+    A.update(labels)
+    B.update(labels)
+    for _ in range(2):
+        got = A.fetch_unlabelled(k)
+        want = [int(i) for i in B.fetch_unlabelled(k)]
+        cand0 = B.trace[0][0]
+        pos = {c: i for i, c in enumerate(cand0)}
+        for t, (cand, vals, _) in enumerate(B.trace):
+            mine = A.last_scores[t].cpu().numpy()[[pos[c] for c in cand]]
+            np.testing.assert_allclose(mine, vals, rtol=1e-8, atol=1e-10)
+        assert got == want
+        fb = {i: (1 if X[i, 0] > 0.5 else -1) for i in got}
+        A.update(fb)
+        B.update(fb)
+    assert mvn_stream.GLOBAL.draws == omvn.rng_draws()   # the replayed stream stands where the serial reference's does
+
+
+# ------------------------------------------------------------------------------------------ API behaviour / edge cases
+def test_api_edge_cases(dev):
+    ITAL, _, mvn_stream = _learners()
+    rng = np.random.default_rng(9)
+    X = rng.random((12, 6))
+    L = ITAL(X, length_scale=0.7, device=dev)
+    with pytest.raises(RuntimeError):
+        L.fetch_unlabelled(2)                      # not fitted yet
+    L.update({0: 1, 1: -1, 2: 0})                  # 2 is "unnameable": never trained on, never a candidate again
+    assert L.rounds == 1 and L.relevant_ids == {0} and L.irrelevant_ids == {1} and L.unnameable_ids == {2}
+    assert L.gp.ind == [0, 1]
+    assert L.fetch_unlabelled(0) == []
+    ret = L.fetch_unlabelled(3)
+    assert len(ret) == 3 and len(set(ret)) == 3 and not set(ret) & {0, 1, 2}
+    assert all(isinstance(i, int) for i in ret)
+    with pytest.raises(RuntimeError, match="Cannot change feedback"):
+        L.update({0: -1})
+    L.update({0: 1})                                # repeating a label is ignored
+    assert L.rounds == 1
+    L.update({i: 1 for i in ret})
+    rest = L.fetch_unlabelled(8)                    # only 6 unseen samples are left
+    assert len(rest) == 6 and sorted(rest + ret + [0, 1, 2]) == list(range(12))
+    assert L.top_results(3).tolist() == np.argsort(L.rel_mean)[::-1][:3].tolist()
+    L.reset()
+    assert L.rounds == 0 and L.gp.m == 0 and L.rel_mean is None
+    with pytest.raises(NotImplementedError):
+        ITAL(X, length_scale=0.7, label_prob=0.8, device=dev).fetch_unlabelled(2)
+
+
+def test_queries_constructor(dev):
+    from oracle.ital import OracleITAL
+    ITAL, _, _ = _learners()
+    rng = np.random.default_rng(4)
+    X = rng.random((80, 7))
+    Q = rng.random((2, 7))
+    A = ITAL(X, queries=Q, length_scale=0.8, device=dev)
+    B = OracleITAL(X, queries=Q, length_scale=0.8)
+    np.testing.assert_allclose(A.rel_mean, B.rel_mean, rtol=0, atol=1e-10)
+    assert A.fetch_unlabelled(2) == [int(i) for i in B.fetch_unlabelled(2)]
+
+
+# ------------------------------------------------------------------------------------------ full-size properties
+def test_full_size_properties(dev):
+    """BASELINE config 2 shape (9298 x 256, k = 4): determinism, no seen ids, row-permutation equivariance of the
+    closed-form steps, and agreement of the scores with the oracle on a sampled subset of candidates."""
+    from oracle.gp import rbf_kernel
+    ITAL, _, mvn_stream = _learners()
+    rng = np.random.default_rng(0)
+    n, d = 9298, 256
+    X = rng.random((n, d))
+    labels = {0: 1, 17: -1, 4000: 1, 9000: -1}
+
+    def run(Xm, lab, k):
+        mvn_stream.GLOBAL.reset()
+        L = ITAL(Xm, length_scale=3.0, device=dev)
+        L.keep_scores = True
+        L.update(lab)
+        return L, L.fetch_unlabelled(k)
+
+    L1, r1 = run(X, labels, 4)
+    L2, r2 = run(X, labels, 4)
+    assert r1 == r2 and not set(r1) & set(labels)
+    for a, b in zip(L1.last_scores, L2.last_scores):
+        assert torch.equal(a, b)                                   # bitwise reproducible
+    perm = rng.permutation(n)
+    inv = np.argsort(perm)
+    Lp, rp = run(X[perm], {int(inv[i]): y for i, y in labels.items()}, 2)
+    assert [int(perm[i]) for i in rp] == r1[:2]                    # t <= 2 is closed form: equivariant under row permutation
+    # scores of step 1 against the dense formula on a sample
+    ids = rng.choice(np.setdiff1d(np.arange(n), list(labels)), 64, replace=False)
+    T = list(labels)
+    K = rbf_kernel(X[T], X[T], 3.0, 1.0) + 1e-6 * np.eye(len(T))
+    kt = rbf_kernel(X[T], X[ids], 3.0, 1.0)
+    mu = np.linalg.solve(K, np.array(list(labels.values()), dtype=float)) @ kt
+    var = 1.0 - np.sum(kt * np.linalg.solve(K, kt), axis=0)
+    m, v = L1.gp.predict_stored(cov_mode="diag")
+    np.testing.assert_allclose(m[ids], mu, atol=1e-9)
+    np.testing.assert_allclose(v[ids], var, atol=1e-9)
