@@ -12,6 +12,16 @@
 
 namespace ital {
 
+// n / d for well-scaled d (polynomial denominators, no zero / inf / subnormal): hardware reciprocal seed, two
+// Newton steps and one residual correction -- ~1 ulp, about half the instructions of the IEEE division expansion.
+__device__ __forceinline__ double fast_div(double n, double d) {
+    double r = __builtin_amdgcn_rcp(d);
+    r = fma(fma(-d, r, 1.0), r, r);
+    r = fma(fma(-d, r, 1.0), r, r);
+    double q = n * r;
+    return fma(fma(-d, q, n), r, q);
+}
+
 __device__ __forceinline__ double mvn_phi(double z) {
     const double P0 = 220.2068679123761, P1 = 221.2135961699311, P2 = 112.0792914978709, P3 = 33.91286607838300,
                  P4 = 6.373962203531650, P5 = .7003830644436881, P6 = .03526249659989109;
@@ -27,7 +37,7 @@ __device__ __forceinline__ double mvn_phi(double z) {
         if (zabs < CUTOFF) {
             double num = ((((((P6 * zabs + P5) * zabs + P4) * zabs + P3) * zabs + P2) * zabs + P1) * zabs + P0);
             double den = (((((((Q7 * zabs + Q6) * zabs + Q5) * zabs + Q4) * zabs + Q3) * zabs + Q2) * zabs + Q1) * zabs + Q0);
-            p = expntl * num / den;
+            p = fast_div(expntl * num, den);
         } else {
             p = expntl / (zabs + 1 / (zabs + 2 / (zabs + 3 / (zabs + 4 / (zabs + 0.65))))) / ROOTPI;
         }
@@ -46,8 +56,8 @@ __device__ __forceinline__ double mvn_phinv(double p) {
                      B2 = 6.8718700749205790830E+2, B3 = 5.3941960214247511077E+3, B4 = 2.1213794301586595867E+4,
                      B5 = 3.9307895800092710610E+4, B6 = 2.8729085735721942674E+4, B7 = 5.2264952788528545610E+3;
         double r = CONST1 - q * q;
-        return q * (((((((A7 * r + A6) * r + A5) * r + A4) * r + A3) * r + A2) * r + A1) * r + A0) /
-               (((((((B7 * r + B6) * r + B5) * r + B4) * r + B3) * r + B2) * r + B1) * r + 1);
+        return fast_div(q * (((((((A7 * r + A6) * r + A5) * r + A4) * r + A3) * r + A2) * r + A1) * r + A0),
+                        (((((((B7 * r + B6) * r + B5) * r + B4) * r + B3) * r + B2) * r + B1) * r + 1));
     }
     double r = fmin(p, 1 - p);
     double v;
@@ -60,8 +70,8 @@ __device__ __forceinline__ double mvn_phinv(double p) {
                          D2 = 1.67638483018380384940E0, D3 = 6.89767334985100004550E-1, D4 = 1.48103976427480074590E-1,
                          D5 = 1.51986665636164571966E-2, D6 = 5.47593808499534494600E-4, D7 = 1.05075007164441684324E-9;
             r = r - CONST2;
-            v = (((((((C7 * r + C6) * r + C5) * r + C4) * r + C3) * r + C2) * r + C1) * r + C0) /
-                (((((((D7 * r + D6) * r + D5) * r + D4) * r + D3) * r + D2) * r + D1) * r + 1);
+            v = fast_div((((((((C7 * r + C6) * r + C5) * r + C4) * r + C3) * r + C2) * r + C1) * r + C0),
+                         (((((((D7 * r + D6) * r + D5) * r + D4) * r + D3) * r + D2) * r + D1) * r + 1));
         } else {
             const double E0 = 6.65790464350110377720E0, E1 = 5.46378491116411436990E0, E2 = 1.78482653991729133580E0,
                          E3 = 2.96560571828504891230E-1, E4 = 2.65321895265761230930E-2, E5 = 1.24266094738807843860E-3,
@@ -69,8 +79,8 @@ __device__ __forceinline__ double mvn_phinv(double p) {
                          F2 = 1.36929880922735805310E-1, F3 = 1.48753612908506148525E-2, F4 = 7.86869131145613259100E-4,
                          F5 = 1.84631831751005468180E-5, F6 = 1.42151175831644588870E-7, F7 = 2.04426310338993978564E-15;
             r = r - SPLIT2;
-            v = (((((((E7 * r + E6) * r + E5) * r + E4) * r + E3) * r + E2) * r + E1) * r + E0) /
-                (((((((F7 * r + F6) * r + F5) * r + F4) * r + F3) * r + F2) * r + F1) * r + 1);
+            v = fast_div((((((((E7 * r + E6) * r + E5) * r + E4) * r + E3) * r + E2) * r + E1) * r + E0),
+                         (((((((F7 * r + F6) * r + F5) * r + F4) * r + F3) * r + F2) * r + F1) * r + 1));
         }
     } else {
         v = 9;

@@ -385,8 +385,9 @@ __global__ __launch_bounds__(256) void score_qmc_kernel(ScoreArgs a) {
         // ---------------- Phase C: the wave evaluates the calls of this chunk one after the other
         for (int cl = 0; cl < Q::CHUNK; cl++) {
             const int call = chunk + cl;
-            const bool sat_c = __shfl((int)sat, cl, 64) != 0;
-            const unsigned infi_c = (unsigned)__shfl((int)infi, cl, 64);
+            // wave-uniform copies (SGPR) of the preparing lane's flags: keeps the generator arithmetic on the scalar unit
+            const bool sat_c = __builtin_amdgcn_readlane((int)sat, cl) != 0;
+            const unsigned infi_c = (unsigned)__builtin_amdgcn_readlane((int)infi, cl);
             double value;
             if (sat_c) {
                 value = 1.0;

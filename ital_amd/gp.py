@@ -14,7 +14,7 @@ the HIP kernels of libital_hip.so; torch only owns the device buffers and the st
 import numpy as np
 import torch
 
-from . import _lib
+from . import _lib, sharding
 from ._lib import check
 
 
@@ -53,8 +53,7 @@ class GaussianProcess(object):
         if data.ndim != 2:
             raise ValueError("data must be an n-by-d array")
         self.n_total, self.d = data.shape
-        self.row0 = self.n_total * self.rank // self.world
-        self.row1 = self.n_total * (self.rank + 1) // self.world
+        self.row0, self.row1 = sharding.row_range(self.n_total, self.world, self.rank)
         self.n = self.row1 - self.row0
         self.ldx = _pad16(self.d)
         self.ldv = _pad16(max(self.n, 1))
@@ -192,7 +191,7 @@ class GaussianProcess(object):
         if self.world == 1:
             return loc.cpu().numpy()
         import torch.distributed as dist
-        sizes = [self.n_total * (r + 1) // self.world - self.n_total * r // self.world for r in range(self.world)]
+        sizes = [b - a for a, b in (sharding.row_range(self.n_total, self.world, r) for r in range(self.world))]
         parts = [torch.empty(s, dtype=loc.dtype, device=self.device) for s in sizes]
         dist.all_gather(parts, loc.contiguous(), group=self.group)
         return torch.cat(parts).cpu().numpy()

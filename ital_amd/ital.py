@@ -16,7 +16,7 @@ import ctypes
 import numpy as np
 import torch
 
-from . import _lib, mvn_stream
+from . import _lib, mvn_stream, sharding
 from ._lib import ITAL_JUMP_BITS, ITAL_MAX_T, ITAL_REC_HEADER, ItalBatch, ItalScoreDesc, check
 from .gp import _pad16, _ptr, _stream
 from .retrieval_base import ActiveRetrievalBase
@@ -149,14 +149,7 @@ class ITAL(ActiveRetrievalBase):
             st = _stream()
             # ---- candidate shard of this rank (list positions keep their global numbering)
             cand = np.asarray(candidates, dtype=np.int64)
-            if gp.world == 1 and self.top_candidates is None:
-                loc_rows, pos_offset = cand, 0
-            else:
-                mine = np.flatnonzero((cand >= gp.row0) & (cand < gp.row1))
-                if len(mine) and not np.array_equal(mine, np.arange(mine[0], mine[0] + len(mine))):
-                    raise NotImplementedError("top_candidates ordering across several ranks")
-                loc_rows = cand[mine]
-                pos_offset = int(mine[0]) if len(mine) else 0
+            loc_rows, pos_offset = sharding.shard_candidates(cand, gp.row0, gp.row1)
             n_loc = len(loc_rows)
             cand_d = torch.from_numpy((loc_rows - gp.row0).astype(np.int32)).to(dev) if n_loc else \
                 torch.zeros(1, dtype=torch.int32, device=dev)
@@ -193,12 +186,7 @@ class ITAL(ActiveRetrievalBase):
                                             _ptr(gp.mu), _ptr(gp.s2), _ptr(gp.Xd), _ptr(gp.xnorm), gp.ldx, _ptr(gp.V),
                                             gp.ldv, gp.m, gp.cap, _ptr(b["C"]), gp.ldv, t - 1, b["kmax"], _ptr(b["work"]),
                                             _ptr(b["rec"]), st))
-                if gp.world > 1:
-                    import torch.distributed as dist
-                    dist.all_gather_into_tensor(b["rec_all"].view(-1), b["rec"], group=gp.group)
-                    recs = b["rec_all"]
-                else:
-                    recs = b["rec"]
+                recs = sharding.gather_records(b["rec"], b["rec_all"], gp.group) if gp.world > 1 else b["rec"]
                 check(lib.ital_select_resolve(_ptr(recs), gp.world, b["rec_len"], gp.rank, 0, t - 1, b["batch"],
                                               _ptr(alive), _ptr(b["ret"]), st))
                 if t < k:

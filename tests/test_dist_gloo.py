@@ -1,0 +1,90 @@
+"""N > 1 path on CPU: world size 2 over gloo.  Exercises the product's sharding arithmetic and the one-record-per-rank
+exchange of a greedy step (ital_amd/sharding.py), and checks the winner rule against np.argmax / np.argmin."""
+import os
+import socket
+
+import numpy as np
+import pytest
+
+torch = pytest.importorskip("torch")
+import torch.distributed as dist  # noqa: E402
+import torch.multiprocessing as mp  # noqa: E402
+
+from ital_amd import sharding  # noqa: E402
+
+REC = 8 + 16 + 16 + 4
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, n_total, seen, scores, mode, ret):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        cand = [i for i in range(n_total) if i not in seen]
+        row0, row1 = sharding.row_range(n_total, world, rank)
+        loc, pos_offset = sharding.shard_candidates(cand, row0, row1)
+        rec = torch.zeros(REC, dtype=torch.float64)
+        if len(loc):
+            vals = scores[loc]
+            # local arg-extreme with the reference's rule (first extreme, NaN wins)
+            lp = int(np.argmax(vals) if mode == 0 else np.argmin(vals))
+            rec[0], rec[1], rec[2], rec[6], rec[7] = float(vals[lp]), pos_offset + lp, int(loc[lp]), rank, lp
+        else:
+            rec[1] = -1
+        out = torch.zeros((world, REC), dtype=torch.float64)
+        sharding.gather_records(rec, out, None)
+        w = sharding.winner(out.numpy(), mode)
+        ret[rank] = (int(out[w, 2]), out.numpy().copy(), (row0, row1, pos_offset, len(loc)))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("mode,case", [(0, "plain"), (0, "ties"), (0, "nan"), (1, "plain"), (0, "empty_rank")])
+def test_two_rank_exchange(mode, case):
+    rng = np.random.default_rng(11)
+    n_total = 41
+    scores = rng.normal(size=n_total)
+    seen = {3, 20, 21}
+    if case == "ties":
+        scores[[5, 30, 35]] = scores.max() + 1.0       # equal maxima on both ranks: lowest list position wins
+    if case == "nan":
+        scores[33] = np.nan                              # a NaN beats every number (np.argmax)
+        scores[7] = scores[np.isfinite(scores)].max() + 5
+    if case == "empty_rank":
+        seen = set(range(20, 41))                        # rank 1 has no live candidate
+    world, port = 2, _free_port()
+    with mp.Manager() as mgr:
+        ret = mgr.dict()
+        mp.spawn(_worker, args=(world, port, n_total, seen, scores, mode, ret), nprocs=world, join=True)
+        r0, r1 = ret[0], ret[1]
+    cand = [i for i in range(n_total) if i not in seen]
+    vals = scores[cand]
+    expect = cand[int(np.argmax(vals) if mode == 0 else np.argmin(vals))]
+    assert r0[0] == expect and r1[0] == expect                      # both ranks pick the reference's sample
+    assert np.array_equal(r0[1], r1[1], equal_nan=True)             # and hold identical gathered records
+    (a0, b0, p0, n0), (a1, b1, p1, n1) = r0[2], r1[2]
+    assert a0 == 0 and b0 == a1 and b1 == n_total                   # row blocks tile the data
+    assert n0 + n1 == len(cand) and (n1 == 0 or p1 == n0)           # list positions are continuous across ranks
+
+
+def test_row_range_tiles():
+    for n in (1, 7, 64, 9298, 1000003):
+        for world in (1, 2, 3, 8):
+            edges = [sharding.row_range(n, world, r) for r in range(world)]
+            assert edges[0][0] == 0 and edges[-1][1] == n
+            assert all(edges[i][1] == edges[i + 1][0] for i in range(world - 1))
+            sizes = [b - a for a, b in edges]
+            assert max(sizes) - min(sizes) <= 1
+
+
+def test_top_candidates_order_is_rejected_across_ranks():
+    with pytest.raises(NotImplementedError):
+        sharding.shard_candidates([5, 30, 6, 31], 0, 20)
