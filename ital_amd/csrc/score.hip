@@ -148,7 +148,8 @@ struct Qmc {
     static constexpr int A_PIVOT = 0, A_COR = A_PIVOT + T, A_MU0 = A_COR + NCOR, A_G = A_MU0 + T, A_SD = A_G + T * T,
                          A_SIZE = A_SD + T;
     static constexpr int LAT = 8 * NDIM * 2;                  // per call: permuted generators + shifts, 8 shifts
-    static constexpr int WAVE_DOUBLES = CHUNK * SLAB + A_SIZE + LAT + NDIM + T;  // + running vk + perm
+    static constexpr int TAILQ = 512;                         // compaction queue of the Phi^-1 tail branch (in + out)
+    static constexpr int WAVE_DOUBLES = CHUNK * SLAB + A_SIZE + LAT + NDIM + T + TAILQ;  // + running vk + perm
 };
 
 __device__ __forceinline__ int pidx(int i, int j) { return i * (i + 1) / 2 + j; }  // packed lower, 0-based, j <= i
@@ -213,6 +214,45 @@ __device__ bool covsrt(double* cov, double* lim, double* y, unsigned& infi) {
     return ok;
 }
 
+__device__ __forceinline__ double uniform_f64(double v) {
+    const int lo = __builtin_amdgcn_readfirstlane(__double2loint(v));
+    const int hi = __builtin_amdgcn_readfirstlane(__double2hiint(v));
+    return __hiloint2double(hi, lo);
+}
+
+// Four independent Phi^-1 arguments per lane.  Every lane runs the cheap central branch of AS241; the ~15 % of the
+// arguments that fall into the tails (|p - 1/2| > 0.425) are compacted across the wave through LDS so that the
+// expensive log/sqrt branch runs on full waves of tail arguments only (typically once per 256 inversions instead of
+// once per 64).
+__device__ __forceinline__ void phinv_wave4(const double (&p)[4], double (&out)[4], double* __restrict__ q, int lane) {
+    bool need[4];
+    int slot[4];
+    int total = 0;
+#pragma unroll
+    for (int c = 0; c < 4; c++) {
+        need[c] = !phinv_is_central(p[c]);
+        out[c] = phinv_central(need[c] ? 0.5 : p[c]);
+        const unsigned long long m = __ballot(need[c]);
+        slot[c] = total + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
+        total += __popcll(m);
+        if (need[c]) q[slot[c]] = p[c];
+    }
+    if (total == 0) return;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    for (int s0 = 0; s0 < total; s0 += 64) {
+        const int sl = s0 + lane;
+        if (sl < total) q[256 + sl] = phinv_tail(q[sl]);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+    for (int c = 0; c < 4; c++)
+        if (need[c]) out[c] = q[256 + slot[c]];
+}
+
 template <int T>
 __global__ __launch_bounds__(256) void score_qmc_kernel(ScoreArgs a) {
     using Q = Qmc<T>;
@@ -228,6 +268,7 @@ __global__ __launch_bounds__(256) void score_qmc_kernel(ScoreArgs a) {
     double* lat = area + Q::A_SIZE;          // [8][NDIM] generators, then [8][NDIM] shifts
     double* vkrun = lat + Q::LAT;            // running (shuffled) generator vector
     int* perm = reinterpret_cast<int*>(vkrun + Q::NDIM);  // T ints: natural index held at each sorted slot
+    double* tailq = vkrun + Q::NDIM + T;
 
     const int row = a.cand[p];
     const int64_t gi = a.row_offset + row;
@@ -407,52 +448,62 @@ __global__ __launch_bounds__(256) void score_qmc_kernel(ScoreArgs a) {
                     for (int j = 0; j < Q::NDIM; j++) lat[sft * Q::NDIM + j] = vkrun[j];
                     for (int j = 0; j < Q::NDIM; j++) lat[8 * Q::NDIM + sft * Q::NDIM + j] = mrg_next(rng);
                 }
-                // per-call constants out of the preparing lane's slab
+                // per-call constants out of the preparing lane's slab, as wave-uniform (scalar) values
                 const double* cov = slabs + cl * Q::SLAB;
-                double cf[Q::NCOV > 1 ? Q::NCOR : 1], lm[T];
+                double cf[Q::NCOR > 0 ? Q::NCOR : 1], lm[T];
 #pragma unroll
                 for (int i = 0; i < T; i++) {
-                    lm[i] = cov[Q::NCOV + i];
+                    lm[i] = uniform_f64(cov[Q::NCOV + i]);
 #pragma unroll
-                    for (int j = 0; j < i; j++) cf[i * (i - 1) / 2 + j] = cov[pidx(i, j)];
+                    for (int j = 0; j < i; j++) cf[i * (i - 1) / 2 + j] = uniform_f64(cov[pidx(i, j)]);
                 }
                 double acc = 0.0;
-                for (int item = lane; item < 8 * Q::PRIME; item += 64) {
-                    const int sft = item / Q::PRIME;
-                    const int k = item - sft * Q::PRIME + 1;
-                    double x0[Q::NDIM], x1[Q::NDIM];
+                // NCH = 4 independent chains per lane: two lattice items, each with its antithetic partner
+                for (int base = 0; base < 8 * Q::PRIME; base += 128) {
+                    double xx[4][Q::NDIM], yy[4][Q::NDIM], ff[4];
+                    bool dead[4];
 #pragma unroll
-                    for (int j = 0; j < Q::NDIM; j++) {
-                        const double v = k * lat[sft * Q::NDIM + j] + lat[8 * Q::NDIM + sft * Q::NDIM + j];
-                        const double fr = v - floor(v);
-                        x0[j] = fabs(2 * fr - 1);
-                        x1[j] = 1 - x0[j];
+                    for (int h = 0; h < 2; h++) {
+                        const int item = base + 64 * h + lane;
+                        const bool ok = item < 8 * Q::PRIME;
+                        const int it = ok ? item : 0;
+                        const int sft = it / Q::PRIME;
+                        const int k = it - sft * Q::PRIME + 1;
+#pragma unroll
+                        for (int j = 0; j < Q::NDIM; j++) {
+                            const double v = k * lat[sft * Q::NDIM + j] + lat[8 * Q::NDIM + sft * Q::NDIM + j];
+                            const double fr = v - floor(v);
+                            xx[2 * h][j] = fabs(2 * fr - 1);
+                            xx[2 * h + 1][j] = 1 - xx[2 * h][j];
+                        }
+                        ff[2 * h] = ff[2 * h + 1] = 1.0;
+                        dead[2 * h] = dead[2 * h + 1] = !ok;
                     }
-                    // MVNDFN on the point and its antithetic partner, interleaved for ILP
-                    double f0 = 1.0, f1 = 1.0, y0[T], y1[T];
-                    bool z0 = false, z1 = false;
 #pragma unroll
                     for (int i = 0; i < T; i++) {
-                        double s0 = 0, s1 = 0;
-#pragma unroll
-                        for (int j = 0; j < i; j++) {
-                            s0 += cf[i * (i - 1) / 2 + j] * y0[j];
-                            s1 += cf[i * (i - 1) / 2 + j] * y1[j];
-                        }
                         const bool lower = (infi_c >> i) & 1u;
-                        const double p0 = mvn_phi(lm[i] - s0), p1 = mvn_phi(lm[i] - s1);
-                        const double d0 = lower ? p0 : 0.0, d1 = lower ? p1 : 0.0;
-                        const double w0 = lower ? 1.0 - p0 : p0, w1 = lower ? 1.0 - p1 : p1;
-                        z0 = z0 || !(w0 > 0);
-                        z1 = z1 || !(w1 > 0);
-                        f0 *= w0;
-                        f1 *= w1;
+                        double pin[4];
+#pragma unroll
+                        for (int c = 0; c < 4; c++) {
+                            double sc = 0;
+#pragma unroll
+                            for (int j = 0; j < i; j++) sc = fma(cf[i * (i - 1) / 2 + j], yy[c][j], sc);
+                            const double ph = mvn_phi(lm[i] - sc);
+                            const double d = lower ? ph : 0.0;
+                            const double w = lower ? 1.0 - ph : ph;
+                            dead[c] = dead[c] || !(w > 0);
+                            ff[c] *= w;
+                            if (i < T - 1) pin[c] = dead[c] ? 0.5 : fma(xx[c][i], w, d);
+                        }
                         if (i < T - 1) {
-                            y0[i] = mvn_phinv(d0 + x0[i] * w0);
-                            y1[i] = mvn_phinv(d1 + x1[i] * w1);
+                            double out[4];
+                            phinv_wave4(pin, out, tailq, lane);
+#pragma unroll
+                            for (int c = 0; c < 4; c++) yy[c][i] = out[c];
                         }
                     }
-                    acc += (z0 ? 0.0 : f0) + (z1 ? 0.0 : f1);
+#pragma unroll
+                    for (int c = 0; c < 4; c++) acc += dead[c] ? 0.0 : ff[c];
                 }
                 value = wave_sum(acc) / (16.0 * Q::PRIME);
             }
