@@ -131,6 +131,37 @@ int ital_select_local(const double* mi, const int32_t* cand, const uint8_t* aliv
 int ital_select_resolve(const double* records, int world, int rec_len, int rank, int mode, int slot,
                         ital_batch batch, uint8_t* alive, int64_t* ret, hipStream_t stream);
 
+/* ---- MCMI[min] (pairwise objective) ---------------------------------------------------------------------- */
+
+/* Dense posterior covariance block out[i][j] = k(a_i, b_j) - Va[:,i].Vb[:,j] between na and nb points (FP64 MFMA).
+ * Replaces K_all[np.ix_(pred, ...)] - k_test^T K_inv k_test, reference ital/gp.py:226, :334-336, for the candidate
+ * block MCMI_min scores against (reference ital/mcmi.py:115). */
+int ital_cov_block(const double* Xa, const double* an, int64_t na, const double* Xb, const double* bn, int64_t nb,
+                   int ldx, const double* Va, int64_t ldva, const double* Vb, int64_t ldvb, int m, double var,
+                   double length_scale, double* out, int64_t ldo, hipStream_t stream);
+
+typedef struct ital_mcmi_desc {
+    int t;                  /* batch dimension of this greedy step */
+    int64_t n_i;            /* candidates scored by this rank: block positions pos_offset .. pos_offset + n_i - 1 */
+    int64_t pos_offset;
+    int64_t n_all;          /* size of the candidate block (the objective sums over all of it) */
+    const uint8_t* alive;   /* [n_i] 0 once picked */
+    const double* mu;       /* [n_all] predictive mean of the block */
+    const double* s2;       /* [n_all] predictive variance, NOT clamped */
+    const double* cov;      /* [n_i][ld_cov] posterior covariance of the own candidates with the block */
+    int64_t ld_cov;
+    const double* C;        /* [t-1][ldc] posterior covariance of member b with the block */
+    int64_t ldc;
+    ital_batch batch;       /* bgpos = block position of each member */
+    double noise, eps;
+    double* ce;             /* [n_i] out: min over label patterns of the summed conditional entropy */
+} ital_mcmi_desc;
+
+/* ce[i] = min_r sum_j [q log(q+eps) + (1-q) log(1-q+eps)], q = P(candidate j irrelevant | batch + i labelled r).
+ * Replaces the Pool.map over AppendedConditionalEntropy.__call__, reference ital/mcmi.py:69-75, :101-124
+ * (updated_prediction(..., cov_mode='diag') over all candidates, gp.py:295-344, and scipy.stats.norm.cdf). */
+int ital_mcmi_score_step(const ital_mcmi_desc* d, hipStream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,37 @@
+"""Device buffers of one greedy batch construction (the replicated batch state of include/ital_hip.h `ital_batch`,
+the per-member covariance columns, the selection record and its gather target)."""
+import torch
+
+from ._lib import ITAL_REC_HEADER, ItalBatch
+
+
+def _ptr(t):
+    return 0 if t is None else t.data_ptr()
+
+
+def make_batch_buffers(device, kmax, ldx, cap, ldc, world):
+    """kmax: batch capacity; ldx: padded feature dimension; cap: labelled-set capacity (leading dimension of the
+    whitened columns); ldc: length of one covariance column; world: number of ranks exchanging records."""
+    kmax = max(int(kmax), 4)
+    f64, i64, i32 = torch.float64, torch.int64, torch.int32
+    b = dict(kmax=kmax, ldw=cap, ldc=ldc, ldx=ldx)
+    b["bidx"] = torch.zeros(kmax, dtype=i64, device=device)
+    b["bgpos"] = torch.zeros(kmax, dtype=i64, device=device)
+    b["bsort"] = torch.zeros(kmax, dtype=i32, device=device)
+    b["bmu"] = torch.zeros(kmax, dtype=f64, device=device)
+    b["sig"] = torch.zeros(kmax * kmax, dtype=f64, device=device)
+    b["XB"] = torch.zeros((kmax, ldx), dtype=f64, device=device)
+    b["XBn"] = torch.zeros(kmax, dtype=f64, device=device)
+    b["VB"] = torch.zeros((kmax, cap), dtype=f64, device=device)
+    b["C"] = torch.zeros((kmax, ldc), dtype=f64, device=device)
+    b["ret"] = torch.zeros(kmax, dtype=i64, device=device)
+    b["work"] = torch.zeros(2 * 1024, dtype=f64, device=device)
+    rec_len = ITAL_REC_HEADER + ldx + cap + kmax
+    b["rec_len"] = rec_len
+    b["rec"] = torch.zeros(rec_len, dtype=f64, device=device)
+    b["rec_all"] = torch.zeros((world, rec_len), dtype=f64, device=device)
+    b["jump"] = {}
+    b["vk"] = {}
+    b["batch"] = ItalBatch(kmax, ldx, cap, _ptr(b["bidx"]), _ptr(b["bgpos"]), _ptr(b["bsort"]), _ptr(b["bmu"]),
+                           _ptr(b["sig"]), _ptr(b["XB"]), _ptr(b["XBn"]), _ptr(b["VB"]))
+    return b

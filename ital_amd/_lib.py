@@ -29,6 +29,12 @@ class ItalScoreDesc(ctypes.Structure):
                 ("status", c_void_p)]
 
 
+class ItalMcmiDesc(ctypes.Structure):
+    _fields_ = [("t", c_int), ("n_i", c_int64), ("pos_offset", c_int64), ("n_all", c_int64), ("alive", c_void_p),
+                ("mu", c_void_p), ("s2", c_void_p), ("cov", c_void_p), ("ld_cov", c_int64), ("C", c_void_p),
+                ("ldc", c_int64), ("batch", ItalBatch), ("noise", c_double), ("eps", c_double), ("ce", c_void_p)]
+
+
 SIGNATURES = {
     "ital_version": (ctypes.c_char_p, []),
     "ital_last_error": (ctypes.c_char_p, []),
@@ -45,6 +51,9 @@ SIGNATURES = {
     "ital_predict": (c_int, [c_void_p, c_int64, c_int, c_void_p, c_void_p, c_int, c_void_p, c_int, c_void_p,
                              c_double, c_double, c_void_p, c_void_p, c_void_p]),
     "ital_score_step": (c_int, [ctypes.POINTER(ItalScoreDesc), c_void_p]),
+    "ital_cov_block": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_int, c_void_p, c_int64,
+                               c_void_p, c_int64, c_int, c_double, c_double, c_void_p, c_int64, c_void_p]),
+    "ital_mcmi_score_step": (c_int, [ctypes.POINTER(ItalMcmiDesc), c_void_p]),
     "ital_select_local": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int64, c_int, c_int, c_void_p,
                                   c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int64, c_int, c_int, c_void_p,
                                   c_int64, c_int, c_int, c_void_p, c_void_p, c_void_p]),

@@ -1,0 +1,296 @@
+// MCMI[min] (Guo & Greiner) candidate scorer -- reference ital/mcmi.py:101-124 `ConditionalEntropy.__call__`
+// as driven by MCMI_min.fetch_unlabelled (mcmi.py:48-81), role R11 of SURVEY.md.
+//
+// For the batch S = (members so far, candidate i) and every label pattern r in {-1,+1}^t the reference runs a
+// simulated GP update (gp.updated_prediction -> extend_inv, gp.py:295-344) and predicts mean / variance of ALL
+// current candidates j; here that update is the closed form on the t x t block
+//     W = (Sigma_SS + noise I)^-1,  u_j = W Sigma_Sj,
+//     mu'_j(r) = mu_j + u_j . (y_r - mu_S),   s'_j = max(0, s2_j - Sigma_jS u_j)        (independent of r)
+//     CE_r(i)  = sum_j q log(q + eps) + (1 - q) log(1 - q + eps),   q = ndtr(-mu'_j(r) / sqrt(s'_j))
+//     score(i) = min_r CE_r(i)     (first pattern kept when it is NaN, as `cur_ce < ce` in mcmi.py:121)
+// Sigma_ij over the candidate block comes from ital_cov_block (dense, FP64 MFMA): the pairwise objective is the one
+// place on the path that is a real matrix product (N_c x N_c x (d + m)).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "device_math.h"
+#include "ital_hip.h"
+#include "ital_internal.h"
+
+namespace ital {
+
+typedef double d4 __attribute__((ext_vector_type(4)));
+
+// ---------------------------------------------------------------------------------------------------------
+// out[i][j] = var*exp((|a_i|^2 + |b_j|^2 - 2 a_i.b_j)/s) - sum_r Va[r][i] Vb[r][j]
+// Block = 4 waves, tile 64 (i) x 64 (j): wave w owns i-rows 16w..16w+15 and all four 16-wide j tiles.
+struct CovArgs {
+    const double *Xa, *an; int64_t na;
+    const double *Xb, *bn; int64_t nb;
+    int ldx;
+    const double* Va; int64_t ldva;
+    const double* Vb; int64_t ldvb;
+    int m;
+    double var, s;
+    double* out; int64_t ldo;
+};
+
+__global__ __launch_bounds__(256) void cov_block_kernel(CovArgs a) {
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int col = lane & 15;
+    const int kg = lane >> 4;
+    const int64_t i0 = (int64_t)blockIdx.y * 64 + wave * 16;
+    const int64_t j0 = (int64_t)blockIdx.x * 64;
+    if (i0 >= a.na) return;
+    const int64_t ia = i0 + col;
+    const bool a_ok = ia < a.na;
+    const double* arow = a.Xa + (a_ok ? ia : 0) * a.ldx;
+    const double* brow[4];
+    bool b_ok[4];
+    int64_t jb[4];
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+        jb[q] = j0 + 16 * q + col;
+        b_ok[q] = jb[q] < a.nb;
+        brow[q] = a.Xb + (b_ok[q] ? jb[q] : 0) * a.ldx;
+    }
+    d4 dot[4], sv[4];
+#pragma unroll
+    for (int q = 0; q < 4; q++) { dot[q] = (d4){0, 0, 0, 0}; sv[q] = (d4){0, 0, 0, 0}; }
+    for (int k0 = 0; k0 < a.ldx; k0 += 16) {
+        const int kk = k0 + 4 * kg;
+        double2 a01 = {0, 0}, a23 = {0, 0};
+        if (a_ok) {
+            a01 = *reinterpret_cast<const double2*>(arow + kk);
+            a23 = *reinterpret_cast<const double2*>(arow + kk + 2);
+        }
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            double2 b01 = {0, 0}, b23 = {0, 0};
+            if (b_ok[q]) {
+                b01 = *reinterpret_cast<const double2*>(brow[q] + kk);
+                b23 = *reinterpret_cast<const double2*>(brow[q] + kk + 2);
+            }
+            dot[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(a01.x, b01.x, dot[q], 0, 0, 0);
+            dot[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(a01.y, b01.y, dot[q], 0, 0, 0);
+            dot[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(a23.x, b23.x, dot[q], 0, 0, 0);
+            dot[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(a23.y, b23.y, dot[q], 0, 0, 0);
+        }
+    }
+    for (int r0 = 0; r0 < a.m; r0 += 4) {
+        const int r = r0 + kg;
+        const bool r_ok = r < a.m;
+        const double av = (r_ok && a_ok) ? a.Va[(int64_t)r * a.ldva + ia] : 0.0;
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const double bv = (r_ok && b_ok[q]) ? a.Vb[(int64_t)r * a.ldvb + jb[q]] : 0.0;
+            sv[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, sv[q], 0, 0, 0);
+        }
+    }
+    // D layout: reg -> row (i) = kg + 4*reg, column (j) = col
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+        const double bnj = b_ok[q] ? a.bn[jb[q]] : 0.0;
+#pragma unroll
+        for (int reg = 0; reg < 4; reg++) {
+            const int64_t i = i0 + kg + 4 * reg;
+            if (i < a.na && b_ok[q]) {
+                const double ani = a.an[i];
+                a.out[i * a.ldo + jb[q]] = a.var * exp((ani + bnj - 2 * dot[q][reg]) / a.s) - sv[q][reg];
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+struct McmiArgs {
+    int64_t n_i, pos_offset, n_all;
+    const uint8_t* alive;
+    const double *mu, *s2, *S, *C;
+    int64_t lds_, ldc;
+    ital_batch b;
+    double noise, eps;
+    double* ce;
+};
+
+__device__ __forceinline__ double entropy_term(double z, double eps) {
+    const double q = ndtr(z);
+    const double p = 1.0 - q;
+    return q * log(q + eps) + p * log(p + eps);
+}
+
+// One workgroup per candidate i; the 256 threads stride over the candidates j.  Patterns are enumerated in
+// itertools.product order (variable 0 = slowest = most significant bit); TL low bits live in registers, the
+// remaining high bits are an outer loop.
+template <int T>
+__global__ __launch_bounds__(256) void mcmi_score_kernel(McmiArgs a) {
+    constexpr int TL = T < 5 ? T : 5;
+    constexpr int NL = 1 << TL;
+    constexpr int NH = 1 << (T - TL);
+    __shared__ double Wsh[T][T];
+    __shared__ double muS[T];
+    __shared__ double red[4][NL];
+    __shared__ int64_t mpos[T];
+    const int64_t li = blockIdx.x;
+    if (li >= a.n_i) return;
+    if (!a.alive[li]) return;
+    const int64_t gi = a.pos_offset + li;  // position of candidate i in the candidate block
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (tid == 0) {
+        double Sg[T][T];
+        for (int p = 0; p < T - 1; p++) {
+            muS[p] = a.b.bmu[p];
+            mpos[p] = a.b.bgpos[p];
+            for (int q = 0; q < T - 1; q++) Sg[p][q] = a.b.sig[p * a.b.kmax + q];
+            const double c = a.C[(int64_t)p * a.ldc + gi];
+            Sg[p][T - 1] = c;
+            Sg[T - 1][p] = c;
+        }
+        muS[T - 1] = a.mu[gi];
+        mpos[T - 1] = gi;
+        Sg[T - 1][T - 1] = a.s2[gi];
+        // W = (Sigma + noise I)^-1 through the Cholesky factor
+        double Lc[T][T], Li[T][T];
+        for (int p = 0; p < T; p++)
+            for (int q = 0; q <= p; q++) {
+                double v = Sg[p][q] + (p == q ? a.noise : 0.0);
+                for (int r = 0; r < q; r++) v -= Lc[p][r] * Lc[q][r];
+                Lc[p][q] = (p == q) ? sqrt(v) : v / Lc[q][q];
+            }
+        for (int q = 0; q < T; q++)
+            for (int p = 0; p < T; p++) {
+                if (p < q) { Li[p][q] = 0; continue; }
+                double v = (p == q) ? 1.0 : 0.0;
+                for (int r = q; r < p; r++) v -= Lc[p][r] * Li[r][q];
+                Li[p][q] = v / Lc[p][p];
+            }
+        for (int p = 0; p < T; p++)
+            for (int q = 0; q <= p; q++) {
+                double w = 0;
+                for (int r = p; r < T; r++) w += Li[r][p] * Li[r][q];
+                Wsh[p][q] = w;
+                Wsh[q][p] = w;
+            }
+    }
+    __syncthreads();
+    double W[T][T], ms[T];
+#pragma unroll
+    for (int p = 0; p < T; p++) {
+        ms[p] = muS[p];
+#pragma unroll
+        for (int q = 0; q < T; q++) W[p][q] = Wsh[p][q];
+    }
+    const double* Srow = a.S + li * a.lds_;
+    double best = 0.0;
+    for (int hi = 0; hi < NH; hi++) {
+        double acc[NL];
+#pragma unroll
+        for (int r = 0; r < NL; r++) acc[r] = 0.0;
+        for (int64_t j = tid; j < a.n_all; j += 256) {
+            bool member = false;
+#pragma unroll
+            for (int p = 0; p < T - 1; p++) member = member || (mpos[p] == j);
+            if (member) continue;  // already picked: no longer in learner.candidates (mcmi.py:79)
+            double c[T], u[T];
+#pragma unroll
+            for (int p = 0; p < T - 1; p++) c[p] = a.C[(int64_t)p * a.ldc + j];
+            c[T - 1] = Srow[j];
+            double quad = 0, base = a.mu[j];
+#pragma unroll
+            for (int p = 0; p < T; p++) {
+                double v = 0;
+#pragma unroll
+                for (int q = 0; q < T; q++) v = fma(W[p][q], c[q], v);
+                u[p] = v;
+                quad = fma(c[p], v, quad);
+                base = fma(-v, ms[p], base);
+            }
+            const double sv = fmax(0.0, a.s2[j] - quad);
+            // high-order variables (an outer-loop constant per hi)
+#pragma unroll
+            for (int p = 0; p < T - TL; p++) base += ((hi >> (T - TL - 1 - p)) & 1) ? u[p] : -u[p];
+            double val[NL];
+            double lo = base;
+#pragma unroll
+            for (int p = T - TL; p < T; p++) lo -= u[p];
+            val[0] = lo;
+#pragma unroll
+            for (int bit = 0; bit < TL; bit++) {
+                const double two_u = 2.0 * u[T - 1 - bit];
+#pragma unroll
+                for (int r = 0; r < (1 << bit); r++) val[r | (1 << bit)] = val[r] + two_u;
+            }
+            if (sv > 0) {
+                const double inv_sd = 1.0 / sqrt(sv);
+#pragma unroll
+                for (int r = 0; r < NL; r++) acc[r] += entropy_term(-val[r] * inv_sd, a.eps);
+            } else {
+                // norm.cdf(0, mean, 0) is NaN (scipy scale check): the whole sum becomes NaN
+#pragma unroll
+                for (int r = 0; r < NL; r++) acc[r] = __builtin_nan("");
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < NL; r++) {
+            const double v = wave_sum(acc[r]);
+            if (lane == 0) red[wave][r] = v;
+        }
+        __syncthreads();
+        if (tid == 0) {
+            for (int r = 0; r < NL; r++) {
+                const double v = (red[0][r] + red[1][r]) + (red[2][r] + red[3][r]);
+                if ((hi == 0 && r == 0) || v < best) best = v;
+            }
+        }
+        __syncthreads();
+    }
+    if (tid == 0) a.ce[li] = best;
+}
+
+template <int T>
+static int launch_mcmi(const McmiArgs& a, hipStream_t stream) {
+    hipLaunchKernelGGL(mcmi_score_kernel<T>, dim3((unsigned)a.n_i), dim3(256), 0, stream, a);
+    return ital_check_launch("ital_mcmi_score_step");
+}
+
+}  // namespace ital
+
+using namespace ital;
+
+extern "C" int ital_cov_block(const double* Xa, const double* an, int64_t na, const double* Xb, const double* bn,
+                              int64_t nb, int ldx, const double* Va, int64_t ldva, const double* Vb, int64_t ldvb, int m,
+                              double var, double length_scale, double* out, int64_t ldo, hipStream_t stream) {
+    if (na <= 0 || nb <= 0) return 0;
+    if (ldx % 16 != 0) return ital_fail(-22, "ital_cov_block: ldx must be a multiple of 16");
+    if (m < 0 || (m > 0 && (!Va || !Vb))) return ital_fail(-22, "ital_cov_block: whitened blocks missing");
+    if (ldo < nb) return ital_fail(-22, "ital_cov_block: ldo smaller than nb");
+    const int64_t gx = (nb + 63) / 64, gy = (na + 63) / 64;
+    if (gy > 65535) return ital_fail(-22, "ital_cov_block: more than 65535*64 rows per call");
+    CovArgs a = {Xa, an, na, Xb, bn, nb, ldx, Va, ldva, Vb, ldvb, m, var, -2.0 * length_scale * length_scale, out, ldo};
+    hipLaunchKernelGGL(cov_block_kernel, dim3((unsigned)gx, (unsigned)gy), dim3(256), 0, stream, a);
+    return ital_check_launch("ital_cov_block");
+}
+
+extern "C" int ital_mcmi_score_step(const ital_mcmi_desc* d, hipStream_t stream) {
+    if (!d) return ital_fail(-22, "ital_mcmi_score_step: null descriptor");
+    if (d->n_i <= 0) return 0;
+    if (d->t < 1 || d->t > ITAL_MAX_T) return ital_fail(-22, "ital_mcmi_score_step: batch dimension outside 1..ITAL_MAX_T");
+    if (d->t > d->batch.kmax) return ital_fail(-22, "ital_mcmi_score_step: t exceeds the batch capacity");
+    if (d->pos_offset < 0 || d->pos_offset + d->n_i > d->n_all)
+        return ital_fail(-22, "ital_mcmi_score_step: candidate slice outside the candidate block");
+    if (d->ld_cov < d->n_all || d->ldc < d->n_all) return ital_fail(-22, "ital_mcmi_score_step: leading dimension too small");
+    McmiArgs a = {d->n_i, d->pos_offset, d->n_all, d->alive, d->mu, d->s2, d->cov, d->C, d->ld_cov, d->ldc, d->batch,
+                  d->noise, d->eps, d->ce};
+    switch (d->t) {
+        case 1: return launch_mcmi<1>(a, stream);
+        case 2: return launch_mcmi<2>(a, stream);
+        case 3: return launch_mcmi<3>(a, stream);
+        case 4: return launch_mcmi<4>(a, stream);
+        case 5: return launch_mcmi<5>(a, stream);
+        case 6: return launch_mcmi<6>(a, stream);
+        case 7: return launch_mcmi<7>(a, stream);
+        case 8: return launch_mcmi<8>(a, stream);
+    }
+    return ital_fail(-22, "ital_mcmi_score_step: unsupported batch dimension");
+}

@@ -18,6 +18,7 @@ import torch
 
 from . import _lib, mvn_stream, sharding
 from ._lib import ITAL_JUMP_BITS, ITAL_MAX_T, ITAL_REC_HEADER, ItalBatch, ItalScoreDesc, check
+from ._batch import make_batch_buffers
 from .gp import _pad16, _ptr, _stream
 from .retrieval_base import ActiveRetrievalBase
 
@@ -83,29 +84,7 @@ class ITAL(ActiveRetrievalBase):
         b = self._fetch_bufs
         if b is not None and b["kmax"] >= kmax and b["ldw"] == gp.cap:
             return b
-        dev = gp.device
-        kmax = max(kmax, 4)
-        f64, i64, i32 = torch.float64, torch.int64, torch.int32
-        b = dict(kmax=kmax, ldw=gp.cap)
-        b["bidx"] = torch.zeros(kmax, dtype=i64, device=dev)
-        b["bgpos"] = torch.zeros(kmax, dtype=i64, device=dev)
-        b["bsort"] = torch.zeros(kmax, dtype=i32, device=dev)
-        b["bmu"] = torch.zeros(kmax, dtype=f64, device=dev)
-        b["sig"] = torch.zeros(kmax * kmax, dtype=f64, device=dev)
-        b["XB"] = torch.zeros((kmax, gp.ldx), dtype=f64, device=dev)
-        b["XBn"] = torch.zeros(kmax, dtype=f64, device=dev)
-        b["VB"] = torch.zeros((kmax, gp.cap), dtype=f64, device=dev)
-        b["C"] = torch.zeros((kmax, gp.ldv), dtype=f64, device=dev)
-        b["ret"] = torch.zeros(kmax, dtype=i64, device=dev)
-        b["work"] = torch.zeros(2 * 1024, dtype=f64, device=dev)
-        rec_len = ITAL_REC_HEADER + gp.ldx + gp.cap + kmax
-        b["rec_len"] = rec_len
-        b["rec"] = torch.zeros(rec_len, dtype=f64, device=dev)
-        b["rec_all"] = torch.zeros((gp.world, rec_len), dtype=f64, device=dev)
-        b["jump"] = {}
-        b["vk"] = {}
-        b["batch"] = ItalBatch(kmax, gp.ldx, gp.cap, _ptr(b["bidx"]), _ptr(b["bgpos"]), _ptr(b["bsort"]), _ptr(b["bmu"]),
-                               _ptr(b["sig"]), _ptr(b["XB"]), _ptr(b["XBn"]), _ptr(b["VB"]))
+        b = make_batch_buffers(gp.device, kmax, gp.ldx, gp.cap, gp.ldv, gp.world)
         self._fetch_bufs = b
         return b
 

@@ -1,0 +1,150 @@
+"""MCMI[min] on MI355X: host-side mirror of reference ital/mcmi.py `MCMI_min` (drop-in learner).
+
+Guo & Greiner's optimistic active learner scores a candidate by the summed conditional entropy of ALL candidates
+after a simulated update with the most favourable labelling of the batch (reference mcmi.py:101-124) and picks
+the arg-min greedily (mcmi.py:69-79).  On the device:
+
+    once per fetch:  gather the candidate block (features, whitened columns, mean, variance)   [replicated]
+                     posterior covariance of the own candidates with the block  ital_cov_block (FP64 MFMA)
+    per greedy step: ital_mcmi_score_step -> ital_select_local(arg-min) -> [record all-gather] ->
+                     ital_select_resolve -> ital_cross_cov_cols (the picked member's covariance column)
+
+With several ranks the scored candidates (rows i of the pairwise objective) are split across ranks, the block they
+are scored against is replicated.
+"""
+import ctypes
+
+import numpy as np
+import torch
+
+from . import _lib, sharding
+from ._batch import make_batch_buffers
+from ._lib import ITAL_MAX_T, ItalMcmiDesc, check
+from .gp import _pad16, _ptr, _stream
+from .retrieval_base import ActiveRetrievalBase
+
+
+class MCMI_min(ActiveRetrievalBase):
+    """Constructor arguments as reference ital/mcmi.py:21-45; `parallelized` is accepted and ignored."""
+
+    #: refuse to materialise a covariance block larger than this many bytes per rank (use `subsample`, as the
+    #: reference's configs do: usps.conf:25-26)
+    max_cov_bytes = 96 << 30
+
+    def __init__(self, data=None, queries=[], length_scale=0.1, var=1.0, noise=1e-6, subsample=None,
+                 parallelized=True, *, device=None, rank=0, world=1, group=None):
+        ActiveRetrievalBase.__init__(self, data, queries, length_scale, var, noise, device=device, rank=rank,
+                                     world=world, group=group)
+        self.subsample = subsample
+        self.parallelized = parallelized
+        self.eps = 1e-12  # reference ital/mcmi.py:88
+        self.candidates = []
+        self.keep_scores = False
+        self.last_scores = None
+        self.profile = None
+
+    def _mark(self, stage=None, t=0, size=0, start=None):
+        if self.profile is None:
+            return None
+        ev = torch.cuda.Event(enable_timing=True)
+        ev.record()
+        if start is not None:
+            self.profile.append((stage, t, size, start, ev))
+        return ev
+
+    def _gather_block(self, cand):
+        """Features, squared norms, whitened columns, mean and variance of the candidate block on every rank."""
+        gp = self.gp
+        dev = gp.device
+        nc = len(cand)
+        ldc = _pad16(nc)
+        idx = torch.as_tensor(cand, dtype=torch.int64, device=dev)
+        own = (idx >= gp.row0) & (idx < gp.row1)
+        loc = idx[own] - gp.row0
+        Xc = torch.zeros((nc, gp.ldx), dtype=torch.float64, device=dev)
+        Vc = torch.zeros((max(gp.m, 1), ldc), dtype=torch.float64, device=dev)
+        vec = torch.zeros((3, nc), dtype=torch.float64, device=dev)  # |x|^2, mean, variance
+        if gp.world == 1:
+            Xc.copy_(gp.Xd.index_select(0, loc))
+            Vc[: gp.m, :nc] = gp.V[: gp.m].index_select(1, loc)
+            vec[0], vec[1], vec[2] = gp.xnorm[loc], gp.mu[loc], gp.s2[loc]
+        else:
+            import torch.distributed as dist
+            Xc[own] = gp.Xd.index_select(0, loc)
+            sel = torch.nonzero(own).squeeze(1)
+            Vc[: gp.m, sel] = gp.V[: gp.m].index_select(1, loc)
+            vec[0, sel], vec[1, sel], vec[2, sel] = gp.xnorm[loc], gp.mu[loc], gp.s2[loc]
+            for buf in (Xc, Vc, vec):
+                dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=gp.group)
+        return Xc, Vc, ldc, vec[0].contiguous(), vec[1].contiguous(), vec[2].contiguous()
+
+    def fetch_unlabelled(self, k, show_progress=False):
+        """Fetches a batch of unlabelled samples (reference ital/mcmi.py:48-81); list of python ints."""
+        gp = self.gp
+        if gp.m == 0:
+            raise RuntimeError("fetch_unlabelled() needs a fitted relevance model: call update() first or pass queries")
+        self.candidates = self.get_unseen()
+        if self.subsample and (self.subsample < len(self.candidates)):
+            # same call on the global numpy RNG as the reference (mcmi.py:61-63)
+            self.candidates = np.random.choice(self.candidates, self.subsample, replace=False).tolist()
+        if len(self.candidates) < k:
+            k = len(self.candidates)
+        if k <= 0:
+            return []
+        if k > ITAL_MAX_T:
+            raise NotImplementedError("batches larger than %d are not enumerated on the device" % ITAL_MAX_T)
+        lib = _lib.lib()
+        dev = gp.device
+        cand = np.asarray(self.candidates, dtype=np.int64)
+        nc = len(cand)
+        with torch.cuda.device(dev):
+            st = _stream()
+            Xc, Vc, ldc, xnc, muc, s2c = self._gather_block(cand)
+            i0, i1 = sharding.row_range(nc, gp.world, gp.rank)
+            n_i = i1 - i0
+            if max(n_i, 1) * ldc * 8 > self.max_cov_bytes:
+                raise MemoryError("MCMI_min: %d x %d covariance block; pass subsample= (reference configs use 1000)"
+                                  % (n_i, nc))
+            b = make_batch_buffers(dev, k, gp.ldx, gp.cap, ldc, gp.world)
+            cov = torch.empty((max(n_i, 1), ldc), dtype=torch.float64, device=dev)
+            ev0 = self._mark()
+            if n_i:
+                check(lib.ital_cov_block(_ptr(Xc[i0:]), _ptr(xnc[i0:]), n_i, _ptr(Xc), _ptr(xnc), nc, gp.ldx,
+                                         Vc.data_ptr() + 8 * i0, ldc, _ptr(Vc), ldc, gp.m, float(self.var),
+                                         float(self.length_scale), _ptr(cov), ldc, st))
+            self._mark("cov_block", 0, nc, ev0)
+            pos_d = torch.arange(i0, max(i1, i0 + 1), dtype=torch.int32, device=dev)
+            alive = torch.ones(max(n_i, 1), dtype=torch.uint8, device=dev)
+            ce = torch.zeros(max(n_i, 1), dtype=torch.float64, device=dev)
+            self.last_scores = []
+            for t in range(1, k + 1):
+                desc = ItalMcmiDesc()
+                desc.t, desc.n_i, desc.pos_offset, desc.n_all = t, n_i, i0, nc
+                desc.alive, desc.mu, desc.s2 = _ptr(alive), _ptr(muc), _ptr(s2c)
+                desc.cov, desc.ld_cov, desc.C, desc.ldc = _ptr(cov), ldc, _ptr(b["C"]), ldc
+                desc.batch = b["batch"]
+                desc.noise, desc.eps = float(self.noise), float(self.eps)
+                desc.ce = _ptr(ce)
+                ev0 = self._mark()
+                check(lib.ital_mcmi_score_step(ctypes.byref(desc), st))
+                self._mark("mcmi_score", t, nc - (t - 1), ev0)
+                if self.keep_scores:
+                    self.last_scores.append(ce.clone())
+                check(lib.ital_select_local(_ptr(ce), _ptr(pos_d), _ptr(alive), n_i, i0, 0, gp.rank, 1, _ptr(muc),
+                                            _ptr(s2c), _ptr(Xc), _ptr(xnc), gp.ldx, _ptr(Vc), ldc, gp.m, gp.cap,
+                                            _ptr(b["C"]), ldc, t - 1, b["kmax"], _ptr(b["work"]), _ptr(b["rec"]), st))
+                recs = sharding.gather_records(b["rec"], b["rec_all"], gp.group) if gp.world > 1 else b["rec"]
+                check(lib.ital_select_resolve(_ptr(recs), gp.world, b["rec_len"], gp.rank, 1, t - 1, b["batch"],
+                                              _ptr(alive), _ptr(b["ret"]), st))
+                if t < k:
+                    slot = t - 1
+                    check(lib.ital_cross_cov_cols(_ptr(Xc), _ptr(xnc), nc, gp.ldx, _ptr(b["XB"][slot]),
+                                                  _ptr(b["XBn"][slot:]), 1, _ptr(b["VB"][slot]), gp.cap, _ptr(Vc), ldc,
+                                                  gp.m, float(self.var), float(self.length_scale), _ptr(b["C"][slot]),
+                                                  ldc, st))
+            picked = b["ret"][:k].cpu().tolist()  # block positions; the only synchronisation of the round
+        gp.check_status()
+        ret = [int(cand[p]) for p in picked]
+        gone = set(picked)
+        self.candidates = [int(c) for p, c in enumerate(cand) if p not in gone]  # as `del self.candidates[min_ind]`
+        return ret

@@ -1,0 +1,127 @@
+"""Parity of the device MCMI_min (reference ital/mcmi.py) with the reference's golden vectors and with the oracle,
+through the C ABI.  Run on the GPU box: python -m pytest tests -m gpu."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+torch = pytest.importorskip("torch")
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"))
+import make_golden  # noqa: E402  (fixture table only)
+
+# conditional-entropy sums are O(-0.5 * N_c); the dense reference route (explicit (m+t)^2 inverse, gp.py:295-344)
+# and the whitened closed form agree to ~1e-10 relative, far inside the 1e-5 bar of BASELINE.json
+CE_RTOL = 1e-8
+
+
+@pytest.fixture(scope="module")
+def dev():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    return "cuda:0"
+
+
+def test_cov_block_vs_oracle(dev):
+    from ital_amd import GaussianProcess
+    from ital_amd import _lib
+    from ital_amd.gp import _ptr, _stream
+    from oracle.gp import OracleGP
+    rng = np.random.default_rng(11)
+    n, d = 333, 21
+    X = rng.random((n, d))
+    ls = float(np.sqrt(d / 12.0))
+    gp = GaussianProcess(X, ls, var=1.2, device=dev)
+    ref = OracleGP(X, ls, var=1.2)
+    idx = rng.choice(n, 9, replace=False).tolist()
+    y = np.where(rng.random(9) > 0.5, 1.0, -1.0)
+    gp.update(idx, y)
+    ref.update(idx, y)
+    a = np.sort(rng.choice(n, 70, replace=False))
+    b = np.sort(rng.choice(n, 130, replace=False))
+    ta, tb = torch.as_tensor(a, device=dev), torch.as_tensor(b, device=dev)
+    Xa, Xb = gp.Xd.index_select(0, ta), gp.Xd.index_select(0, tb)
+    Va = gp.V[: gp.m].index_select(1, ta).contiguous()
+    Vb = gp.V[: gp.m].index_select(1, tb).contiguous()
+    na, nb = gp.xnorm[ta].contiguous(), gp.xnorm[tb].contiguous()   # named: the pointers must outlive the launch
+    out = torch.full((len(a), 144), -7.0, dtype=torch.float64, device=dev)
+    _lib.check(_lib.lib().ital_cov_block(_ptr(Xa), _ptr(na), len(a), _ptr(Xb),
+                                         _ptr(nb), len(b), gp.ldx, _ptr(Va), len(a), _ptr(Vb),
+                                         len(b), gp.m, 1.2, ls, _ptr(out), 144, _stream()))
+    got = out.cpu().numpy()
+    want = ref.predict_stored(np.concatenate((a, b)), cov_mode="full")[1][: len(a), len(a):]
+    np.testing.assert_allclose(got[:, : len(b)], want, rtol=0, atol=2e-9)
+    assert np.all(got[:, len(b):] == -7.0)          # padding columns untouched
+
+
+@pytest.mark.parametrize("name", ["usps500_mcmi", "synth300_mcmi"])
+def test_golden_mcmi(dev, golden_dir, name):
+    from ital_amd import MCMI_min
+    z = np.load(os.path.join(golden_dir, name + ".npz"))
+    spec = make_golden.FIXTURES[name]
+    np.random.seed(0)
+    L = MCMI_min(z["X"], length_scale=float(z["length_scale"]), device=dev, **spec["kw"])
+    L.keep_scores = True
+    L.update({int(z["query"]): 1})
+    rel = z["rel"]
+    for r in range(int(z["rounds"])):
+        ret = L.fetch_unlabelled(int(z["k"]))
+        cand0 = z[f"r{r}_s0_cand"].tolist()
+        pos = {c: i for i, c in enumerate(cand0)}
+        for t in range(len(ret)):
+            cand = z[f"r{r}_s{t}_cand"].tolist()
+            mine = L.last_scores[t].cpu().numpy()[[pos[c] for c in cand]]
+            np.testing.assert_allclose(mine, z[f"r{r}_s{t}_mi"], rtol=CE_RTOL, atol=0, err_msg=f"{name} r{r} step {t}")
+        assert ret == z[f"r{r}_ret"].tolist(), (name, r)          # selected indices bit-exact
+        assert len(L.candidates) == len(cand0) - len(ret) and not set(ret) & set(L.candidates)
+        L.update({int(i): float(rel[i]) for i in ret})
+    np.testing.assert_allclose(L.rel_mean, z["final_rel_mean"], rtol=0, atol=1e-9)
+
+
+@pytest.mark.parametrize("seed,n,d,k,sub", [(0, 140, 6, 4, None), (1, 260, 18, 5, 90), (2, 64, 3, 6, None)])
+def test_mcmi_against_oracle(dev, seed, n, d, k, sub):
+    from ital_amd import MCMI_min
+    from oracle.ital import OracleMCMI
+    rng = np.random.default_rng(seed)
+    X = rng.random((n, d))
+    ls = float(np.sqrt(d / 12.0))
+    labels = {int(i): (1 if X[i, 0] > 0.5 else -1) for i in rng.choice(n, 4, replace=False)}
+    A = MCMI_min(X, length_scale=ls, subsample=sub, device=dev)
+    A.keep_scores = True
+    B = OracleMCMI(X, length_scale=ls, subsample=sub)
+    A.update(labels)
+    B.update(labels)
+    for _ in range(2):
+        np.random.seed(seed)
+        got = A.fetch_unlabelled(k)
+        np.random.seed(seed)
+        want = [int(i) for i in B.fetch_unlabelled(k)]
+        cand0 = B.trace[0][0]
+        pos = {c: i for i, c in enumerate(cand0)}
+        for t, (cand, vals, _) in enumerate(B.trace):
+            mine = A.last_scores[t].cpu().numpy()[[pos[c] for c in cand]]
+            np.testing.assert_allclose(mine, vals, rtol=CE_RTOL, atol=0)
+        assert got == want
+        fb = {i: (1 if X[i, 0] > 0.5 else -1) for i in got}
+        A.update(fb)
+        B.update(fb)
+
+
+def test_mcmi_edge_cases(dev):
+    from ital_amd import MCMI_min
+    rng = np.random.default_rng(3)
+    X = rng.random((9, 4))
+    L = MCMI_min(X, length_scale=0.6, device=dev)
+    with pytest.raises(RuntimeError):
+        L.fetch_unlabelled(2)
+    L.update({0: 1, 1: -1})
+    assert L.fetch_unlabelled(0) == []
+    ret = L.fetch_unlabelled(20)                    # more than there are candidates, and more than the device batch limit
+    assert sorted(ret) == list(range(2, 9)) and L.candidates == []
+    big = MCMI_min(rng.random((40, 4)), length_scale=0.6, device=dev)
+    big.update({0: 1})
+    with pytest.raises(NotImplementedError):
+        big.fetch_unlabelled(9)
