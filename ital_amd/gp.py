@@ -149,8 +149,7 @@ class GaussianProcess(object):
         if bool(own.any()):
             rows[own] = self.Xd.index_select(0, idx[own] - self.row0)
         if self.world > 1:
-            import torch.distributed as dist
-            dist.all_reduce(rows, op=dist.ReduceOp.SUM, group=self.group)
+            sharding.all_reduce_sum(rows, self.group)
         return rows
 
     def _append(self, rows, y):
@@ -190,11 +189,8 @@ class GaussianProcess(object):
         loc = t[: self.n]
         if self.world == 1:
             return loc.cpu().numpy()
-        import torch.distributed as dist
         sizes = [b - a for a, b in (sharding.row_range(self.n_total, self.world, r) for r in range(self.world))]
-        parts = [torch.empty(s, dtype=loc.dtype, device=self.device) for s in sizes]
-        dist.all_gather(parts, loc.contiguous(), group=self.group)
-        return torch.cat(parts).cpu().numpy()
+        return sharding.all_gather_parts(loc, sizes, self.group).cpu().numpy()
 
     def predict_stored(self, ind=None, cov_mode=None):
         """Predictive mean / variance / covariance of samples of the data matrix (reference gp.py:203-232)."""

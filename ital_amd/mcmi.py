@@ -69,13 +69,12 @@ class MCMI_min(ActiveRetrievalBase):
             Vc[: gp.m, :nc] = gp.V[: gp.m].index_select(1, loc)
             vec[0], vec[1], vec[2] = gp.xnorm[loc], gp.mu[loc], gp.s2[loc]
         else:
-            import torch.distributed as dist
             Xc[own] = gp.Xd.index_select(0, loc)
             sel = torch.nonzero(own).squeeze(1)
             Vc[: gp.m, sel] = gp.V[: gp.m].index_select(1, loc)
             vec[0, sel], vec[1, sel], vec[2, sel] = gp.xnorm[loc], gp.mu[loc], gp.s2[loc]
             for buf in (Xc, Vc, vec):
-                dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=gp.group)
+                sharding.all_reduce_sum(buf, gp.group)
         return Xc, Vc, ldc, vec[0].contiguous(), vec[1].contiguous(), vec[2].contiguous()
 
     def fetch_unlabelled(self, k, show_progress=False):

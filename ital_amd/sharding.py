@@ -25,6 +25,13 @@ def shard_candidates(candidates, row0, row1):
     return cand[mine], (int(mine[0]) if len(mine) else 0)
 
 
+def _host_staged(t, group):
+    """gloo moves host memory only: device tensors are staged through the host for it (CPU tests, and the
+    two-ranks-on-one-GPU parity test); RCCL ("nccl") takes device pointers directly."""
+    import torch.distributed as dist
+    return t.is_cuda and dist.get_backend(group) == "gloo"
+
+
 def gather_records(record, out, group=None):
     """ONE collective per greedy step: every rank contributes its fixed-size record, all ranks receive all of them.
     `record` [R], `out` [world, R] (same dtype/device)."""
@@ -33,8 +40,44 @@ def gather_records(record, out, group=None):
     if world == 1:
         out[0].copy_(record)
         return out
+    if _host_staged(record, group):
+        host = [torch_like_cpu(record) for _ in range(world)]
+        dist.all_gather(host, record.cpu(), group=group)
+        for w in range(world):
+            out[w].copy_(host[w])
+        return out
     dist.all_gather(list(out.unbind(0)), record, group=group)
     return out
+
+
+def torch_like_cpu(t):
+    import torch
+    return torch.empty(t.shape, dtype=t.dtype)
+
+
+def all_reduce_sum(t, group=None):
+    """In-place sum over ranks (replication of rows owned by one rank: owners contribute, the others add zeros)."""
+    import torch.distributed as dist
+    if _host_staged(t, group):
+        h = t.cpu()
+        dist.all_reduce(h, op=dist.ReduceOp.SUM, group=group)
+        t.copy_(h)
+        return t
+    dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+    return t
+
+
+def all_gather_parts(loc, sizes, group=None):
+    """Concatenation over ranks of 1-D shards of the given sizes."""
+    import torch
+    import torch.distributed as dist
+    if _host_staged(loc, group):
+        parts = [torch.empty(s, dtype=loc.dtype) for s in sizes]
+        dist.all_gather(parts, loc.cpu().contiguous(), group=group)
+        return torch.cat(parts).to(loc.device)
+    parts = [torch.empty(s, dtype=loc.dtype, device=loc.device) for s in sizes]
+    dist.all_gather(parts, loc.contiguous(), group=group)
+    return torch.cat(parts)
 
 
 def winner(records, mode=0):
