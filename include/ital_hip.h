@@ -24,6 +24,8 @@ typedef struct ihipStream_t* hipStream_t; /* same declaration as hip_runtime_api
 #define ITAL_MAX_T 8        /* largest batch dimension with full sign-pattern enumeration on the device */
 #define ITAL_REC_HEADER 8   /* doubles in front of the feature row inside a selection record */
 #define ITAL_JUMP_BITS 48
+#define ITAL_GENERIC_MAX_DIM 12  /* largest orthant dimension of the general scorer (subset + picks + candidate) */
+#define ITAL_GENERIC_MAX_REL 6   /* largest number of enumerated variables of the general scorer */
 
 /* Library identification / error reporting. */
 const char* ital_version(void);
@@ -161,6 +163,50 @@ typedef struct ital_mcmi_desc {
  * Replaces the Pool.map over AppendedConditionalEntropy.__call__, reference ital/mcmi.py:69-75, :101-124
  * (updated_prediction(..., cov_mode='diag') over all candidates, gp.py:295-344, and scipy.stats.norm.cdf). */
 int ital_mcmi_score_step(const ital_mcmi_desc* d, hipStream_t stream);
+
+/* ---- general scorer: noisy user models, change-estimation subset ------------------------------------------- */
+typedef struct ital_gscore_desc {
+    int64_t n_cand;         /* candidate-list positions held by this rank */
+    const int32_t* cand;    /* [n_cand] local row of each position */
+    const uint8_t* alive;   /* [n_cand] */
+    const double* mu;       /* [rows] */
+    const double* s2;       /* [rows] NOT clamped */
+    const double* C;        /* [nE][ldc] posterior covariance of base member e with every row */
+    int64_t ldc;
+    int64_t row_offset, pos_offset;
+    /* base set E: the change-estimation subset followed by the picks outside it (subset_mode 1), or the picks */
+    int nE;
+    const int64_t* E_idx;   /* [nE] data indices */
+    const int32_t* E_sort;  /* [nE] positions of E ordered by data index */
+    const double* E_mu;     /* [nE] */
+    const double* E_sig;    /* [nE][ldE] posterior covariance among E */
+    int ldE;
+    int n_picks;            /* picks so far (enumerated together with the candidate) */
+    const int32_t* pick_pos;/* [n_picks] their positions in E, selection order */
+    int subset_mode;        /* 0: MutualInformation._call_iter_all, 1: _call_iter_sub (reference ital/ital.py:183-275) */
+    int fb_mode;            /* 0 perfect user, 1 label_prob >= 1 with mistakes, 2 general (reference ital/ital.py:300-342) */
+    double label_prob, mistake_prob;
+    int label_mode;         /* 0 mean, 1 optimistic, 2 pessimistic (subset_mode 0 only) */
+    double noise, eps;
+    /* replay of mvndst's MVNUNI stream */
+    int seed[6];            /* generator state before the first call of this greedy step */
+    const long long* jump1; /* [ITAL_JUMP_BITS][18] transition matrices for 2^b uniforms */
+    const long long* skip;  /* [ITAL_GENERIC_MAX_DIM + 1][18] transition matrix of one call of dimension n */
+    const double* vk;       /* [ITAL_GENERIC_MAX_DIM + 1][ITAL_GENERIC_MAX_DIM] Korobov generators of dimension n */
+    int64_t draws_out;      /* uniforms one candidate outside E consumes */
+    int64_t draws_in;       /* ... one live candidate that is a member of E */
+    int n_in;
+    const int64_t* in_pos;  /* [n_in] list positions of the live candidates inside E */
+    int n_dead;
+    const int64_t* dead_pos;/* [n_dead] list positions already picked */
+    double* mi;             /* [n_cand] out */
+    int* status;
+} ital_gscore_desc;
+
+/* mi[p] = MI(batch + candidate p) for any user model / with a change-estimation subset.  Replaces
+ * MutualInformation._call_iter_all / _call_iter_sub (reference ital/ital.py:183-275) with rel_iter (:278-291, full
+ * enumeration), fb_iter (:300-342), likelihood (:453-481), prob_rel (:345-383) and updated_prob_rel (:432-450). */
+int ital_score_generic(const ital_gscore_desc* d, hipStream_t stream);
 
 #ifdef __cplusplus
 }

@@ -13,6 +13,8 @@ c_void_p, c_int, c_int64, c_double = ctypes.c_void_p, ctypes.c_int, ctypes.c_int
 ITAL_MAX_T = 8
 ITAL_REC_HEADER = 8
 ITAL_JUMP_BITS = 48
+ITAL_GENERIC_MAX_DIM = 12
+ITAL_GENERIC_MAX_REL = 6
 
 
 class ItalBatch(ctypes.Structure):
@@ -27,6 +29,17 @@ class ItalScoreDesc(ctypes.Structure):
                 ("pos_offset", c_int64), ("batch", ItalBatch), ("noise", c_double), ("eps", c_double),
                 ("label_mode", c_int), ("mi", c_void_p), ("seed", c_int * 6), ("jump", c_void_p), ("vk", c_void_p),
                 ("status", c_void_p)]
+
+
+class ItalGscoreDesc(ctypes.Structure):
+    _fields_ = [("n_cand", c_int64), ("cand", c_void_p), ("alive", c_void_p), ("mu", c_void_p), ("s2", c_void_p),
+                ("C", c_void_p), ("ldc", c_int64), ("row_offset", c_int64), ("pos_offset", c_int64),
+                ("nE", c_int), ("E_idx", c_void_p), ("E_sort", c_void_p), ("E_mu", c_void_p), ("E_sig", c_void_p),
+                ("ldE", c_int), ("n_picks", c_int), ("pick_pos", c_void_p), ("subset_mode", c_int), ("fb_mode", c_int),
+                ("label_prob", c_double), ("mistake_prob", c_double), ("label_mode", c_int), ("noise", c_double),
+                ("eps", c_double), ("seed", c_int * 6), ("jump1", c_void_p), ("skip", c_void_p), ("vk", c_void_p),
+                ("draws_out", c_int64), ("draws_in", c_int64), ("n_in", c_int), ("in_pos", c_void_p),
+                ("n_dead", c_int), ("dead_pos", c_void_p), ("mi", c_void_p), ("status", c_void_p)]
 
 
 class ItalMcmiDesc(ctypes.Structure):
@@ -54,6 +67,7 @@ SIGNATURES = {
     "ital_cov_block": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_int, c_void_p, c_int64,
                                c_void_p, c_int64, c_int, c_double, c_double, c_void_p, c_int64, c_void_p]),
     "ital_mcmi_score_step": (c_int, [ctypes.POINTER(ItalMcmiDesc), c_void_p]),
+    "ital_score_generic": (c_int, [ctypes.POINTER(ItalGscoreDesc), c_void_p]),
     "ital_select_local": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int64, c_int, c_int, c_void_p,
                                   c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int64, c_int, c_int, c_void_p,
                                   c_int64, c_int, c_int, c_void_p, c_void_p, c_void_p]),

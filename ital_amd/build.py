@@ -8,7 +8,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 INCLUDE = os.path.join(os.path.dirname(HERE), "include")
 LIB = os.path.join(HERE, "libital_hip.so")
-SOURCES = ["api.hip", "rbf.hip", "chol.hip", "score.hip", "select.hip", "mcmi.hip"]
+SOURCES = ["api.hip", "rbf.hip", "chol.hip", "score.hip", "select.hip", "mcmi.hip", "score_generic.hip"]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fgpu-rdc" if False else "-fno-gpu-rdc",
          "-I", INCLUDE, "-I", CSRC, "-Wall", "-Wno-unused-function"]

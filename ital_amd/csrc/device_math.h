@@ -191,26 +191,28 @@ __device__ __forceinline__ double norm_cdf0(double mean, double sd) {
     return ndtr((0.0 - mean) / sd);
 }
 
+// Gauss-Legendre nodes / weights of Genz's BVU (constant memory: indexed at run time).
+__constant__ const double BVU_W6[3] = {0.1713244923791705, 0.3607615730481384, 0.4679139345726904};
+__constant__ const double BVU_X6[3] = {-0.9324695142031522, -0.6612093864662647, -0.2386191860831970};
+__constant__ const double BVU_W12[6] = {0.4717533638651177e-01, 0.1069393259953183, 0.1600783285433464,
+                       0.2031674267230659, 0.2334925365383547, 0.2491470458134029};
+__constant__ const double BVU_X12[6] = {-0.9815606342467191, -0.9041172563704750, -0.7699026741943050,
+                       -0.5873179542866171, -0.3678314989981802, -0.1252334085114692};
+__constant__ const double BVU_W20[10] = {0.1761400713915212e-01, 0.4060142980038694e-01, 0.6267204833410906e-01,
+                        0.8327674157670475e-01, 0.1019301198172404, 0.1181945319615184, 0.1316886384491766,
+                        0.1420961093183821, 0.1491729864726037, 0.1527533871307259};
+__constant__ const double BVU_X20[10] = {-0.9931285991850949, -0.9639719272779138, -0.9122344282513259, -0.8391169718222188,
+                        -0.7463319064601508, -0.6360536807265150, -0.5108670019508271, -0.3737060887154196,
+                        -0.2277858511416451, -0.7652652113349733e-01};
+
 // P(X > sh, Y > sk), correlation r.
 __device__ inline double mvn_bvu(double sh, double sk, double r) {
-    const double W6[3] = {0.1713244923791705, 0.3607615730481384, 0.4679139345726904};
-    const double X6[3] = {-0.9324695142031522, -0.6612093864662647, -0.2386191860831970};
-    const double W12[6] = {0.4717533638651177e-01, 0.1069393259953183, 0.1600783285433464,
-                           0.2031674267230659, 0.2334925365383547, 0.2491470458134029};
-    const double X12[6] = {-0.9815606342467191, -0.9041172563704750, -0.7699026741943050,
-                           -0.5873179542866171, -0.3678314989981802, -0.1252334085114692};
-    const double W20[10] = {0.1761400713915212e-01, 0.4060142980038694e-01, 0.6267204833410906e-01,
-                            0.8327674157670475e-01, 0.1019301198172404, 0.1181945319615184, 0.1316886384491766,
-                            0.1420961093183821, 0.1491729864726037, 0.1527533871307259};
-    const double X20[10] = {-0.9931285991850949, -0.9639719272779138, -0.9122344282513259, -0.8391169718222188,
-                            -0.7463319064601508, -0.6360536807265150, -0.5108670019508271, -0.3737060887154196,
-                            -0.2277858511416451, -0.7652652113349733e-01};
     const double TWOPI = 6.283185307179586;
     int lg;
     const double *W, *X;
-    if (fabs(r) < 0.3) { lg = 3; W = W6; X = X6; }
-    else if (fabs(r) < 0.75) { lg = 6; W = W12; X = X12; }
-    else { lg = 10; W = W20; X = X20; }
+    if (fabs(r) < 0.3) { lg = 3; W = BVU_W6; X = BVU_X6; }
+    else if (fabs(r) < 0.75) { lg = 6; W = BVU_W12; X = BVU_X12; }
+    else { lg = 10; W = BVU_W20; X = BVU_X20; }
     double h = sh, k = sk, hk = h * k, bvn = 0;
     if (fabs(r) < 0.925) {
         double hs = (h * h + k * k) / 2;

@@ -21,6 +21,7 @@
 #include "device_math.h"
 #include "ital_hip.h"
 #include "ital_internal.h"
+#include "qmc_common.h"
 
 namespace ital {
 
@@ -131,8 +132,6 @@ __global__ __launch_bounds__(256) void score_t2_kernel(ScoreArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------------ t >= 3
-constexpr int P_TAB[10] = {31, 47, 73, 113, 173, 263, 397, 593, 907, 1361};
-
 template <int T>
 struct Qmc {
     static constexpr int NDIM = T - 1;
@@ -151,8 +150,6 @@ struct Qmc {
     static constexpr int TAILQ = 512;                         // compaction queue of the Phi^-1 tail branch (in + out)
     static constexpr int WAVE_DOUBLES = CHUNK * SLAB + A_SIZE + LAT + NDIM + T + TAILQ;  // + running vk + perm
 };
-
-__device__ __forceinline__ int pidx(int i, int j) { return i * (i + 1) / 2 + j; }  // packed lower, 0-based, j <= i
 
 // Swap rows/columns p < q of the packed lower-triangular matrix, the limits and the limit-type bits (RCSWP).
 template <int T>
@@ -212,45 +209,6 @@ __device__ bool covsrt(double* cov, double* lim, double* y, unsigned& infi) {
         }
     }
     return ok;
-}
-
-__device__ __forceinline__ double uniform_f64(double v) {
-    const int lo = __builtin_amdgcn_readfirstlane(__double2loint(v));
-    const int hi = __builtin_amdgcn_readfirstlane(__double2hiint(v));
-    return __hiloint2double(hi, lo);
-}
-
-// Four independent Phi^-1 arguments per lane.  Every lane runs the cheap central branch of AS241; the ~15 % of the
-// arguments that fall into the tails (|p - 1/2| > 0.425) are compacted across the wave through LDS so that the
-// expensive log/sqrt branch runs on full waves of tail arguments only (typically once per 256 inversions instead of
-// once per 64).
-__device__ __forceinline__ void phinv_wave4(const double (&p)[4], double (&out)[4], double* __restrict__ q, int lane) {
-    bool need[4];
-    int slot[4];
-    int total = 0;
-#pragma unroll
-    for (int c = 0; c < 4; c++) {
-        need[c] = !phinv_is_central(p[c]);
-        out[c] = phinv_central(need[c] ? 0.5 : p[c]);
-        const unsigned long long m = __ballot(need[c]);
-        slot[c] = total + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
-        total += __popcll(m);
-        if (need[c]) q[slot[c]] = p[c];
-    }
-    if (total == 0) return;
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    for (int s0 = 0; s0 < total; s0 += 64) {
-        const int sl = s0 + lane;
-        if (sl < total) q[256 + sl] = phinv_tail(q[sl]);
-    }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-#pragma unroll
-    for (int c = 0; c < 4; c++)
-        if (need[c]) out[c] = q[256 + slot[c]];
 }
 
 template <int T>

@@ -1,0 +1,680 @@
+// General mutual-information scorer: every combination of the reference's options that the perfect-user fast path
+// (score.hip) does not cover --
+//   * user models (reference ital/ital.py:300-342 `fb_iter`, :453-481 `likelihood`): perfect, "motivated"
+//     (label_prob >= 1, mistake_prob > 0: feedback in {-1,+1}^t) and general (feedback in {-1,0,+1}^t without the
+//     all-zero configuration; zero feedbacks are dropped from the simulated update, retrieval_base.py:192-193);
+//   * the change-estimation subset (ital.py:227-275 `_call_iter_sub`, :504-529, :541-582): the orthant
+//     probabilities run over U = subset + picks (+ candidate), of which only the picks and the candidate are
+//     enumerated; the others keep the sign of their predictive mean;
+//   * label_estimation mean / optimistic / pessimistic (ital.py:210-219, `_call_iter_all` only).
+//
+// Per candidate (one wave) the reference's call sequence is reproduced in its serial order:
+//   for pattern r (itertools.product order):  prior call(s);  for feedback f (product order, all-zero skipped): updated call
+// "prior" = prob_rel over U in natural order (plain mode), or prob_rel over the enumerated variables followed by
+// prob_rel over all of U (subset mode); "updated" = prob_rel over U sorted by data index under the closed-form
+// posterior after the simulated update with the non-zero feedbacks F:
+//     W = (Sigma_FF + s I)^-1, g = W (f - mu_F),
+//     mu'_F = f - s g,  mu'_a = mu_a + Sigma_aF g,
+//     Sigma'_FF = s (I - s W),  Sigma'_aF = s Sigma_aF W,  Sigma'_ab = Sigma_ab - Sigma_aF W Sigma_Fb   (s = noise)
+// (cancellation-free on the fed-back block; equal to gp.updated_prediction's (m+|F|)-dimensional inverse).
+// Calls of dimension 1 / 2 are closed forms (norm.cdf / Genz BVU) and draw nothing; dimension >= 3 is Genz's
+// MVNDST lattice rule with the MVNUNI stream replayed at the offset the serial reference reaches (jump-ahead by the
+// number of uniforms the preceding candidates and calls consume).  Lane l prepares call l of a chunk (closed-form
+// update, COVSRT) in its own LDS slab; the wave then evaluates the chunk's calls one after the other with the lattice
+// points spread over the lanes (4 chains per lane, runtime dimension <= NMAX with uniform early exits).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "device_math.h"
+#include "ital_hip.h"
+#include "ital_internal.h"
+#include "qmc_common.h"
+
+namespace ital {
+
+constexpr int GN = ITAL_GENERIC_MAX_DIM;  // largest orthant dimension
+constexpr int GR = ITAL_GENERIC_MAX_REL;  // largest number of enumerated variables
+
+struct GArgs {
+    ital_gscore_desc d;
+    int chunk;         // calls prepared per pass (<= 64)
+    int stride;        // doubles per preparing lane (odd)
+    int slab;          // of which the COVSRT slab (packed factor, limits, expected values); the rest is update scratch
+    int wave_doubles;  // LDS doubles per wave
+};
+
+// ------------------------------------------------------------------------------------------------ COVSRT, runtime n
+__device__ void rcswp_n(int n, int p, int q, double* cov, double* lim, unsigned& infi) {
+    double tmp = lim[p]; lim[p] = lim[q]; lim[q] = tmp;
+    unsigned bp = (infi >> p) & 1u, bq = (infi >> q) & 1u;
+    infi = (infi & ~((1u << p) | (1u << q))) | (bq << p) | (bp << q);
+    tmp = cov[pidx(p, p)]; cov[pidx(p, p)] = cov[pidx(q, q)]; cov[pidx(q, q)] = tmp;
+    for (int j = 0; j < p; j++) { tmp = cov[pidx(p, j)]; cov[pidx(p, j)] = cov[pidx(q, j)]; cov[pidx(q, j)] = tmp; }
+    for (int i = p + 1; i < q; i++) { tmp = cov[pidx(i, p)]; cov[pidx(i, p)] = cov[pidx(q, i)]; cov[pidx(q, i)] = tmp; }
+    for (int i = q + 1; i < n; i++) { tmp = cov[pidx(i, p)]; cov[pidx(i, p)] = cov[pidx(i, q)]; cov[pidx(i, q)] = tmp; }
+}
+
+__device__ bool covsrt_n(int n, double* cov, double* lim, double* y, unsigned& infi) {
+    const double SQTWPI = 2.506628274631001, EPS = 1e-10;
+    bool ok = true;
+    for (int i = 0; i < n; i++) {
+        double dmin = 0, emin = 1, zmin = 0, cvdiag = 0;
+        int jmin = i;
+        for (int j = i; j < n; j++) {
+            const double cjj = cov[pidx(j, j)];
+            if (cjj > EPS) {
+                const double sumsq = sqrt(cjj);
+                double sum = 0;
+                for (int k = 0; k < i; k++) sum += cov[pidx(j, k)] * y[k];
+                const double z = (lim[j] - sum) / sumsq;
+                const double ph = mvn_phi(z);
+                const bool lower = (infi >> j) & 1u;
+                const double d = lower ? ph : 0.0;
+                const double e = lower ? 1.0 : fmax(ph, 0.0);
+                if (emin + d >= e + dmin) { jmin = j; zmin = z; dmin = d; emin = e; cvdiag = sumsq; }
+            }
+        }
+        if (jmin > i) rcswp_n(n, i, jmin, cov, lim, infi);
+        cov[pidx(i, i)] = cvdiag;
+        if (cvdiag > 0) {
+            for (int l = i + 1; l < n; l++) {
+                cov[pidx(l, i)] = cov[pidx(l, i)] / cvdiag;
+                for (int j = i + 1; j <= l; j++) cov[pidx(l, j)] -= cov[pidx(l, i)] * cov[pidx(j, i)];
+            }
+            const bool lower = (infi >> i) & 1u;
+            if (emin > dmin + EPS) {
+                const double dens = -exp(-zmin * zmin / 2) / SQTWPI;
+                const double yl = lower ? dens : 0.0, yu = lower ? 0.0 : dens;
+                y[i] = (yu - yl) / (emin - dmin);
+            } else {
+                y[i] = zmin;
+            }
+            for (int j = 0; j <= i; j++) cov[pidx(i, j)] = cov[pidx(i, j)] / cvdiag;
+            lim[i] = lim[i] / cvdiag;
+        } else {
+            // zero diagonal (linearly dependent variable): Genz's COVSRT expresses the row through the last earlier
+            // variable it depends on and moves it right behind that variable; MVNDFN then intersects the limits
+            for (int l = i + 1; l < n; l++) cov[pidx(l, i)] = 0;
+            for (int j = i - 1; j >= 0; j--) {
+                const double cij = cov[pidx(i, j)];
+                if (fabs(cij) > EPS) {
+                    lim[i] = lim[i] / cij;
+                    if (cij < 0) infi ^= 1u << i;
+                    for (int l = 0; l <= j; l++) cov[pidx(i, l)] = cov[pidx(i, l)] / cij;
+                    for (int l = j + 1; l <= i - 1; l++) {
+                        if (cov[pidx(l, j + 1)] > 0) {
+                            for (int k = i - 1; k >= l; k--) {
+                                for (int m = 0; m <= k; m++) {
+                                    const double tmp = cov[pidx(k, m)];
+                                    cov[pidx(k, m)] = cov[pidx(k + 1, m)];
+                                    cov[pidx(k + 1, m)] = tmp;
+                                }
+                                const double tl = lim[k]; lim[k] = lim[k + 1]; lim[k + 1] = tl;
+                                const unsigned bk = (infi >> k) & 1u, bk1 = (infi >> (k + 1)) & 1u;
+                                infi = (infi & ~((1u << k) | (1u << (k + 1)))) | (bk1 << k) | (bk << (k + 1));
+                            }
+                            break;
+                        }
+                    }
+                    break;
+                }
+                cov[pidx(i, j)] = 0;
+            }
+            y[i] = 0;
+        }
+    }
+    return ok;
+}
+
+// After COVSRT: which rows close a group of MVNDFN (a row whose successor has a positive diagonal, or the last row),
+// and the factor re-packed so that column (closing row of group g) carries the coefficient of group g -- the
+// evaluator can then index its y registers by row.  Bit i of the result = row i closes a group.
+__device__ unsigned group_layout(int n, double* cov) {
+    unsigned closes = 0;
+    int ik = 0;                    // groups closed before the current row
+    unsigned long long crow = 0;   // closing row of each group, 4 bits each
+    for (int i = 0; i < n; i++) {
+        // columns >= ik of row i are ignored by MVNDFN; re-pack columns g < ik to column crow[g]
+        const int nk = ik < i ? ik : i;
+        for (int j = nk; j < i; j++) cov[pidx(i, j)] = 0;
+        for (int g = nk - 1; g >= 0; g--) {
+            const int r = (int)((crow >> (4 * g)) & 15ull);
+            if (r != g) {
+                cov[pidx(i, r)] = cov[pidx(i, g)];
+                cov[pidx(i, g)] = 0;
+            }
+        }
+        const bool close = (i == n - 1) || (cov[pidx(i + 1, ik + 1)] > 0);
+        if (close) {
+            closes |= 1u << i;
+            crow |= (unsigned long long)i << (4 * ik);
+            ik++;
+        }
+    }
+    return closes;
+}
+
+// ------------------------------------------------------------------------------------------------ call list
+enum { K_PRIOR = 0, K_PRIOR_SUB = 1, K_PRIOR_FULL = 2, K_UPDATED = 3 };
+
+struct CallInfo {
+    int kind;
+    unsigned pat;     // pattern bits, enumerated variable v at bit (nr-1-v)
+    unsigned fnz;     // enumerated variables with non-zero feedback (bit v)
+    unsigned fpos;    // ... whose feedback is +1 (bit v)
+    double weight;    // likelihood of the feedback given the pattern (ital.py:472-481), 1 for a perfect user
+};
+
+__device__ __forceinline__ int pow3(int n) {
+    int r = 1;
+    for (int i = 0; i < n; i++) r *= 3;
+    return r;
+}
+
+__device__ CallInfo decode_call(int call, int cpp, int npre, int nr, int fb_mode, bool subset, double lp, double mp) {
+    CallInfo c;
+    const int pi = call / cpp, s = call - pi * cpp;
+    c.pat = (unsigned)pi;
+    c.fnz = 0; c.fpos = 0; c.weight = 1.0;
+    if (s < npre) {
+        c.kind = subset ? (s == 0 ? K_PRIOR_SUB : K_PRIOR_FULL) : K_PRIOR;
+        return c;
+    }
+    c.kind = K_UPDATED;
+    int f = s - npre;
+    if (fb_mode == 0) {
+        c.fnz = (1u << nr) - 1u;
+        for (int v = 0; v < nr; v++) c.fpos |= ((c.pat >> (nr - 1 - v)) & 1u) << v;
+        return c;
+    }
+    if (fb_mode == 1) {
+        c.fnz = (1u << nr) - 1u;
+        for (int v = 0; v < nr; v++) c.fpos |= (((unsigned)f >> (nr - 1 - v)) & 1u) << v;
+    } else {
+        const int zero = (pow3(nr) - 1) / 2;
+        if (f >= zero) f++;
+        int rem = f;
+        for (int v = nr - 1; v >= 0; v--) {   // last variable = least significant base-3 digit
+            const int dgt = rem % 3;
+            rem /= 3;
+            if (dgt != 1) c.fnz |= 1u << v;
+            if (dgt == 2) c.fpos |= 1u << v;
+        }
+    }
+    double w = 1.0;
+    for (int v = 0; v < nr; v++) {
+        const bool r = (c.pat >> (nr - 1 - v)) & 1u;
+        if (!((c.fnz >> v) & 1u)) w *= 1.0 - lp;
+        else if ((((c.fpos >> v) & 1u) != 0) == r) w *= lp * (1.0 - mp);
+        else w *= lp * mp;
+    }
+    c.weight = w;
+    return c;
+}
+
+// position of the q-th set bit helpers are avoided: loops run over the set bits directly
+#define FOR_BITS(mask, u, q) for (unsigned _m = (mask), q = 0, u = 0; _m && ((u = __builtin_ctz(_m)), true); _m &= _m - 1, q++)
+
+struct Prep {
+    int n;
+    unsigned infi;
+    unsigned closes; // rows that close a group of MVNDFN (all rows unless the covariance is singular)
+    int flags;       // 1 closed form (value valid), 2 integrand == 1, 4 integrand == 0
+    double value;
+};
+
+// Prepares one call in the lane's slab: cov (packed, n(n+1)/2), lim (n), y (n); scratch fs for the update.
+__device__ Prep prepare_call(const ital_gscore_desc& d, const CallInfo& ci, int nU, int nr, const double* muU,
+                             const double* SigU, const int* usort, const int* ipos, bool clamp_prior, double* slab,
+                             double* fs) {
+    Prep out;
+    out.flags = 0; out.value = 0; out.infi = 0; out.closes = 0;
+    const bool subset = d.subset_mode != 0;
+    const int n = ci.kind == K_PRIOR_SUB ? nr : nU;
+    out.n = n;
+    double* cov = slab;
+    double* lim = slab + n * (n + 1) / 2;
+    double* y = lim + n;
+    // sign of every variable of U: enumerated ones from the pattern, the rest from the predictive mean (ital.py:238)
+    unsigned relU = 0;
+    if (subset)
+        for (int u = 0; u < nU; u++) relU |= (muU[u] > 0 ? 1u : 0u) << u;
+    for (int v = 0; v < nr; v++) {
+        const unsigned bit = (ci.pat >> (nr - 1 - v)) & 1u;
+        relU = (relU & ~(1u << ipos[v])) | (bit << ipos[v]);
+    }
+    // feedback set F as positions of U
+    unsigned Fm = 0, Fp = 0;
+    if (ci.kind == K_UPDATED)
+        for (int v = 0; v < nr; v++)
+            if ((ci.fnz >> v) & 1u) {
+                Fm |= 1u << ipos[v];
+                if ((ci.fpos >> v) & 1u) Fp |= 1u << ipos[v];
+            }
+    const int nf = __builtin_popcount(Fm);
+    double* M = fs;               // nf x nf
+    double* dg = fs + nf * nf;    // diagonal of W
+    double* gv = dg + nf;         // W (f - mu_F)
+    const double s = d.noise;
+    if (nf > 0) {
+        FOR_BITS(Fm, ua, qa) {
+            FOR_BITS(Fm, ub, qb) {
+                if (qb > qa) break;
+                M[qa * nf + qb] = SigU[ua * GN + ub] + (qa == qb ? s : 0.0);
+            }
+        }
+        for (int i = 0; i < nf; i++)
+            for (int j = 0; j <= i; j++) {
+                double v = M[i * nf + j];
+                for (int q = 0; q < j; q++) v -= M[i * nf + q] * M[j * nf + q];
+                M[i * nf + j] = (i == j) ? sqrt(v) : v / M[j * nf + j];
+            }
+        // in-place inverse of the lower factor (column by column, the columns to the right still hold L)
+        for (int j = 0; j < nf; j++) {
+            M[j * nf + j] = 1.0 / M[j * nf + j];
+            for (int i = j + 1; i < nf; i++) {
+                double sm = 0;
+                for (int q = j; q < i; q++) sm += M[i * nf + q] * M[q * nf + j];
+                M[i * nf + j] = -sm / M[i * nf + i];
+            }
+        }
+        // W = X^T X: off-diagonal into the upper triangle, diagonal aside
+        for (int j = 0; j < nf; j++) {
+            for (int i = 0; i < j; i++) {
+                double w = 0;
+                for (int k = j; k < nf; k++) w += M[k * nf + i] * M[k * nf + j];
+                M[i * nf + j] = w;
+            }
+        }
+        for (int i = 0; i < nf; i++) {
+            double w = 0;
+            for (int k = i; k < nf; k++) w += M[k * nf + i] * M[k * nf + i];
+            dg[i] = w;
+        }
+        FOR_BITS(Fm, ua, qa) {
+            double acc = 0;
+            FOR_BITS(Fm, ub, qb) {
+                const double w = qa == qb ? dg[qa] : (qa < qb ? M[qa * nf + qb] : M[qb * nf + qa]);
+                const double fb = ((Fp >> ub) & 1u) ? 1.0 : -1.0;
+                acc += w * (fb - muU[ub]);
+            }
+            gv[qa] = acc;
+        }
+    }
+    auto Wat = [&](unsigned qa, unsigned qb) -> double {
+        return qa == qb ? dg[qa] : (qa < qb ? M[qa * nf + qb] : M[qb * nf + qa]);
+    };
+    auto upos_of = [&](int a) -> int {
+        return ci.kind == K_PRIOR_SUB ? ipos[a] : (ci.kind == K_UPDATED ? usort[a] : a);
+    };
+    // posterior mean (into lim) and covariance (packed) of the call's variables, then standardise
+    for (int a = 0; a < n; a++) {
+        const int ua = upos_of(a);
+        const bool aF = (Fm >> ua) & 1u;
+        const unsigned qa = __builtin_popcount(Fm & ((1u << ua) - 1u));
+        double mean;
+        if (aF) {
+            mean = (((Fp >> ua) & 1u) ? 1.0 : -1.0) - s * gv[qa];
+        } else {
+            mean = muU[ua];
+            FOR_BITS(Fm, uf, q) mean += SigU[ua * GN + uf] * gv[q];
+        }
+        lim[a] = mean;
+        out.infi |= ((relU >> ua) & 1u) << a;
+        for (int b = 0; b <= a; b++) {
+            const int ub = upos_of(b);
+            const bool bF = (Fm >> ub) & 1u;
+            const unsigned qb = __builtin_popcount(Fm & ((1u << ub) - 1u));
+            double v;
+            if (nf == 0) {
+                v = SigU[ua * GN + ub];
+            } else if (aF && bF) {
+                v = s * ((qa == qb ? 1.0 : 0.0) - s * Wat(qa, qb));
+            } else if (bF) {
+                double acc = 0;
+                FOR_BITS(Fm, uf, q) acc += SigU[ua * GN + uf] * Wat(q, qb);
+                v = s * acc;
+            } else if (aF) {
+                double acc = 0;
+                FOR_BITS(Fm, uf, q) acc += SigU[ub * GN + uf] * Wat(q, qa);
+                v = s * acc;
+            } else {
+                double acc = 0;
+                FOR_BITS(Fm, uf, q) {
+                    double inner = 0;
+                    FOR_BITS(Fm, ug, q2) inner += Wat(q, q2) * SigU[ug * GN + ub];
+                    acc += SigU[ua * GN + uf] * inner;
+                }
+                v = SigU[ua * GN + ub] - acc;
+            }
+            cov[pidx(a, b)] = v;
+        }
+    }
+    if (clamp_prior && ci.kind != K_UPDATED && n == 1) cov[0] = fmax(0.0, cov[0]);  // predict_stored 'diag' (gp.py:229)
+    for (int a = 0; a < n; a++) y[a] = sqrt(cov[pidx(a, a)]);  // standard deviations, for now
+    if (n == 1) {
+        const double p_irr = norm_cdf0(lim[0], y[0]);      // prob_rel, ital.py:364-369
+        out.value = (out.infi & 1u) ? 1.0 - p_irr : p_irr;
+        out.flags = 1;
+        return out;
+    }
+    for (int a = 0; a < n; a++) {
+        lim[a] = -lim[a] / y[a];
+        for (int b = 0; b < a; b++) cov[pidx(a, b)] = cov[pidx(a, b)] / (y[a] * y[b]);
+    }
+    for (int a = 0; a < n; a++) cov[pidx(a, a)] = 1.0;
+    if (n == 2) {
+        out.value = bvn_orthant(lim[0], lim[1], out.infi & 1u, (out.infi >> 1) & 1u, cov[pidx(1, 0)]);
+        out.flags = 1;
+        return out;
+    }
+    covsrt_n(n, cov, lim, y, out.infi);
+    out.closes = group_layout(n, cov);
+    bool sat1 = true, sat0 = false;
+    for (int i = 0; i < n; i++) {
+        double bound = 0;
+        for (int j = 0; j < i; j++) bound += fabs(cov[pidx(i, j)]) * 9.0;
+        const bool lower = (out.infi >> i) & 1u;
+        if (lower) {
+            if (!(lim[i] + bound < -37.0)) sat1 = false;
+            if (lim[i] - bound > 37.0) sat0 = true;
+        } else {
+            if (!(lim[i] - bound > 37.0)) sat1 = false;
+            if (lim[i] + bound < -37.0) sat0 = true;
+        }
+    }
+    if (sat0) out.flags = 4;
+    else if (sat1) out.flags = 2;
+    return out;
+}
+
+__device__ __forceinline__ double readlane_f64(double v, int lane) {
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), lane);
+    const int hi = __builtin_amdgcn_readlane(__double2hiint(v), lane);
+    return __hiloint2double(hi, lo);
+}
+
+// One MVNDST pass (8 shifted lattices, antithetic pairs) for a prepared call of dimension n <= NMAX; every lane runs
+// NH lattice items per round, each with its antithetic partner (2*NH independent chains).
+template <int NMAX, int NH>
+__device__ double qmc_eval(int n, const double* __restrict__ slab, unsigned infi, unsigned closes,
+                           const double* __restrict__ lat, int lane, double* __restrict__ tailq) {
+    constexpr int NC = 2 * NH;
+    const int ndim = n - 1;
+    const int prime = P_TAB[(ndim < 10 ? ndim : 10) - 1];
+    const double* cf = slab;
+    const double* lm = slab + n * (n + 1) / 2;
+    const int items = 8 * prime;
+    double acc = 0.0;
+    for (int base = 0; base < items; base += 64 * NH) {
+        double yy[NC][NMAX - 1], ff[NC], ai[NC], bi[NC];
+        bool dead[NC];
+        int kk[NH], so[NH];
+#pragma unroll
+        for (int h = 0; h < NH; h++) {
+            const int item = base + 64 * h + lane;
+            const bool ok = item < items;
+            const int it = ok ? item : 0;
+            const int sft = it / prime;
+            kk[h] = it - sft * prime + 1;
+            so[h] = sft * ndim;
+            ff[2 * h] = ff[2 * h + 1] = 1.0;
+            dead[2 * h] = dead[2 * h + 1] = !ok;
+        }
+#pragma unroll
+        for (int c = 0; c < NC; c++) { ai[c] = 0; bi[c] = 0; }
+        bool infa = false, infb = false;   // wave-uniform: the open group has a lower / an upper limit (MVNDFN)
+        int ik = 0;                        // groups closed so far = lattice coordinate of the open group
+#pragma unroll
+        for (int i = 0; i < NMAX; i++) {
+            if (i < n) {   // uniform; no `break`: the body holds convergent wave operations and must stay unrollable
+                const bool lower = (infi >> i) & 1u;
+                const bool close = (closes >> i) & 1u;
+                const bool last = i == n - 1;
+                const double lmi = lm[i];
+#pragma unroll
+                for (int c = 0; c < NC; c++) {
+                    double sc = 0;
+#pragma unroll
+                    for (int j = 0; j < i; j++) sc = fma(cf[pidx(i, j)], yy[c][j], sc);
+                    const double z = lmi - sc;
+                    if (lower) ai[c] = infa ? fmax(ai[c], z) : z;
+                    else bi[c] = infb ? fmin(bi[c], z) : z;
+                }
+                if (lower) infa = true; else infb = true;
+                if (close) {
+                    double xh[NH];
+#pragma unroll
+                    for (int h = 0; h < NH; h++) {
+                        xh[h] = 0;
+                        if (!last) {
+                            const double v = kk[h] * lat[so[h] + ik] + lat[8 * ndim + so[h] + ik];
+                            const double fr = v - floor(v);
+                            xh[h] = fabs(2 * fr - 1);
+                        }
+                    }
+                    double pin[NC];
+#pragma unroll
+                    for (int c = 0; c < NC; c++) {
+                        const double dd = infa ? mvn_phi(ai[c]) : 0.0;
+                        const double ee = infb ? mvn_phi(bi[c]) : 1.0;
+                        const double w = ee - dd;
+                        dead[c] = dead[c] || !(w > 0);
+                        ff[c] *= w;
+                        const double x = (c & 1) ? 1 - xh[c >> 1] : xh[c >> 1];
+                        pin[c] = dead[c] ? 0.5 : fma(x, w, dd);
+                    }
+                    if (!last) {
+                        double outv[NC];
+                        phinv_wave<NC>(pin, outv, tailq, lane);
+#pragma unroll
+                        for (int c = 0; c < NC; c++)
+                            if (i < NMAX - 1) yy[c][i < NMAX - 1 ? i : 0] = outv[c];
+                    }
+                    infa = false; infb = false;
+                    ik++;
+                } else {
+#pragma unroll
+                    for (int c = 0; c < NC; c++)
+                        if (i < NMAX - 1) yy[c][i < NMAX - 1 ? i : 0] = 0.0;
+                }
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < NC; c++) acc += dead[c] ? 0.0 : ff[c];
+    }
+    return wave_sum(acc) / (16.0 * prime);
+}
+
+__device__ __forceinline__ void wave_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+template <int NMAX, int NH>
+__global__ __launch_bounds__(128) void score_generic_kernel(GArgs a) {
+    extern __shared__ double lds_all[];
+    const ital_gscore_desc& d = a.d;
+    const int lane = threadIdx.x & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int64_t p = (int64_t)blockIdx.x * 2 + wid;
+    if (p >= d.n_cand) return;
+    if (!d.alive[p]) return;
+    double* W = lds_all + (size_t)wid * a.wave_doubles;
+    double* muU = W;
+    double* SigU = muU + GN;
+    int* usort = reinterpret_cast<int*>(SigU + GN * GN);
+    int* ipos = usort + GN;
+    double* lat = SigU + GN * GN + (GN + GR + 1) / 2;
+    double* vkrun = lat + 16 * (GN - 1);
+    double* tailq = vkrun + GN;
+    double* slabs = tailq + 512;
+
+    const int row = d.cand[p];
+    const int64_t gi = d.row_offset + row;
+    const int nE = d.nE;
+    const bool subset = d.subset_mode != 0;
+    int epos = -1;
+    for (int e = 0; e < nE; e++)
+        if (d.E_idx[e] == gi) epos = e;
+    if (!subset) epos = -1;
+    const int nU = epos >= 0 ? nE : nE + 1;
+    const int cpos = epos >= 0 ? epos : nE;
+    const int nr = d.n_picks + 1;
+
+    // ---------------- Phase A: joint mean / covariance of U = E (+ candidate) in the wave's LDS area
+    for (int idx = lane; idx < nU * nU; idx += 64) {
+        const int r = idx / nU, c = idx - r * nU;
+        double v;
+        if (r < nE && c < nE) v = d.E_sig[r * d.ldE + c];
+        else if (r == c) v = d.s2[row];                         // not clamped (gp.py:254)
+        else v = d.C[(int64_t)(r < c ? r : c) * d.ldc + row];
+        SigU[r * GN + c] = v;
+    }
+    for (int e = lane; e < nU; e += 64) muU[e] = e < nE ? d.E_mu[e] : d.mu[row];
+    if (lane == 0) {
+        if (epos >= 0) {
+            for (int sidx = 0; sidx < nE; sidx++) usort[sidx] = d.E_sort[sidx];
+        } else {
+            int rank = 0;
+            for (int e = 0; e < nE; e++) rank += (d.E_idx[e] < gi) ? 1 : 0;
+            for (int sidx = 0; sidx < nU; sidx++)
+                usort[sidx] = sidx < rank ? d.E_sort[sidx] : (sidx == rank ? nE : d.E_sort[sidx - 1]);
+        }
+        for (int v = 0; v < nr; v++) ipos[v] = v < d.n_picks ? d.pick_pos[v] : cpos;
+    }
+    // ---------------- stream position of this candidate in the reference's serial order
+    MrgState rng = {d.seed[0], d.seed[1], d.seed[2], d.seed[3], d.seed[4], d.seed[5]};
+    {
+        const int64_t gpos = d.pos_offset + p;
+        int64_t before = gpos, n_in = 0;
+        for (int i = 0; i < d.n_dead; i++) before -= (d.dead_pos[i] < gpos) ? 1 : 0;
+        for (int i = 0; i < d.n_in; i++) n_in += (d.in_pos[i] < gpos) ? 1 : 0;
+        uint64_t off = (uint64_t)(before - n_in) * (uint64_t)d.draws_out + (uint64_t)n_in * (uint64_t)d.draws_in;
+        for (int bit = 0; off != 0; bit++, off >>= 1)
+            if (off & 1) mrg_apply(rng, d.jump1 + bit * 18);
+    }
+    wave_sync();
+
+    const int npat = 1 << nr;
+    const int npre = subset ? 2 : 1;
+    const int nfb = d.fb_mode == 0 ? 1 : (d.fb_mode == 1 ? (1 << nr) : pow3(nr) - 1);
+    const int cpp = npre + nfb;
+    const int total = npat * cpp;
+    const bool clamp_prior = !subset && nr == 1;   // first greedy step: predict_stored(cov_mode='diag') (ital.py:558)
+
+    double mi = 0.0, pr_cur = 0.0, logpr_cur = 0.0;
+    for (int chunk0 = 0; chunk0 < total; chunk0 += a.chunk) {
+        // ---------------- Phase B: lane l prepares call chunk0 + l
+        Prep pp;
+        pp.n = 0; pp.infi = 0; pp.flags = 0; pp.value = 0; pp.closes = 0;
+        if (lane < a.chunk && chunk0 + lane < total) {
+            const CallInfo ci = decode_call(chunk0 + lane, cpp, npre, nr, d.fb_mode, subset, d.label_prob, d.mistake_prob);
+            double* slab = slabs + (size_t)lane * a.stride;
+            pp = prepare_call(d, ci, nU, nr, muU, SigU, usort, ipos, clamp_prior, slab, slab + a.slab);
+        }
+        wave_sync();
+        // ---------------- Phase C
+        for (int cl = 0; cl < a.chunk && chunk0 + cl < total; cl++) {
+            const int n_c = __builtin_amdgcn_readlane(pp.n, cl);
+            const int fl_c = __builtin_amdgcn_readlane(pp.flags, cl);
+            const unsigned infi_c = (unsigned)__builtin_amdgcn_readlane((int)pp.infi, cl);
+            const unsigned closes_c = (unsigned)__builtin_amdgcn_readlane((int)pp.closes, cl);
+            double value;
+            if (fl_c & 1) {
+                value = readlane_f64(pp.value, cl);
+            } else if (fl_c & 6) {
+                value = (fl_c & 2) ? 1.0 : 0.0;
+                mrg_apply(rng, d.skip + n_c * 18);
+            } else {
+                const int ndim = n_c - 1;
+                for (int j = 0; j < ndim; j++) vkrun[j] = d.vk[n_c * GN + j];
+                for (int sft = 0; sft < 8; sft++) {
+                    for (int j = 1; j <= ndim - 1; j++) {
+                        const double u = mrg_next(rng);
+                        const int jp = (int)(j + u * (ndim + 1 - j));
+                        const double xt = vkrun[j - 1];
+                        vkrun[j - 1] = vkrun[jp - 1];
+                        vkrun[jp - 1] = xt;
+                    }
+                    for (int j = 0; j < ndim; j++) lat[sft * ndim + j] = vkrun[j];
+                    for (int j = 0; j < ndim; j++) lat[8 * ndim + sft * ndim + j] = mrg_next(rng);
+                }
+                wave_sync();
+                value = qmc_eval<NMAX, NH>(n_c, slabs + (size_t)cl * a.stride, infi_c, closes_c, lat, lane, tailq);
+                wave_sync();
+            }
+            const CallInfo ci = decode_call(chunk0 + cl, cpp, npre, nr, d.fb_mode, subset, d.label_prob, d.mistake_prob);
+            if (ci.kind == K_PRIOR) {
+                pr_cur = value;
+                logpr_cur = log(value + d.eps);
+            } else if (ci.kind == K_PRIOR_SUB) {
+                pr_cur = value;
+            } else if (ci.kind == K_PRIOR_FULL) {
+                logpr_cur = log(value + d.eps);
+            } else {
+                double cur = (log(value + d.eps) - logpr_cur) * ci.weight;
+                if (!subset && d.label_mode == 1) {
+                    if (cur > mi) mi = cur;
+                } else if (!subset && d.label_mode == 2) {
+                    if (mi == 0 || cur < mi) mi = cur;
+                } else {
+                    mi += cur * pr_cur;
+                }
+            }
+        }
+        wave_sync();
+    }
+    if (lane == 0) d.mi[p] = mi;
+}
+
+}  // namespace ital
+
+using namespace ital;
+
+static int fs_doubles(int nr) { return nr * nr + 2 * nr; }
+
+extern "C" int ital_score_generic(const ital_gscore_desc* d, hipStream_t stream) {
+    if (!d) return ital_fail(-22, "ital_score_generic: null descriptor");
+    if (d->n_cand <= 0) return 0;
+    const int nr = d->n_picks + 1;
+    const int nUmax = d->nE + 1;
+    if (d->nE < 0 || nUmax > ITAL_GENERIC_MAX_DIM)
+        return ital_fail(-22, "ital_score_generic: orthant dimension exceeds ITAL_GENERIC_MAX_DIM");
+    if (nr < 1 || nr > ITAL_GENERIC_MAX_REL)
+        return ital_fail(-22, "ital_score_generic: more enumerated variables than ITAL_GENERIC_MAX_REL");
+    if (!d->subset_mode && d->nE != d->n_picks)
+        return ital_fail(-22, "ital_score_generic: without a change-estimation subset the base set is the batch");
+    if (d->fb_mode < 0 || d->fb_mode > 2) return ital_fail(-22, "ital_score_generic: fb_mode must be 0, 1 or 2");
+    if (!d->jump1 || !d->skip || !d->vk) return ital_fail(-22, "ital_score_generic: stream tables missing");
+    GArgs a;
+    a.d = *d;
+    const int slab = nUmax * (nUmax + 1) / 2 + 2 * nUmax;
+    int stride = slab + fs_doubles(nr);
+    stride |= 1;
+    int chunk = 64;
+    while (chunk > 4 && chunk * stride > 3072) chunk >>= 1;
+    a.chunk = chunk;
+    a.stride = stride;
+    a.slab = slab;
+    const int fixed = GN + GN * GN + (GN + GR + 1) / 2 + 16 * (GN - 1) + GN + 512;
+    a.wave_doubles = fixed + chunk * stride;
+    const size_t lds = (size_t)2 * a.wave_doubles * sizeof(double);
+    if (lds > 160 * 1024) return ital_fail(-12, "ital_score_generic: LDS budget exceeded");
+    const int64_t blocks = (d->n_cand + 1) / 2;
+    static bool attr_done = false;
+    if (!attr_done) {
+        hipError_t e1 = hipFuncSetAttribute(reinterpret_cast<const void*>(&score_generic_kernel<6, 2>),
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        hipError_t e2 = hipFuncSetAttribute(reinterpret_cast<const void*>(&score_generic_kernel<ITAL_GENERIC_MAX_DIM, 1>),
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e1 != hipSuccess || e2 != hipSuccess) return ital_fail(-12, "ital_score_generic: cannot raise the dynamic LDS limit");
+        attr_done = true;
+    }
+    if (nUmax <= 6)
+        hipLaunchKernelGGL((score_generic_kernel<6, 2>), dim3((unsigned)blocks), dim3(128), lds, stream, a);
+    else
+        hipLaunchKernelGGL((score_generic_kernel<ITAL_GENERIC_MAX_DIM, 1>), dim3((unsigned)blocks), dim3(128), lds, stream, a);
+    return ital_check_launch("ital_score_generic");
+}

@@ -152,6 +152,19 @@ class GaussianProcess(object):
             sharding.all_reduce_sum(rows, self.group)
         return rows
 
+    def gather_columns(self, mat, ind):
+        """mat[:, local column of each global index] replicated on every rank ([rows, len(ind)]); `mat` holds one column
+        per local data row (V, or covariance columns)."""
+        idx = torch.as_tensor([int(i) for i in ind], dtype=torch.int64, device=self.device)
+        out = torch.zeros((mat.shape[0], len(idx)), dtype=torch.float64, device=self.device)
+        own = (idx >= self.row0) & (idx < self.row1)
+        if bool(own.any()):
+            sel = torch.nonzero(own).squeeze(1)
+            out[:, sel] = mat.index_select(1, idx[own] - self.row0)
+        if self.world > 1:
+            sharding.all_reduce_sum(out, self.group)
+        return out
+
     def _append(self, rows, y):
         lib, st = self._lib, _stream()
         c_total = rows.shape[0]

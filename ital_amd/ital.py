@@ -17,7 +17,8 @@ import numpy as np
 import torch
 
 from . import _lib, mvn_stream, sharding
-from ._lib import ITAL_JUMP_BITS, ITAL_MAX_T, ITAL_REC_HEADER, ItalBatch, ItalScoreDesc, check
+from ._lib import (ITAL_GENERIC_MAX_DIM, ITAL_GENERIC_MAX_REL, ITAL_JUMP_BITS, ITAL_MAX_T, ITAL_REC_HEADER, ItalBatch,
+                   ItalGscoreDesc, ItalScoreDesc, check)
 from ._batch import make_batch_buffers
 from .gp import _pad16, _ptr, _stream
 from .retrieval_base import ActiveRetrievalBase
@@ -52,21 +53,37 @@ class ITAL(ActiveRetrievalBase):
         self.eps = 1e-12  # reference ital/ital.py:144
         self.last_scores = None  # per greedy step: device tensor of MI per list position (diagnostics/tests)
         self.keep_scores = False
+        self.force_generic = False  # route the perfect-user case through the general scorer too (cross-check in tests)
+        self._ce_subset = None
         self.profile = None      # list to receive (stage, t, size, start_event, end_event) per launch (bench.py)
         self._fetch_bufs = None
 
     # ------------------------------------------------------------------ helpers
-    def _unsupported(self):
-        if not (self.label_prob >= 1 and self.mistake_prob <= 0):
-            return "non-perfect user models (label_prob < 1 or mistake_prob > 0)"
-        if self.change_estimation_subset is None or self.change_estimation_subset > 0:
-            return "change_estimation_subset"
-        if self.clip_cov:
-            return "clip_cov"
+    def _perfect_user(self):
+        return self.label_prob >= 1 and self.mistake_prob <= 0
+
+    def _subset_mode(self):
+        return self.change_estimation_subset is None or self.change_estimation_subset > 0
+
+    def _unsupported(self, k):
+        """Reason why the device scorers cannot run this configuration (None if they can)."""
         if self.monte_carlo_num_rel is not None or self.monte_carlo_num_fb is not None:
-            return "monte-carlo enumeration"
+            return "monte-carlo enumeration (monte_carlo_num_rel / monte_carlo_num_fb)"
         if self.label_estimation not in _LABEL_MODES:
             return "label_estimation=%r" % (self.label_estimation,)
+        if self.change_estimation_subset is None:
+            return "change_estimation_subset=None (the whole candidate set as estimation subset)"
+        sub = self.change_estimation_subset if self.change_estimation_subset > 0 else 0
+        max_dim = sub + k
+        if self.clip_cov and 0 < self.clip_cov < 1 and max_dim > 5:
+            return "clip_cov with orthant dimensions above 5 (grouped probabilities, reference ital.py:386-429)"
+        if sub > 0 or not self._perfect_user():
+            if max_dim > ITAL_GENERIC_MAX_DIM:
+                return "orthant dimension %d (subset + batch) above %d" % (max_dim, ITAL_GENERIC_MAX_DIM)
+            if k > ITAL_GENERIC_MAX_REL:
+                return "batches larger than %d with a noisy user model or an estimation subset" % ITAL_GENERIC_MAX_REL
+        elif k > ITAL_MAX_T:
+            return "batches larger than %d (needs the monte-carlo enumeration, reference ital.py:293-297)" % ITAL_MAX_T
         return None
 
     def _mark(self, stage=None, t=0, size=0, start=None):
@@ -91,6 +108,12 @@ class ITAL(ActiveRetrievalBase):
     def _candidate_list(self):
         """Candidate list in the reference's order (ital.py:98, :111-117)."""
         candidates = self.get_unseen()
+        # change-estimation subset: drawn from the unrestricted candidate list on the global numpy RNG (ital.py:103-108)
+        if self.change_estimation_subset is not None and self.change_estimation_subset > 0:
+            self._ce_subset = sorted(int(i) for i in np.random.choice(
+                candidates, min(len(candidates), self.change_estimation_subset), replace=False))
+        else:
+            self._ce_subset = None
         if self.top_candidates is not None:
             top_candidates = self.top_candidates
             if isinstance(self.top_candidates, float):
@@ -107,20 +130,19 @@ class ITAL(ActiveRetrievalBase):
         """Selects k unlabelled samples by greedy maximisation of mutual information (reference ital.py:84-134).
 
         Returns the list of selected sample indices (python ints, selection order)."""
-        why = self._unsupported()
-        if why is not None:
-            raise NotImplementedError("ital_amd device scorer: %s is not implemented yet" % why)
         gp = self.gp
         if gp.m == 0:
             raise RuntimeError("fetch_unlabelled() needs a fitted relevance model: call update() first or pass queries "
                                "(the reference fails with an AttributeError at gp.py:222)")
-        candidates = self._candidate_list()
-        k = min(int(k), len(candidates))
+        k = min(int(k), len(self.get_unseen()))
         if k <= 0:
             return []
-        if k > ITAL_MAX_T:
-            raise NotImplementedError("batches larger than %d need the monte-carlo enumeration (reference ital.py:293-297)"
-                                      % ITAL_MAX_T)
+        why = self._unsupported(k)
+        if why is not None:
+            raise NotImplementedError("ital_amd device scorer: %s is not implemented" % why)
+        candidates = self._candidate_list()
+        if self._subset_mode() or not self._perfect_user() or self.force_generic:
+            return self._fetch_generic(k, candidates)
         lib = _lib.lib()
         dev = gp.device
         with torch.cuda.device(dev):
@@ -136,6 +158,7 @@ class ITAL(ActiveRetrievalBase):
             mi = torch.zeros(max(n_loc, 1), dtype=torch.float64, device=dev)
             self.last_scores = []
             stream = mvn_stream.GLOBAL
+            saved_stream = (stream.state, stream.draws)
             n_alive = len(candidates)
             for t in range(1, k + 1):
                 desc = ItalScoreDesc()
@@ -180,5 +203,146 @@ class ITAL(ActiveRetrievalBase):
                 stream.advance(n_alive * (2 << t) * mvn_stream.draws_per_call(t))
                 n_alive -= 1
             ret = b["ret"][:k].cpu().tolist()  # the only synchronisation of the round
+            if int(gp.status.item()) & 2:
+                # linearly dependent variables inside a batch (duplicate samples): the fast scorer does not carry
+                # MVNDFN's limit-intersection logic; redo the round with the general scorer from the same stream position
+                gp.status.zero_()
+                stream.state, stream.draws = saved_stream
+                return self._fetch_generic(k, candidates)
         gp.check_status()
         return [int(i) for i in ret]
+
+    # ------------------------------------------------------------------ general scorer (noisy users, estimation subset)
+    def _fetch_generic(self, k, candidates):
+        """Greedy batch construction through ital_score_generic: any user model (reference ital.py:300-342), with or
+        without a change-estimation subset (ital.py:227-275, 541-582).  One host synchronisation per greedy step (the
+        winner's record is read back to extend the base set); the perfect-user path above has none."""
+        lib = _lib.lib()
+        gp = self.gp
+        dev = gp.device
+        subset_mode = self._ce_subset is not None
+        fb_mode = 0 if self._perfect_user() else (1 if self.label_prob >= 1 else 2)
+        E = list(self._ce_subset) if subset_mode else []
+        kmax_e = len(E) + k
+        GN = ITAL_GENERIC_MAX_DIM
+        stream = mvn_stream.GLOBAL
+        with torch.cuda.device(dev):
+            st = _stream()
+            b = make_batch_buffers(dev, max(kmax_e, 4), gp.ldx, gp.cap, gp.ldv, gp.world)
+            cand = np.asarray(candidates, dtype=np.int64)
+            pos_of = {int(c): i for i, c in enumerate(candidates)}
+            loc_rows, pos_offset = sharding.shard_candidates(cand, gp.row0, gp.row1)
+            n_loc = len(loc_rows)
+            cand_d = torch.from_numpy((loc_rows - gp.row0).astype(np.int32)).to(dev) if n_loc else \
+                torch.zeros(1, dtype=torch.int32, device=dev)
+            alive = torch.ones(max(n_loc, 1), dtype=torch.uint8, device=dev)
+            mi = torch.zeros(max(n_loc, 1), dtype=torch.float64, device=dev)
+            jump1 = torch.from_numpy(mvn_stream.jump1_table(ITAL_JUMP_BITS)).to(dev)
+            skip = torch.from_numpy(mvn_stream.skip_table(GN)).to(dev)
+            vk = torch.from_numpy(mvn_stream.vk_table(GN)).to(dev)
+            C = b["C"]
+            e_mu = np.zeros(kmax_e)
+            e_sig = np.zeros((kmax_e, kmax_e))
+            if E:
+                # covariance columns of the subset members with every row, and among themselves
+                rows = gp._gather_rows(E)
+                norms = torch.empty(len(E), dtype=torch.float64, device=dev)
+                check(lib.ital_row_norms(_ptr(rows), len(E), gp.ldx, _ptr(norms), st))
+                vcols = gp.gather_columns(gp.V[: max(gp.m, 1)], E)          # [m, |E|]
+                for c0 in range(0, len(E), 16):
+                    c = min(16, len(E) - c0)
+                    Wt = torch.zeros((c, gp.cap), dtype=torch.float64, device=dev)
+                    Wt[:, : gp.m] = vcols[: gp.m, c0:c0 + c].t()
+                    check(lib.ital_cross_cov_cols(_ptr(gp.Xd), _ptr(gp.xnorm), gp.n, gp.ldx, _ptr(rows[c0:c0 + c]),
+                                                  _ptr(norms[c0:c0 + c]), c, _ptr(Wt), gp.cap, _ptr(gp.V), gp.ldv, gp.m,
+                                                  float(self.var), float(self.length_scale), _ptr(C[c0:c0 + c]), gp.ldv,
+                                                  st))
+                    torch.cuda.current_stream().synchronize()   # Wt is a temporary
+                e_sig[: len(E), : len(E)] = gp.gather_columns(C[: len(E)], E).cpu().numpy()
+                e_mu[: len(E)] = self.rel_mean[np.asarray(E)]
+            picks, pick_pos = [], []
+            self.last_scores = []
+            n_alive = len(candidates)
+            for t in range(1, k + 1):
+                nE = len(E)
+                nr = t
+                npat = 1 << nr
+                nfb = 1 if fb_mode == 0 else ((1 << nr) if fb_mode == 1 else 3 ** nr - 1)
+                dpc = mvn_stream.draws_per_call
+                if subset_mode:
+                    draws_out = npat * (dpc(nr) + (1 + nfb) * dpc(nE + 1))
+                    draws_in = npat * (dpc(nr) + (1 + nfb) * dpc(nE))
+                    in_pos = sorted(pos_of[e] for e in E if e in pos_of and e not in picks)
+                else:
+                    draws_out = npat * (1 + nfb) * dpc(nr)
+                    draws_in = 0
+                    in_pos = []
+                dead_pos = [pos_of[q] for q in picks]
+                desc = ItalGscoreDesc()
+                desc.n_cand = n_loc
+                desc.cand, desc.alive, desc.mu, desc.s2 = _ptr(cand_d), _ptr(alive), _ptr(gp.mu), _ptr(gp.s2)
+                desc.C, desc.ldc = _ptr(C), gp.ldv
+                desc.row_offset, desc.pos_offset = gp.row0, pos_offset
+                t_eidx = torch.as_tensor(E if E else [0], dtype=torch.int64, device=dev)
+                t_esort = torch.as_tensor(np.argsort(np.asarray(E, dtype=np.int64), kind="stable") if E else [0],
+                                          dtype=torch.int32, device=dev)
+                t_emu = torch.from_numpy(np.ascontiguousarray(e_mu)).to(dev)
+                t_esig = torch.from_numpy(np.ascontiguousarray(e_sig)).to(dev)
+                t_ppos = torch.as_tensor(pick_pos if pick_pos else [0], dtype=torch.int32, device=dev)
+                t_in = torch.as_tensor(in_pos if in_pos else [0], dtype=torch.int64, device=dev)
+                t_dead = torch.as_tensor(dead_pos if dead_pos else [0], dtype=torch.int64, device=dev)
+                desc.nE, desc.E_idx, desc.E_sort, desc.E_mu, desc.E_sig, desc.ldE = nE, _ptr(t_eidx), _ptr(t_esort), \
+                    _ptr(t_emu), _ptr(t_esig), kmax_e
+                desc.n_picks, desc.pick_pos = len(picks), _ptr(t_ppos)
+                desc.subset_mode, desc.fb_mode = int(subset_mode), fb_mode
+                desc.label_prob, desc.mistake_prob = float(self.label_prob), float(self.mistake_prob)
+                desc.label_mode = _LABEL_MODES[self.label_estimation]
+                desc.noise, desc.eps = float(self.noise), float(self.eps)
+                for j in range(6):
+                    desc.seed[j] = stream.state[j]
+                desc.jump1, desc.skip, desc.vk = _ptr(jump1), _ptr(skip), _ptr(vk)
+                desc.draws_out, desc.draws_in = draws_out, draws_in
+                desc.n_in, desc.in_pos, desc.n_dead, desc.dead_pos = len(in_pos), _ptr(t_in), len(dead_pos), _ptr(t_dead)
+                desc.mi, desc.status = _ptr(mi), _ptr(gp.status)
+                ev0 = self._mark()
+                check(lib.ital_score_generic(ctypes.byref(desc), st))
+                self._mark("score_generic", t, n_alive, ev0)
+                if self.keep_scores:
+                    self.last_scores.append(mi.clone())
+                check(lib.ital_select_local(_ptr(mi), _ptr(cand_d), _ptr(alive), n_loc, pos_offset, gp.row0, gp.rank, 0,
+                                            _ptr(gp.mu), _ptr(gp.s2), _ptr(gp.Xd), _ptr(gp.xnorm), gp.ldx, _ptr(gp.V),
+                                            gp.ldv, gp.m, gp.cap, _ptr(C), gp.ldv, nE, b["kmax"], _ptr(b["work"]),
+                                            _ptr(b["rec"]), st))
+                recs = sharding.gather_records(b["rec"], b["rec_all"], gp.group) if gp.world > 1 else b["rec"].unsqueeze(0)
+                recs_h = recs.cpu().numpy()          # host synchronisation of this greedy step
+                w = sharding.winner(recs_h, 0)
+                rec = recs_h[w]
+                pick = int(rec[2])
+                if int(rec[6]) == gp.rank:
+                    alive[int(rec[7])] = 0
+                n_in_alive = len(in_pos)
+                stream.advance((n_alive - n_in_alive) * draws_out + n_in_alive * draws_in)
+                n_alive -= 1
+                picks.append(pick)
+                if pick in E:
+                    pick_pos.append(E.index(pick))
+                else:
+                    # new member of the base set: its covariance column, mean and covariances with the members so far
+                    h = ITAL_REC_HEADER
+                    e_mu[nE] = rec[3]
+                    e_sig[nE, nE] = rec[4]
+                    e_sig[nE, :nE] = rec[h + gp.ldx + gp.cap: h + gp.ldx + gp.cap + nE]
+                    e_sig[:nE, nE] = e_sig[nE, :nE]
+                    if t < k:
+                        rec_d = recs[w]
+                        xrow = rec_d[h:h + gp.ldx].contiguous()
+                        vcol = rec_d[h + gp.ldx:h + gp.ldx + gp.cap].contiguous()
+                        xn = rec_d[5:6].contiguous()
+                        check(lib.ital_cross_cov_cols(_ptr(gp.Xd), _ptr(gp.xnorm), gp.n, gp.ldx, _ptr(xrow), _ptr(xn), 1,
+                                                      _ptr(vcol), gp.cap, _ptr(gp.V), gp.ldv, gp.m, float(self.var),
+                                                      float(self.length_scale), _ptr(C[nE]), gp.ldv, st))
+                        torch.cuda.current_stream().synchronize()   # xrow / vcol are temporaries
+                    pick_pos.append(nE)
+                    E.append(pick)
+        gp.check_status()
+        return [int(i) for i in picks]

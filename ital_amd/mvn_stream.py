@@ -101,5 +101,40 @@ def jump_table(n, bits=48):
     return _jump_cache[key]
 
 
+def jump1_table(bits=48):
+    """int64 [bits][18]: transition matrices of both components for 2^b uniforms."""
+    key = ("single", bits)
+    if key not in _jump_cache:
+        j1, j2 = A1, A2
+        out = np.empty((bits, 18), dtype=np.int64)
+        for b in range(bits):
+            out[b, :9] = np.array(j1, dtype=np.int64).ravel()
+            out[b, 9:] = np.array(j2, dtype=np.int64).ravel()
+            j1, j2 = _matmul(j1, j1, M1), _matmul(j2, j2, M2)
+        _jump_cache[key] = out
+    return _jump_cache[key]
+
+
+def skip_table(nmax):
+    """int64 [nmax + 1][18]: transition matrix of the uniforms ONE call of dimension n consumes (identity, n <= 2)."""
+    key = ("skip", nmax)
+    if key not in _jump_cache:
+        out = np.empty((nmax + 1, 18), dtype=np.int64)
+        for n in range(nmax + 1):
+            d = draws_per_call(n)
+            out[n, :9] = np.array(_matpow(A1, d, M1), dtype=np.int64).ravel()
+            out[n, 9:] = np.array(_matpow(A2, d, M2), dtype=np.int64).ravel()
+        _jump_cache[key] = out
+    return _jump_cache[key]
+
+
+def vk_table(nmax):
+    """float64 [nmax + 1][nmax]: Korobov generator vector of every dimension 3..nmax (row n, first n - 1 entries)."""
+    out = np.zeros((nmax + 1, nmax), dtype=np.float64)
+    for n in range(3, nmax + 1):
+        out[n, : n - 1] = korobov_vk(n)
+    return out
+
+
 #: the process-global stream (one per process, as in the reference)
 GLOBAL = MvnStream()

@@ -74,13 +74,15 @@ def test_gp_update_predict_vs_oracle(dev):
 
 
 # ------------------------------------------------------------------------------------------ golden vectors
-def _run_fixture(dev, golden_dir, name, rounds=None, mi_atol=1e-10):
+def _run_fixture(dev, golden_dir, name, rounds=None, mi_atol=1e-10, force_generic=False):
     ITAL, _, mvn_stream = _learners()
     z = np.load(os.path.join(golden_dir, name + ".npz"))
     spec = make_golden.FIXTURES[name]
     mvn_stream.GLOBAL.reset()
+    np.random.seed(0)          # as the fixture generator (the change-estimation subset is drawn from numpy's global RNG)
     L = ITAL(z["X"], length_scale=float(z["length_scale"]), device=dev, **spec["kw"])
     L.keep_scores = True
+    L.force_generic = force_generic
     L.update({int(z["query"]): 1})
     rel = z["rel"]
     for r in range(int(z["rounds"]) if rounds is None else rounds):
@@ -88,6 +90,8 @@ def _run_fixture(dev, golden_dir, name, rounds=None, mi_atol=1e-10):
         np.testing.assert_allclose(m, z[f"r{r}_rel_mean"], rtol=0, atol=1e-10)
         np.testing.assert_allclose(v, z[f"r{r}_var"], rtol=0, atol=1e-9)
         ret = L.fetch_unlabelled(int(z["k"]))
+        if f"r{r}_ce_subset" in z:
+            assert L._ce_subset == z[f"r{r}_ce_subset"].tolist()
         cand0 = z[f"r{r}_s0_cand"].tolist()
         pos = {c: i for i, c in enumerate(cand0)}
         for t in range(len(ret)):
@@ -108,6 +112,18 @@ def test_golden_fixture(dev, golden_dir, name):
     pm, pv = L.gp.predict(z["predict_X"], cov_mode="diag")
     np.testing.assert_allclose(pm, z["predict_mean"], rtol=0, atol=1e-9)
     np.testing.assert_allclose(pv, z["predict_var"], rtol=0, atol=1e-9)
+
+
+@pytest.mark.parametrize("name", ["synth200_noisy", "synth200_motivated", "iris_ce5"])
+def test_golden_fixture_general_scorer(dev, golden_dir, name):
+    """Noisy user models (general / motivated) and the change-estimation subset: ital_score_generic."""
+    _run_fixture(dev, golden_dir, name)
+
+
+@pytest.mark.parametrize("name", ["usps500", "synth96_k6", "synth200_optimistic", "synth200_topcand"])
+def test_general_scorer_equals_fast_path(dev, golden_dir, name):
+    """The perfect-user case through the general scorer must give the golden MI vectors and picks as well."""
+    _run_fixture(dev, golden_dir, name, force_generic=True)
 
 
 # ------------------------------------------------------------------------------------------ HIP vs oracle, seeded
@@ -143,6 +159,47 @@ def test_against_oracle(dev, seed, n, d, k, mode):
     assert mvn_stream.GLOBAL.draws == omvn.rng_draws()   # the replayed stream stands where the serial reference's does
 
 
+@pytest.mark.parametrize("seed,n,d,k,kw", [
+    (0, 90, 6, 3, dict(label_prob=0.75, mistake_prob=0.05)),
+    (1, 70, 10, 4, dict(label_prob=0.5, mistake_prob=0.25)),
+    (2, 80, 5, 4, dict(label_prob=1.0, mistake_prob=0.2)),
+    (3, 60, 4, 3, dict(change_estimation_subset=4)),
+    (4, 50, 4, 3, dict(change_estimation_subset=3, label_prob=0.8, mistake_prob=0.1)),
+    (5, 64, 7, 3, dict(label_prob=0.6, mistake_prob=0.1, label_estimation="optimistic")),
+    (6, 40, 3, 5, dict(change_estimation_subset=6)),
+])
+def test_general_scorer_against_oracle(dev, seed, n, d, k, kw):
+    from oracle import mvn as omvn
+    from oracle.ital import OracleITAL
+    ITAL, _, mvn_stream = _learners()
+    rng = np.random.default_rng(seed)
+    X = rng.random((n, d))
+    ls = float(np.sqrt(d / 12.0))
+    labels = {int(i): (1 if X[i, 0] > 0.5 else -1) for i in rng.choice(n, 4, replace=False)}
+    mvn_stream.GLOBAL.reset()
+    omvn.rng_reset()
+    A = ITAL(X, length_scale=ls, device=dev, **kw)
+    A.keep_scores = True
+    B = OracleITAL(X, length_scale=ls, **kw)
+    A.update(labels)
+    B.update(labels)
+    for rnd in range(2):
+        np.random.seed(100 + rnd)
+        got = A.fetch_unlabelled(k)
+        np.random.seed(100 + rnd)
+        want = [int(i) for i in B.fetch_unlabelled(k)]
+        cand0 = B.trace[0][0]
+        pos = {c: i for i, c in enumerate(cand0)}
+        for t, (cand, vals, _) in enumerate(B.trace):
+            mine = A.last_scores[t].cpu().numpy()[[pos[c] for c in cand]]
+            np.testing.assert_allclose(mine, vals, rtol=1e-7, atol=1e-10, err_msg=f"round {rnd} step {t}")
+        assert got == want
+        fb = {i: (1 if X[i, 0] > 0.5 else -1) for i in got}
+        A.update(fb)
+        B.update(fb)
+    assert mvn_stream.GLOBAL.draws == omvn.rng_draws()
+
+
 # ------------------------------------------------------------------------------------------ API behaviour / edge cases
 def test_api_edge_cases(dev):
     ITAL, _, mvn_stream = _learners()
@@ -169,7 +226,9 @@ def test_api_edge_cases(dev):
     L.reset()
     assert L.rounds == 0 and L.gp.m == 0 and L.rel_mean is None
     with pytest.raises(NotImplementedError):
-        ITAL(X, length_scale=0.7, label_prob=0.8, device=dev).fetch_unlabelled(2)
+        M = ITAL(X, length_scale=0.7, monte_carlo_num_rel=2, device=dev)
+        M.update({0: 1})
+        M.fetch_unlabelled(2)
 
 
 def test_queries_constructor(dev):
