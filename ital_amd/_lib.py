@@ -6,7 +6,7 @@ import ctypes
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libital_hip.so")
+LIB_PATH = os.environ.get("ITAL_HIP_LIB", os.path.join(HERE, "libital_hip.so"))  # override: kernel-variant experiments
 
 c_void_p, c_int, c_int64, c_double = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_double
 

@@ -10,7 +10,9 @@ INCLUDE = os.path.join(os.path.dirname(HERE), "include")
 LIB = os.path.join(HERE, "libital_hip.so")
 SOURCES = ["api.hip", "rbf.hip", "chol.hip", "score.hip", "select.hip", "mcmi.hip", "score_generic.hip"]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fgpu-rdc" if False else "-fno-gpu-rdc",
+EXTRA = os.environ.get("ITAL_HIPCC_EXTRA", "").split()
+LIB = os.environ.get("ITAL_HIP_LIB_OUT", LIB)
+FLAGS = EXTRA + ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fgpu-rdc" if False else "-fno-gpu-rdc",
          "-I", INCLUDE, "-I", CSRC, "-Wall", "-Wno-unused-function"]
 
 
@@ -24,7 +26,7 @@ def _newer(target, deps):
 def build(force=False, verbose=False):
     headers = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")] + \
               [os.path.join(INCLUDE, "ital_hip.h")]
-    objdir = os.path.join(HERE, "_obj")
+    objdir = os.environ.get("ITAL_OBJ_DIR", os.path.join(HERE, "_obj"))
     os.makedirs(objdir, exist_ok=True)
     jobs = []
     objs = []

@@ -12,6 +12,23 @@
 
 namespace ital {
 
+// acc * x + K with the constant K held in a scalar register pair.  Plain fma() lets the compiler park polynomial
+// coefficients in VGPRs and form v_fmac (dst tied to the addend), which costs a v_mov_b64 per Horner step to keep the
+// coefficient alive (measured: 188 of 1700 VALU instructions of the lattice loop); the three-address form with a scalar
+// addend is one VALU instruction, the s_mov pair that loads K issues on the scalar unit in the shadow of other waves.
+#ifndef ITAL_FMA_K
+#define ITAL_FMA_K 0   // measured on MI355X: the scalar-addend form is slower (the scalar unit becomes the co-bottleneck)
+#endif
+__device__ __forceinline__ double fma_k(double acc, double x, double K) {
+#if ITAL_FMA_K
+    double r;
+    asm("v_fma_f64 %0, %1, %2, %3" : "=v"(r) : "v"(acc), "v"(x), "s"(K));
+    return r;
+#else
+    return fma(acc, x, K);
+#endif
+}
+
 // n / d for well-scaled d (polynomial denominators, no zero / inf / subnormal): hardware reciprocal seed, two
 // Newton steps and one residual correction -- ~1 ulp, about half the instructions of the IEEE division expansion.
 __device__ __forceinline__ double fast_div(double n, double d) {
@@ -30,16 +47,16 @@ __device__ __forceinline__ double exp_neg(double x) {
     double r = fma(-n, LN2_HI, x);
     r = fma(-n, LN2_LO, r);
     double p = 1.0 / 6227020800.0;
-    p = fma(p, r, 1.0 / 479001600.0);
-    p = fma(p, r, 1.0 / 39916800.0);
-    p = fma(p, r, 1.0 / 3628800.0);
-    p = fma(p, r, 1.0 / 362880.0);
-    p = fma(p, r, 1.0 / 40320.0);
-    p = fma(p, r, 1.0 / 5040.0);
-    p = fma(p, r, 1.0 / 720.0);
-    p = fma(p, r, 1.0 / 120.0);
-    p = fma(p, r, 1.0 / 24.0);
-    p = fma(p, r, 1.0 / 6.0);
+    p = fma_k(p, r, 1.0 / 479001600.0);
+    p = fma_k(p, r, 1.0 / 39916800.0);
+    p = fma_k(p, r, 1.0 / 3628800.0);
+    p = fma_k(p, r, 1.0 / 362880.0);
+    p = fma_k(p, r, 1.0 / 40320.0);
+    p = fma_k(p, r, 1.0 / 5040.0);
+    p = fma_k(p, r, 1.0 / 720.0);
+    p = fma_k(p, r, 1.0 / 120.0);
+    p = fma_k(p, r, 1.0 / 24.0);
+    p = fma_k(p, r, 1.0 / 6.0);
     p = fma(p, r, 0.5);
     p = fma(p, r, 1.0);
     p = fma(p, r, 1.0);
@@ -59,14 +76,14 @@ __device__ __forceinline__ double log_pos(double x) {
     const double s = fast_div(f, 2.0 + f);
     const double z = s * s;
     double p = 2.0 / 19.0;
-    p = fma(p, z, 2.0 / 17.0);
-    p = fma(p, z, 2.0 / 15.0);
-    p = fma(p, z, 2.0 / 13.0);
-    p = fma(p, z, 2.0 / 11.0);
-    p = fma(p, z, 2.0 / 9.0);
-    p = fma(p, z, 2.0 / 7.0);
-    p = fma(p, z, 2.0 / 5.0);
-    p = fma(p, z, 2.0 / 3.0);
+    p = fma_k(p, z, 2.0 / 17.0);
+    p = fma_k(p, z, 2.0 / 15.0);
+    p = fma_k(p, z, 2.0 / 13.0);
+    p = fma_k(p, z, 2.0 / 11.0);
+    p = fma_k(p, z, 2.0 / 9.0);
+    p = fma_k(p, z, 2.0 / 7.0);
+    p = fma_k(p, z, 2.0 / 5.0);
+    p = fma_k(p, z, 2.0 / 3.0);
     const double lm = fma(s * z, p, s + s);
     const double de = (double)e;
     return fma(de, LN2_HI, fma(de, LN2_LO, lm));
@@ -102,8 +119,8 @@ __device__ __forceinline__ double mvn_phi(double z) {
     } else {
         const double expntl = exp_neg(-zabs * zabs / 2);
         if (zabs < CUTOFF) {
-            const double num = ((((((P6 * zabs + P5) * zabs + P4) * zabs + P3) * zabs + P2) * zabs + P1) * zabs + P0);
-            const double den = (((((((Q7 * zabs + Q6) * zabs + Q5) * zabs + Q4) * zabs + Q3) * zabs + Q2) * zabs + Q1) * zabs + Q0);
+            const double num = fma_k(fma_k(fma_k(fma_k(fma_k(fma_k(P6, zabs, P5), zabs, P4), zabs, P3), zabs, P2), zabs, P1), zabs, P0);
+            const double den = fma_k(fma_k(fma_k(fma_k(fma_k(fma_k(fma_k(Q7, zabs, Q6), zabs, Q5), zabs, Q4), zabs, Q3), zabs, Q2), zabs, Q1), zabs, Q0);
             p = fast_div(expntl * num, den);
         } else {
             const double n5 = zabs + 0.65;
@@ -130,8 +147,9 @@ __device__ __forceinline__ double phinv_central(double p) {
                  B5 = 3.9307895800092710610E+4, B6 = 2.8729085735721942674E+4, B7 = 5.2264952788528545610E+3;
     const double q = (2 * p - 1) / 2;
     const double r = 0.180625 - q * q;
-    return fast_div(q * (((((((A7 * r + A6) * r + A5) * r + A4) * r + A3) * r + A2) * r + A1) * r + A0),
-                    (((((((B7 * r + B6) * r + B5) * r + B4) * r + B3) * r + B2) * r + B1) * r + 1));
+    const double num = fma_k(fma_k(fma_k(fma_k(fma_k(fma_k(fma_k(A7, r, A6), r, A5), r, A4), r, A3), r, A2), r, A1), r, A0);
+    const double den = fma(fma_k(fma_k(fma_k(fma_k(fma_k(fma_k(B7, r, B6), r, B5), r, B4), r, B3), r, B2), r, B1), r, 1.0);
+    return fast_div(q * num, den);
 }
 
 __device__ __forceinline__ double phinv_tail(double p) {
@@ -147,8 +165,8 @@ __device__ __forceinline__ double phinv_tail(double p) {
                          D2 = 1.67638483018380384940E0, D3 = 6.89767334985100004550E-1, D4 = 1.48103976427480074590E-1,
                          D5 = 1.51986665636164571966E-2, D6 = 5.47593808499534494600E-4, D7 = 1.05075007164441684324E-9;
             r = r - 1.6;
-            v = fast_div((((((((C7 * r + C6) * r + C5) * r + C4) * r + C3) * r + C2) * r + C1) * r + C0),
-                         (((((((D7 * r + D6) * r + D5) * r + D4) * r + D3) * r + D2) * r + D1) * r + 1));
+            v = fast_div(fma_k(fma_k(fma_k(fma_k(fma_k(fma_k(fma_k(C7, r, C6), r, C5), r, C4), r, C3), r, C2), r, C1), r, C0),
+                         fma(fma_k(fma_k(fma_k(fma_k(fma_k(fma_k(D7, r, D6), r, D5), r, D4), r, D3), r, D2), r, D1), r, 1.0));
         } else {
             const double E0 = 6.65790464350110377720E0, E1 = 5.46378491116411436990E0, E2 = 1.78482653991729133580E0,
                          E3 = 2.96560571828504891230E-1, E4 = 2.65321895265761230930E-2, E5 = 1.24266094738807843860E-3,
@@ -156,8 +174,8 @@ __device__ __forceinline__ double phinv_tail(double p) {
                          F2 = 1.36929880922735805310E-1, F3 = 1.48753612908506148525E-2, F4 = 7.86869131145613259100E-4,
                          F5 = 1.84631831751005468180E-5, F6 = 1.42151175831644588870E-7, F7 = 2.04426310338993978564E-15;
             r = r - 5.0;
-            v = fast_div((((((((E7 * r + E6) * r + E5) * r + E4) * r + E3) * r + E2) * r + E1) * r + E0),
-                         (((((((F7 * r + F6) * r + F5) * r + F4) * r + F3) * r + F2) * r + F1) * r + 1));
+            v = fast_div(fma_k(fma_k(fma_k(fma_k(fma_k(fma_k(fma_k(E7, r, E6), r, E5), r, E4), r, E3), r, E2), r, E1), r, E0),
+                         fma(fma_k(fma_k(fma_k(fma_k(fma_k(fma_k(F7, r, F6), r, F5), r, F4), r, F3), r, F2), r, F1), r, 1.0));
         }
     } else {
         v = 9;

@@ -22,6 +22,7 @@ __device__ __forceinline__ double uniform_f64(double v) {
 // arguments that fall into the tails (|p - 1/2| > 0.425) are compacted across the wave through LDS so that the
 // expensive log/sqrt branch runs on full waves of tail arguments only (typically once per 256 inversions instead of
 // once per 64).
+// q: wave-private LDS queue of 64*NC doubles.
 template <int NC>
 __device__ __forceinline__ void phinv_wave(const double (&p)[NC], double (&out)[NC], double* __restrict__ q, int lane) {
     bool need[NC];
@@ -30,7 +31,7 @@ __device__ __forceinline__ void phinv_wave(const double (&p)[NC], double (&out)[
 #pragma unroll
     for (int c = 0; c < NC; c++) {
         need[c] = !phinv_is_central(p[c]);
-        out[c] = phinv_central(need[c] ? 0.5 : p[c]);
+        out[c] = phinv_central(p[c]);   // garbage (never a trap) for tail arguments: replaced below
         const unsigned long long m = __ballot(need[c]);
         slot[c] = total + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
         total += __popcll(m);
@@ -42,14 +43,14 @@ __device__ __forceinline__ void phinv_wave(const double (&p)[NC], double (&out)[
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     for (int s0 = 0; s0 < total; s0 += 64) {
         const int sl = s0 + lane;
-        if (sl < total) q[256 + sl] = phinv_tail(q[sl]);
+        if (sl < total) q[sl] = phinv_tail(q[sl]);   // in place: each lane rewrites the slot it read
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 #pragma unroll
     for (int c = 0; c < NC; c++)
-        if (need[c]) out[c] = q[256 + slot[c]];
+        if (need[c]) out[c] = q[slot[c]];
 }
 
 __device__ __forceinline__ void phinv_wave4(const double (&p)[4], double (&out)[4], double* __restrict__ q, int lane) {

@@ -23,6 +23,13 @@
 #include "ital_internal.h"
 #include "qmc_common.h"
 
+#ifndef ITAL_QMC_NH
+#define ITAL_QMC_NH 2      // lattice items per lane and round (each with its antithetic partner)
+#endif
+#ifndef ITAL_QMC_WAVES
+#define ITAL_QMC_WAVES 3   // waves per SIMD the register allocation aims at (measured best: 2 items x 3 waves)
+#endif
+
 namespace ital {
 
 struct ScoreArgs {
@@ -147,7 +154,7 @@ struct Qmc {
     static constexpr int A_PIVOT = 0, A_COR = A_PIVOT + T, A_MU0 = A_COR + NCOR, A_G = A_MU0 + T, A_SD = A_G + T * T,
                          A_SIZE = A_SD + T;
     static constexpr int LAT = 8 * NDIM * 2;                  // per call: permuted generators + shifts, 8 shifts
-    static constexpr int TAILQ = 512;                         // compaction queue of the Phi^-1 tail branch (in + out)
+    static constexpr int TAILQ = 128 * ITAL_QMC_NH;           // compaction queue of the Phi^-1 tail branch (in place)
     static constexpr int WAVE_DOUBLES = CHUNK * SLAB + A_SIZE + LAT + NDIM + T + TAILQ;  // + running vk + perm
 };
 
@@ -212,7 +219,7 @@ __device__ bool covsrt(double* cov, double* lim, double* y, unsigned& infi) {
 }
 
 template <int T>
-__global__ __launch_bounds__(256) void score_qmc_kernel(ScoreArgs a) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(ITAL_QMC_WAVES, ITAL_QMC_WAVES))) void score_qmc_kernel(ScoreArgs a) {
     using Q = Qmc<T>;
     extern __shared__ double lds_all[];
     const int lane = threadIdx.x & 63;
@@ -416,12 +423,13 @@ __global__ __launch_bounds__(256) void score_qmc_kernel(ScoreArgs a) {
                     for (int j = 0; j < i; j++) cf[i * (i - 1) / 2 + j] = uniform_f64(cov[pidx(i, j)]);
                 }
                 double acc = 0.0;
-                // NCH = 4 independent chains per lane: two lattice items, each with its antithetic partner
-                for (int base = 0; base < 8 * Q::PRIME; base += 128) {
-                    double xx[4][Q::NDIM], yy[4][Q::NDIM], ff[4];
-                    bool dead[4];
+                // NC = 2*NH independent chains per lane: NH lattice items, each with its antithetic partner
+                constexpr int NH = ITAL_QMC_NH, NC = 2 * NH;
+                for (int base = 0; base < 8 * Q::PRIME; base += 64 * NH) {
+                    double xx[NC][Q::NDIM], yy[NC][Q::NDIM], ff[NC];
+                    bool dead[NC];
 #pragma unroll
-                    for (int h = 0; h < 2; h++) {
+                    for (int h = 0; h < NH; h++) {
                         const int item = base + 64 * h + lane;
                         const bool ok = item < 8 * Q::PRIME;
                         const int it = ok ? item : 0;
@@ -440,9 +448,9 @@ __global__ __launch_bounds__(256) void score_qmc_kernel(ScoreArgs a) {
 #pragma unroll
                     for (int i = 0; i < T; i++) {
                         const bool lower = (infi_c >> i) & 1u;
-                        double pin[4];
+                        double pin[NC];
 #pragma unroll
-                        for (int c = 0; c < 4; c++) {
+                        for (int c = 0; c < NC; c++) {
                             double sc = 0;
 #pragma unroll
                             for (int j = 0; j < i; j++) sc = fma(cf[i * (i - 1) / 2 + j], yy[c][j], sc);
@@ -451,17 +459,17 @@ __global__ __launch_bounds__(256) void score_qmc_kernel(ScoreArgs a) {
                             const double w = lower ? 1.0 - ph : ph;
                             dead[c] = dead[c] || !(w > 0);
                             ff[c] *= w;
-                            if (i < T - 1) pin[c] = dead[c] ? 0.5 : fma(xx[c][i], w, d);
+                            if (i < T - 1) pin[c] = fma(xx[c][i], w, d);   // a dead chain (w == 0) just inverts d: finite, discarded
                         }
                         if (i < T - 1) {
-                            double out[4];
-                            phinv_wave4(pin, out, tailq, lane);
+                            double out[NC];
+                            phinv_wave<NC>(pin, out, tailq, lane);
 #pragma unroll
-                            for (int c = 0; c < 4; c++) yy[c][i] = out[c];
+                            for (int c = 0; c < NC; c++) yy[c][i] = out[c];
                         }
                     }
 #pragma unroll
-                    for (int c = 0; c < 4; c++) acc += dead[c] ? 0.0 : ff[c];
+                    for (int c = 0; c < NC; c++) acc += dead[c] ? 0.0 : ff[c];
                 }
                 value = wave_sum(acc) / (16.0 * Q::PRIME);
             }

@@ -462,7 +462,7 @@ __device__ double qmc_eval(int n, const double* __restrict__ slab, unsigned infi
                         dead[c] = dead[c] || !(w > 0);
                         ff[c] *= w;
                         const double x = (c & 1) ? 1 - xh[c >> 1] : xh[c >> 1];
-                        pin[c] = dead[c] ? 0.5 : fma(x, w, dd);
+                        pin[c] = fma(x, w, dd);
                     }
                     if (!last) {
                         double outv[NC];
