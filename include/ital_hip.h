@@ -24,8 +24,9 @@ typedef struct ihipStream_t* hipStream_t; /* same declaration as hip_runtime_api
 #define ITAL_MAX_T 8        /* largest batch dimension with full sign-pattern enumeration on the device */
 #define ITAL_REC_HEADER 8   /* doubles in front of the feature row inside a selection record */
 #define ITAL_JUMP_BITS 48
-#define ITAL_GENERIC_MAX_DIM 12  /* largest orthant dimension of the general scorer (subset + picks + candidate) */
-#define ITAL_GENERIC_MAX_REL 6   /* largest number of enumerated variables of the general scorer */
+#define ITAL_GENERIC_MAX_DIM 20  /* largest orthant dimension of the general scorer (subset + picks + candidate) */
+#define ITAL_GENERIC_MAX_REL 16  /* largest number of enumerated / sampled variables of the general scorer */
+#define ITAL_GENERIC_MAX_CALLS (1 << 22) /* orthant probabilities per candidate and greedy step */
 
 /* Library identification / error reporting. */
 const char* ital_version(void);
@@ -199,6 +200,14 @@ typedef struct ital_gscore_desc {
     const int64_t* in_pos;  /* [n_in] list positions of the live candidates inside E */
     int n_dead;
     const int64_t* dead_pos;/* [n_dead] list positions already picked */
+    /* Monte-Carlo switches (reference ital/ital.py:293-297, :318-337): explicit sign patterns / feedback configurations
+     * per candidate instead of the full enumeration; sampled by the host (numpy's global RNG, as the reference) */
+    int mc_rel;             /* 0: enumerate the 2^(n_picks+1) patterns; > 0: patterns per candidate in rel_samples */
+    const uint32_t* rel_samples; /* [n_cand][mc_rel] bit (n_picks - v) = sign of enumerated variable v */
+    int mc_fb;              /* 0: enumerate; > 0: feedback configurations per pattern in fb_samples */
+    const uint32_t* fb_samples;  /* [n_cand][patterns][mc_fb] low 16 bits: non-zero feedback (bit v), high 16: positive */
+    const int64_t* draw_off;/* [n_cand] uniforms consumed before each candidate (replaces draws_out / draws_in when the
+                               count per candidate varies: all-zero feedback samples are skipped without a call); or NULL */
     double* mi;             /* [n_cand] out */
     int* status;
 } ital_gscore_desc;

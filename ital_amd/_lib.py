@@ -13,8 +13,9 @@ c_void_p, c_int, c_int64, c_double = ctypes.c_void_p, ctypes.c_int, ctypes.c_int
 ITAL_MAX_T = 8
 ITAL_REC_HEADER = 8
 ITAL_JUMP_BITS = 48
-ITAL_GENERIC_MAX_DIM = 12
-ITAL_GENERIC_MAX_REL = 6
+ITAL_GENERIC_MAX_DIM = 20
+ITAL_GENERIC_MAX_REL = 16
+ITAL_GENERIC_MAX_CALLS = 1 << 22
 
 
 class ItalBatch(ctypes.Structure):
@@ -39,7 +40,9 @@ class ItalGscoreDesc(ctypes.Structure):
                 ("label_prob", c_double), ("mistake_prob", c_double), ("label_mode", c_int), ("noise", c_double),
                 ("eps", c_double), ("seed", c_int * 6), ("jump1", c_void_p), ("skip", c_void_p), ("vk", c_void_p),
                 ("draws_out", c_int64), ("draws_in", c_int64), ("n_in", c_int), ("in_pos", c_void_p),
-                ("n_dead", c_int), ("dead_pos", c_void_p), ("mi", c_void_p), ("status", c_void_p)]
+                ("n_dead", c_int), ("dead_pos", c_void_p), ("mc_rel", c_int), ("rel_samples", c_void_p),
+                ("mc_fb", c_int), ("fb_samples", c_void_p), ("draw_off", c_void_p), ("mi", c_void_p),
+                ("status", c_void_p)]
 
 
 class ItalMcmiDesc(ctypes.Structure):

@@ -23,6 +23,7 @@
 // update, COVSRT) in its own LDS slab; the wave then evaluates the chunk's calls one after the other with the lattice
 // points spread over the lanes (4 chains per lane, runtime dimension <= NMAX with uniform early exits).
 #include <hip/hip_runtime.h>
+#include <math.h>
 #include <stdint.h>
 
 #include "device_math.h"
@@ -132,13 +133,13 @@ __device__ bool covsrt_n(int n, double* cov, double* lim, double* y, unsigned& i
 __device__ unsigned group_layout(int n, double* cov) {
     unsigned closes = 0;
     int ik = 0;                    // groups closed before the current row
-    unsigned long long crow = 0;   // closing row of each group, 4 bits each
+    unsigned long long crow0 = 0, crow1 = 0;   // closing row of each group, 5 bits each (12 groups per word)
     for (int i = 0; i < n; i++) {
         // columns >= ik of row i are ignored by MVNDFN; re-pack columns g < ik to column crow[g]
         const int nk = ik < i ? ik : i;
         for (int j = nk; j < i; j++) cov[pidx(i, j)] = 0;
         for (int g = nk - 1; g >= 0; g--) {
-            const int r = (int)((crow >> (4 * g)) & 15ull);
+            const int r = g < 12 ? (int)((crow0 >> (5 * g)) & 31ull) : (int)((crow1 >> (5 * (g - 12))) & 31ull);
             if (r != g) {
                 cov[pidx(i, r)] = cov[pidx(i, g)];
                 cov[pidx(i, g)] = 0;
@@ -147,7 +148,8 @@ __device__ unsigned group_layout(int n, double* cov) {
         const bool close = (i == n - 1) || (cov[pidx(i + 1, ik + 1)] > 0);
         if (close) {
             closes |= 1u << i;
-            crow |= (unsigned long long)i << (4 * ik);
+            if (ik < 12) crow0 |= (unsigned long long)i << (5 * ik);
+            else crow1 |= (unsigned long long)i << (5 * (ik - 12));
             ik++;
         }
     }
@@ -171,10 +173,14 @@ __device__ __forceinline__ int pow3(int n) {
     return r;
 }
 
-__device__ CallInfo decode_call(int call, int cpp, int npre, int nr, int fb_mode, bool subset, double lp, double mp) {
+enum { K_SKIP = 4 };
+
+// Call `call` of candidate position p.  cpp = calls per pattern (npre prior calls + nfb feedback configurations).
+__device__ CallInfo decode_call(const ital_gscore_desc& d, int64_t p, int call, int cpp, int npre, int nr, int npat) {
     CallInfo c;
+    const bool subset = d.subset_mode != 0;
     const int pi = call / cpp, s = call - pi * cpp;
-    c.pat = (unsigned)pi;
+    c.pat = d.mc_rel > 0 ? d.rel_samples[p * d.mc_rel + pi] : (unsigned)pi;
     c.fnz = 0; c.fpos = 0; c.weight = 1.0;
     if (s < npre) {
         c.kind = subset ? (s == 0 ? K_PRIOR_SUB : K_PRIOR_FULL) : K_PRIOR;
@@ -182,12 +188,20 @@ __device__ CallInfo decode_call(int call, int cpp, int npre, int nr, int fb_mode
     }
     c.kind = K_UPDATED;
     int f = s - npre;
-    if (fb_mode == 0) {
+    if (d.fb_mode == 0) {
         c.fnz = (1u << nr) - 1u;
         for (int v = 0; v < nr; v++) c.fpos |= ((c.pat >> (nr - 1 - v)) & 1u) << v;
         return c;
     }
-    if (fb_mode == 1) {
+    if (d.mc_fb > 0) {
+        const unsigned w = d.fb_samples[(p * npat + pi) * d.mc_fb + f];
+        c.fnz = w & 0xffffu;
+        c.fpos = w >> 16;
+        c.weight = 1.0 / d.mc_fb;
+        if (c.fnz == 0) c.kind = K_SKIP;   // all-zero feedback: no call at all (ital.py:201)
+        return c;
+    }
+    if (d.fb_mode == 1) {
         c.fnz = (1u << nr) - 1u;
         for (int v = 0; v < nr; v++) c.fpos |= (((unsigned)f >> (nr - 1 - v)) & 1u) << v;
     } else {
@@ -201,6 +215,7 @@ __device__ CallInfo decode_call(int call, int cpp, int npre, int nr, int fb_mode
             if (dgt == 2) c.fpos |= 1u << v;
         }
     }
+    const double lp = d.label_prob, mp = d.mistake_prob;
     double w = 1.0;
     for (int v = 0; v < nr; v++) {
         const bool r = (c.pat >> (nr - 1 - v)) & 1u;
@@ -552,14 +567,15 @@ __global__ __launch_bounds__(128) void score_generic_kernel(GArgs a) {
         for (int i = 0; i < d.n_dead; i++) before -= (d.dead_pos[i] < gpos) ? 1 : 0;
         for (int i = 0; i < d.n_in; i++) n_in += (d.in_pos[i] < gpos) ? 1 : 0;
         uint64_t off = (uint64_t)(before - n_in) * (uint64_t)d.draws_out + (uint64_t)n_in * (uint64_t)d.draws_in;
+        if (d.draw_off) off = (uint64_t)d.draw_off[p];
         for (int bit = 0; off != 0; bit++, off >>= 1)
             if (off & 1) mrg_apply(rng, d.jump1 + bit * 18);
     }
     wave_sync();
 
-    const int npat = 1 << nr;
+    const int npat = d.mc_rel > 0 ? d.mc_rel : (1 << nr);
     const int npre = subset ? 2 : 1;
-    const int nfb = d.fb_mode == 0 ? 1 : (d.fb_mode == 1 ? (1 << nr) : pow3(nr) - 1);
+    const int nfb = d.fb_mode == 0 ? 1 : (d.mc_fb > 0 ? d.mc_fb : (d.fb_mode == 1 ? (1 << nr) : pow3(nr) - 1));
     const int cpp = npre + nfb;
     const int total = npat * cpp;
     const bool clamp_prior = !subset && nr == 1;   // first greedy step: predict_stored(cov_mode='diag') (ital.py:558)
@@ -570,9 +586,10 @@ __global__ __launch_bounds__(128) void score_generic_kernel(GArgs a) {
         Prep pp;
         pp.n = 0; pp.infi = 0; pp.flags = 0; pp.value = 0; pp.closes = 0;
         if (lane < a.chunk && chunk0 + lane < total) {
-            const CallInfo ci = decode_call(chunk0 + lane, cpp, npre, nr, d.fb_mode, subset, d.label_prob, d.mistake_prob);
+            const CallInfo ci = decode_call(d, p, chunk0 + lane, cpp, npre, nr, npat);
             double* slab = slabs + (size_t)lane * a.stride;
-            pp = prepare_call(d, ci, nU, nr, muU, SigU, usort, ipos, clamp_prior, slab, slab + a.slab);
+            if (ci.kind == K_SKIP) { pp.flags = 16; }
+            else pp = prepare_call(d, ci, nU, nr, muU, SigU, usort, ipos, clamp_prior, slab, slab + a.slab);
         }
         wave_sync();
         // ---------------- Phase C
@@ -582,6 +599,7 @@ __global__ __launch_bounds__(128) void score_generic_kernel(GArgs a) {
             const unsigned infi_c = (unsigned)__builtin_amdgcn_readlane((int)pp.infi, cl);
             const unsigned closes_c = (unsigned)__builtin_amdgcn_readlane((int)pp.closes, cl);
             double value;
+            if (fl_c & 16) continue;   // skipped all-zero feedback sample
             if (fl_c & 1) {
                 value = readlane_f64(pp.value, cl);
             } else if (fl_c & 6) {
@@ -605,7 +623,7 @@ __global__ __launch_bounds__(128) void score_generic_kernel(GArgs a) {
                 value = qmc_eval<NMAX, NH>(n_c, slabs + (size_t)cl * a.stride, infi_c, closes_c, lat, lane, tailq);
                 wave_sync();
             }
-            const CallInfo ci = decode_call(chunk0 + cl, cpp, npre, nr, d.fb_mode, subset, d.label_prob, d.mistake_prob);
+            const CallInfo ci = decode_call(d, p, chunk0 + cl, cpp, npre, nr, npat);
             if (ci.kind == K_PRIOR) {
                 pr_cur = value;
                 logpr_cur = log(value + d.eps);
@@ -620,12 +638,13 @@ __global__ __launch_bounds__(128) void score_generic_kernel(GArgs a) {
                 } else if (!subset && d.label_mode == 2) {
                     if (mi == 0 || cur < mi) mi = cur;
                 } else {
-                    mi += cur * pr_cur;
+                    mi += d.mc_rel > 0 ? cur : cur * pr_cur;   // sampled patterns are not weighted (ital.py:216-218)
                 }
             }
         }
         wave_sync();
     }
+    if (d.mc_rel > 0) mi /= d.mc_rel;   // ital.py:221-222
     if (lane == 0) d.mi[p] = mi;
 }
 
@@ -647,6 +666,14 @@ extern "C" int ital_score_generic(const ital_gscore_desc* d, hipStream_t stream)
     if (!d->subset_mode && d->nE != d->n_picks)
         return ital_fail(-22, "ital_score_generic: without a change-estimation subset the base set is the batch");
     if (d->fb_mode < 0 || d->fb_mode > 2) return ital_fail(-22, "ital_score_generic: fb_mode must be 0, 1 or 2");
+    if ((d->mc_rel > 0 && !d->rel_samples) || (d->mc_fb > 0 && !d->fb_samples))
+        return ital_fail(-22, "ital_score_generic: sample lists missing");
+    {
+        double npat = d->mc_rel > 0 ? (double)d->mc_rel : pow(2.0, nr);
+        double nfb = d->fb_mode == 0 ? 1.0 : (d->mc_fb > 0 ? (double)d->mc_fb : (d->fb_mode == 1 ? pow(2.0, nr) : pow(3.0, nr) - 1));
+        if (npat * (2 + nfb) > (double)ITAL_GENERIC_MAX_CALLS)
+            return ital_fail(-22, "ital_score_generic: more calls per candidate than ITAL_GENERIC_MAX_CALLS (use the monte-carlo switches)");
+    }
     if (!d->jump1 || !d->skip || !d->vk) return ital_fail(-22, "ital_score_generic: stream tables missing");
     GArgs a;
     a.d = *d;
@@ -667,13 +694,17 @@ extern "C" int ital_score_generic(const ital_gscore_desc* d, hipStream_t stream)
     if (!attr_done) {
         hipError_t e1 = hipFuncSetAttribute(reinterpret_cast<const void*>(&score_generic_kernel<6, 2>),
                                             hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        hipError_t e2 = hipFuncSetAttribute(reinterpret_cast<const void*>(&score_generic_kernel<ITAL_GENERIC_MAX_DIM, 1>),
+        hipError_t e2 = hipFuncSetAttribute(reinterpret_cast<const void*>(&score_generic_kernel<12, 1>),
                                             hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        if (e1 != hipSuccess || e2 != hipSuccess) return ital_fail(-12, "ital_score_generic: cannot raise the dynamic LDS limit");
+        hipError_t e3 = hipFuncSetAttribute(reinterpret_cast<const void*>(&score_generic_kernel<ITAL_GENERIC_MAX_DIM, 1>),
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e1 != hipSuccess || e2 != hipSuccess || e3 != hipSuccess) return ital_fail(-12, "ital_score_generic: cannot raise the dynamic LDS limit");
         attr_done = true;
     }
     if (nUmax <= 6)
         hipLaunchKernelGGL((score_generic_kernel<6, 2>), dim3((unsigned)blocks), dim3(128), lds, stream, a);
+    else if (nUmax <= 12)
+        hipLaunchKernelGGL((score_generic_kernel<12, 1>), dim3((unsigned)blocks), dim3(128), lds, stream, a);
     else
         hipLaunchKernelGGL((score_generic_kernel<ITAL_GENERIC_MAX_DIM, 1>), dim3((unsigned)blocks), dim3(128), lds, stream, a);
     return ital_check_launch("ital_score_generic");

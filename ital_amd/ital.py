@@ -17,7 +17,7 @@ import numpy as np
 import torch
 
 from . import _lib, mvn_stream, sharding
-from ._lib import (ITAL_GENERIC_MAX_DIM, ITAL_GENERIC_MAX_REL, ITAL_JUMP_BITS, ITAL_MAX_T, ITAL_REC_HEADER, ItalBatch,
+from ._lib import (ITAL_GENERIC_MAX_CALLS, ITAL_GENERIC_MAX_DIM, ITAL_GENERIC_MAX_REL, ITAL_JUMP_BITS, ITAL_MAX_T, ITAL_REC_HEADER, ItalBatch,
                    ItalGscoreDesc, ItalScoreDesc, check)
 from ._batch import make_batch_buffers
 from .gp import _pad16, _ptr, _stream
@@ -65,10 +65,25 @@ class ITAL(ActiveRetrievalBase):
     def _subset_mode(self):
         return self.change_estimation_subset is None or self.change_estimation_subset > 0
 
+    def _mc_plan(self, nr, fb_mode):
+        """Which enumerations the reference replaces by sampling at a step with nr enumerated variables
+        (ital.py:293-297, :318-337): (rel sampled?, patterns, feedback sampled?, feedback configurations)."""
+        num_rel = nr * self.monte_carlo_num_rel if self.monte_carlo_num_rel is not None else None
+        rel_mc = num_rel is not None and not (2 ** (nr - 1) < num_rel)
+        npat = num_rel if rel_mc else 2 ** nr
+        num_fb = nr * self.monte_carlo_num_fb if self.monte_carlo_num_fb is not None else None
+        if fb_mode == 0:
+            fb_mc, nfb = False, 1
+        elif fb_mode == 1:
+            fb_mc = num_fb is not None and not (2 ** (nr - 1) < num_fb)
+            nfb = num_fb if fb_mc else 2 ** nr
+        else:
+            fb_mc = num_fb is not None and not (3 ** nr < 2 * num_fb)
+            nfb = num_fb if fb_mc else 3 ** nr - 1
+        return rel_mc, npat, fb_mc, nfb
+
     def _unsupported(self, k):
         """Reason why the device scorers cannot run this configuration (None if they can)."""
-        if self.monte_carlo_num_rel is not None or self.monte_carlo_num_fb is not None:
-            return "monte-carlo enumeration (monte_carlo_num_rel / monte_carlo_num_fb)"
         if self.label_estimation not in _LABEL_MODES:
             return "label_estimation=%r" % (self.label_estimation,)
         if self.change_estimation_subset is None:
@@ -77,14 +92,25 @@ class ITAL(ActiveRetrievalBase):
         max_dim = sub + k
         if self.clip_cov and 0 < self.clip_cov < 1 and max_dim > 5:
             return "clip_cov with orthant dimensions above 5 (grouped probabilities, reference ital.py:386-429)"
-        if sub > 0 or not self._perfect_user():
+        if self._needs_generic():
             if max_dim > ITAL_GENERIC_MAX_DIM:
                 return "orthant dimension %d (subset + batch) above %d" % (max_dim, ITAL_GENERIC_MAX_DIM)
             if k > ITAL_GENERIC_MAX_REL:
-                return "batches larger than %d with a noisy user model or an estimation subset" % ITAL_GENERIC_MAX_REL
+                return "batches larger than %d with the general scorer" % ITAL_GENERIC_MAX_REL
+            fb_mode = 0 if self._perfect_user() else (1 if self.label_prob >= 1 else 2)
+            for nr in range(1, k + 1):
+                _, npat, _, nfb = self._mc_plan(nr, fb_mode)
+                if npat * (2 + nfb) > ITAL_GENERIC_MAX_CALLS:
+                    return ("%d orthant probabilities per candidate at greedy step %d: set monte_carlo_num_rel / "
+                            "monte_carlo_num_fb (reference ital.py:293-297)" % (npat * (2 + nfb), nr))
         elif k > ITAL_MAX_T:
-            return "batches larger than %d (needs the monte-carlo enumeration, reference ital.py:293-297)" % ITAL_MAX_T
+            return ("batches larger than %d with full enumeration: set monte_carlo_num_rel (reference ital.py:293-297)"
+                    % ITAL_MAX_T)
         return None
+
+    def _needs_generic(self):
+        return (self._subset_mode() or not self._perfect_user() or self.force_generic
+                or self.monte_carlo_num_rel is not None or self.monte_carlo_num_fb is not None)
 
     def _mark(self, stage=None, t=0, size=0, start=None):
         """HIP event on the launch stream (only when bench.py asked for per-kernel timings)."""
@@ -141,7 +167,7 @@ class ITAL(ActiveRetrievalBase):
         if why is not None:
             raise NotImplementedError("ital_amd device scorer: %s is not implemented" % why)
         candidates = self._candidate_list()
-        if self._subset_mode() or not self._perfect_user() or self.force_generic:
+        if self._needs_generic():
             return self._fetch_generic(k, candidates)
         lib = _lib.lib()
         dev = gp.device
@@ -266,8 +292,7 @@ class ITAL(ActiveRetrievalBase):
             for t in range(1, k + 1):
                 nE = len(E)
                 nr = t
-                npat = 1 << nr
-                nfb = 1 if fb_mode == 0 else ((1 << nr) if fb_mode == 1 else 3 ** nr - 1)
+                rel_mc, npat, fb_mc, nfb = self._mc_plan(nr, fb_mode)
                 dpc = mvn_stream.draws_per_call
                 if subset_mode:
                     draws_out = npat * (dpc(nr) + (1 + nfb) * dpc(nE + 1))
@@ -277,6 +302,10 @@ class ITAL(ActiveRetrievalBase):
                     draws_out = npat * (1 + nfb) * dpc(nr)
                     draws_in = 0
                     in_pos = []
+                mc = None
+                if rel_mc or fb_mc:
+                    mc = self._mc_samples(nr, npat, rel_mc, fb_mc, nfb, fb_mode, cand, picks, pos_of, E, pick_pos, e_mu,
+                                          e_sig, C, subset_mode)
                 dead_pos = [pos_of[q] for q in picks]
                 desc = ItalGscoreDesc()
                 desc.n_cand = n_loc
@@ -304,6 +333,20 @@ class ITAL(ActiveRetrievalBase):
                 desc.draws_out, desc.draws_in = draws_out, draws_in
                 desc.n_in, desc.in_pos, desc.n_dead, desc.dead_pos = len(in_pos), _ptr(t_in), len(dead_pos), _ptr(t_dead)
                 desc.mi, desc.status = _ptr(mi), _ptr(gp.status)
+                total_draws = None
+                if mc is not None:
+                    rel_arr, fb_arr, draws_pp = mc          # per list position (dead positions hold zeros)
+                    lo, hi = pos_offset, pos_offset + max(n_loc, 1)
+                    if rel_arr is not None:
+                        t_rel = torch.from_numpy(np.ascontiguousarray(rel_arr[lo:hi])).to(dev)
+                        desc.mc_rel, desc.rel_samples = npat, _ptr(t_rel)
+                    if fb_arr is not None:
+                        t_fb = torch.from_numpy(np.ascontiguousarray(fb_arr[lo:hi])).to(dev)
+                        desc.mc_fb, desc.fb_samples = nfb, _ptr(t_fb)
+                    off = np.concatenate(([0], np.cumsum(draws_pp)[:-1])).astype(np.int64)
+                    t_off = torch.from_numpy(np.ascontiguousarray(off[lo:hi])).to(dev)
+                    desc.draw_off = _ptr(t_off)
+                    total_draws = int(draws_pp.sum())
                 ev0 = self._mark()
                 check(lib.ital_score_generic(ctypes.byref(desc), st))
                 self._mark("score_generic", t, n_alive, ev0)
@@ -321,7 +364,8 @@ class ITAL(ActiveRetrievalBase):
                 if int(rec[6]) == gp.rank:
                     alive[int(rec[7])] = 0
                 n_in_alive = len(in_pos)
-                stream.advance((n_alive - n_in_alive) * draws_out + n_in_alive * draws_in)
+                stream.advance(total_draws if total_draws is not None else
+                               (n_alive - n_in_alive) * draws_out + n_in_alive * draws_in)
                 n_alive -= 1
                 picks.append(pick)
                 if pick in E:
@@ -346,3 +390,105 @@ class ITAL(ActiveRetrievalBase):
                     E.append(pick)
         gp.check_status()
         return [int(i) for i in picks]
+
+    def _mc_samples(self, nr, npat, rel_mc, fb_mc, nfb, fb_mode, cand, picks, pos_of, E, pick_pos, e_mu, e_sig, C, subset_mode):
+        """Sign patterns / feedback configurations of the Monte-Carlo switches, drawn from numpy's global RNG in the
+        reference's serial order (per live candidate: one multivariate_normal.rvs, ital.py:297; per pattern one
+        np.random.choice, ital.py:323-337).  Returns per list position: patterns [P, npat] uint32 (or None), feedback
+        [P, npat, nfb] uint32 (or None), uniforms of mvndst's stream consumed [P] int64."""
+        gp = self.gp
+        P = len(cand)
+        dead = np.zeros(P, dtype=bool)
+        for q in picks:
+            dead[pos_of[q]] = True
+        live = np.flatnonzero(~dead)
+        nE = len(E)
+        in_e = np.full(P, -1, dtype=np.int64)
+        if subset_mode:
+            for e_pos, e in enumerate(E):
+                if e in pos_of:
+                    in_e[pos_of[e]] = e_pos
+        n_full = np.where(in_e >= 0, nE, nE + 1)               # orthant dimension of the full-dimension calls
+        dpc = mvn_stream.draws_per_call
+        d_full = np.array([dpc(int(v)) for v in range(nE + 2)], dtype=np.int64)[n_full]
+        npre_draws = (dpc(nr) + d_full) if subset_mode else d_full
+        rel_arr = fb_arr = None
+        # ---- mean / covariance of the enumerated variables of every live candidate (ital.py:247-248, :529)
+        if rel_mc:
+            mu_all = np.asarray(self.rel_mean, dtype=np.float64)
+            s2_all = gp._full(gp.s2)
+            pp = list(pick_pos)
+            cpick = np.stack([gp._full(C[b]) for b in pp]) if pp else np.zeros((0, gp.n_total))
+            rows = cand[live]
+            L = len(live)
+            mean = np.empty((L, nr))
+            cov = np.empty((L, nr, nr))
+            mean[:, : nr - 1] = e_mu[pp][None, :] if pp else 0
+            cov[:, : nr - 1, : nr - 1] = e_sig[np.ix_(pp, pp)][None] if pp else 0
+            mean[:, nr - 1] = mu_all[rows]
+            cov[:, nr - 1, nr - 1] = s2_all[rows]
+            if pp:
+                cov[:, : nr - 1, nr - 1] = cpick[:, rows].T
+                cov[:, nr - 1, : nr - 1] = cpick[:, rows].T
+            if subset_mode:
+                for j in np.flatnonzero(in_e[live] >= 0):          # members of the base set: covariances from E itself
+                    idx = pp + [int(in_e[live[j]])]
+                    mean[j] = e_mu[idx]
+                    cov[j] = e_sig[np.ix_(idx, idx)]
+            elif nr == 1:
+                cov[:, 0, 0] = np.maximum(0, cov[:, 0, 0])         # first step: predict_stored(cov_mode='diag') (ital.py:558)
+        weights = (1 << np.arange(nr - 1, -1, -1)).astype(np.uint32)   # variable v at bit nr-1-v
+        if fb_mc:
+            if fb_mode == 1:
+                vals = np.array([1, -1])
+                pr = np.array([1.0 - self.mistake_prob, self.mistake_prob])
+            else:
+                vals = np.array([0, 1, -1])
+                pr = np.array([1.0 - self.label_prob, self.label_prob * (1.0 - self.mistake_prob),
+                               self.label_prob * self.mistake_prob])
+            cdf = pr.cumsum()
+            cdf /= cdf[-1]
+
+        def draw_rel(j0, j1):
+            """multivariate_normal.rvs for live candidates j0..j1-1: numpy's legacy generator = standard normals in
+            order, then x = z . (sqrt(s) v) + mean with (u, s, v) = svd(cov)."""
+            z = np.random.standard_normal((j1 - j0, npat, nr))
+            _, sv, vt = np.linalg.svd(cov[j0:j1])
+            x = z @ (np.sqrt(sv)[:, :, None] * vt) + mean[j0:j1, None, :]
+            return ((x > 0) * weights).sum(axis=2).astype(np.uint32)
+
+        def draw_fb(pats):
+            """np.random.choice(vals, (nfb, nr), p) for every pattern of `pats` [..., npat]: uniforms in order."""
+            u = np.random.random_sample(pats.shape + (nfb, nr))
+            smp = vals[cdf.searchsorted(u, side="right")]
+            relv = ((pats[..., None] >> np.arange(nr - 1, -1, -1)) & 1).astype(bool)     # [..., npat, nr]
+            smp = np.where(relv[..., None, :], smp, -smp)
+            vbit = (1 << np.arange(nr)).astype(np.uint32)
+            nz = ((smp != 0) * vbit).sum(axis=-1).astype(np.uint32)
+            ps = ((smp > 0) * vbit).sum(axis=-1).astype(np.uint32)
+            return nz | (ps << np.uint32(16))
+
+        L = len(live)
+        enum_pats = np.arange(npat, dtype=np.uint32)
+        if rel_mc and not fb_mc:
+            rel_live = draw_rel(0, L)
+        elif fb_mc and not rel_mc:
+            fb_live = draw_fb(np.broadcast_to(enum_pats, (L, npat)))
+        else:
+            rel_live = np.empty((L, npat), dtype=np.uint32)
+            fb_live = np.empty((L, npat, nfb), dtype=np.uint32)
+            for j in range(L):                                       # the two samplers interleave per candidate
+                rel_live[j] = draw_rel(j, j + 1)[0]
+                fb_live[j] = draw_fb(rel_live[j])
+        if rel_mc:
+            rel_arr = np.zeros((P, npat), dtype=np.uint32)
+            rel_arr[live] = rel_live
+        draws = np.zeros(P, dtype=np.int64)
+        if fb_mc:
+            fb_arr = np.zeros((P, npat, nfb), dtype=np.uint32)
+            fb_arr[live] = fb_live
+            calls = ((fb_live & 0xffff) != 0).sum(axis=(1, 2))      # all-zero feedback samples make no call
+            draws[live] = npat * npre_draws[live] + calls * d_full[live]
+        else:
+            draws[live] = npat * (npre_draws[live] + nfb * d_full[live])
+        return rel_arr, fb_arr, draws

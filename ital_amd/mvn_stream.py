@@ -16,8 +16,10 @@ A1 = ((0, 1, 0), (0, 0, 1), ((-183326) % M1, 63308, 0))
 A2 = ((0, 1, 0), (0, 0, 1), ((-539608) % M2, 0, 86098))
 
 PRIMES = (31, 47, 73, 113, 173, 263, 397, 593, 907, 1361)
-# Keast's optimal Korobov generators C(NP, NDIM-1), NP = min(NDIM, 10), for NDIM = 2..12 (Genz, MVNDST)
-KOROBOV_C = {2: 13, 3: 28, 4: 27, 5: 28, 6: 20, 7: 92, 8: 102, 9: 339, 10: 206, 11: 422, 12: 134}
+# Keast's optimal Korobov generators C(NP, NDIM-1), NP = min(NDIM, 10), for NDIM = 2..19 (Genz, MVNDST; pinned against
+# SciPy by tests/golden/mvndst_stream.npz and mvndst_stream_hi.npz through the oracle's restatement)
+KOROBOV_C = {2: 13, 3: 28, 4: 27, 5: 28, 6: 20, 7: 92, 8: 102, 9: 339, 10: 206, 11: 422, 12: 134, 13: 518, 14: 134,
+             15: 134, 16: 518, 17: 652, 18: 382, 19: 206}
 
 
 def _matmul(a, b, m):

@@ -44,6 +44,12 @@ FIXTURES = {
                              kw=dict(top_candidates=40)),
     "iris_ce5": dict(data="iris", rows=120, ls=0.1, k=4, rounds=2, learner="ITAL",
                      kw=dict(change_estimation_subset=5)),
+    "synth80_mcrel": dict(data="synth", rows=80, d=6, ls=None, k=5, rounds=1, learner="ITAL",
+                          kw=dict(monte_carlo_num_rel=2)),
+    "synth60_mcfb": dict(data="synth", rows=60, d=5, ls=None, k=3, rounds=2, learner="ITAL",
+                         kw=dict(label_prob=0.7, mistake_prob=0.1, monte_carlo_num_fb=2)),
+    "synth50_mcboth": dict(data="synth", rows=50, d=5, ls=None, k=4, rounds=1, learner="ITAL",
+                           kw=dict(label_prob=1.0, mistake_prob=0.2, monte_carlo_num_rel=2, monte_carlo_num_fb=1)),
     "usps500_mcmi": dict(data="usps", rows=500, ls=3.0, k=3, rounds=2, learner="MCMI_min",
                          kw=dict(subsample=150)),
     "synth300_mcmi": dict(data="synth", rows=300, d=16, ls=None, k=3, rounds=2, learner="MCMI_min", kw={}),
@@ -264,12 +270,54 @@ def mvndst_stream_fixture():
     print("mvndst_stream ok")
 
 
+def mvndst_stream_hi_fixture():
+    """Fresh-process mvndst calls of dimension 13..20 (the Monte-Carlo pattern mode of ITAL reaches batch sizes above
+    12): pins the Korobov generators and the stream consumption beyond the dimensions of mvndst_stream.npz.
+    Includes singular cases (duplicated variables), which exercise COVSRT's zero-diagonal branch."""
+    _mvn = install_shims()
+    rng = np.random.default_rng(4711)
+    recs = []
+    for it in range(40):
+        n = [13, 14, 16, 15, 17, 18, 19, 20][it % 8]
+        Z = rng.random((n, 5))
+        if it % 9 == 4:
+            Z[3] = Z[1]            # two identical variables -> singular correlation matrix
+        D = ((Z[:, None] - Z[None]) ** 2).sum(-1)
+        S = np.exp(-D / (2 * 0.7 ** 2)) + (0.0 if it % 9 == 4 else 0.05) * np.eye(n)
+        s = np.sqrt(np.diag(S))
+        Cn = S / np.outer(s, s)
+        i_, j_ = np.tril_indices(n, -1)
+        cor = Cn[i_, j_]
+        a = rng.normal(size=n) * 0.6
+        if it % 9 == 4:
+            a[3] = a[1]
+        inf = rng.integers(0, 2, size=n).astype(np.int32)
+        if it % 9 == 4:
+            inf[3] = inf[1]
+        e, v, i = _mvn.mvndst(a, a, inf, cor, maxpts=100 * n, abseps=1e-4, releps=1e-4)
+        recs.append((n, a, inf, cor, e, v, i))
+    nmax = 20
+    out = dict(n=np.array([r[0] for r in recs], dtype=np.int32),
+               lower=np.zeros((len(recs), nmax)), infin=np.zeros((len(recs), nmax), dtype=np.int32),
+               correl=np.zeros((len(recs), nmax * (nmax - 1) // 2)),
+               err=np.array([r[4] for r in recs]), val=np.array([r[5] for r in recs]),
+               inform=np.array([r[6] for r in recs], dtype=np.int32))
+    for j, r in enumerate(recs):
+        out["lower"][j, : r[0]] = r[1]
+        out["infin"][j, : r[0]] = r[2]
+        out["correl"][j, : len(r[3])] = r[3]
+    np.savez_compressed(os.path.join(HERE, "mvndst_stream_hi.npz"), **out)
+    print("mvndst_stream_hi ok", out["val"][:6])
+
+
 if __name__ == "__main__":
     if len(sys.argv) > 1:
         if sys.argv[1] == "mvndst_stream":
             mvndst_stream_fixture()
+        elif sys.argv[1] == "mvndst_stream_hi":
+            mvndst_stream_hi_fixture()
         else:
             run_fixture(sys.argv[1])
     else:
-        for name in ["mvndst_stream"] + list(FIXTURES):
+        for name in ["mvndst_stream", "mvndst_stream_hi"] + list(FIXTURES):
             subprocess.check_call([sys.executable, os.path.abspath(__file__), name])

@@ -114,9 +114,11 @@ def test_golden_fixture(dev, golden_dir, name):
     np.testing.assert_allclose(pv, z["predict_var"], rtol=0, atol=1e-9)
 
 
-@pytest.mark.parametrize("name", ["synth200_noisy", "synth200_motivated", "iris_ce5"])
+@pytest.mark.parametrize("name", ["synth200_noisy", "synth200_motivated", "iris_ce5", "synth80_mcrel", "synth60_mcfb",
+                                  "synth50_mcboth"])
 def test_golden_fixture_general_scorer(dev, golden_dir, name):
-    """Noisy user models (general / motivated) and the change-estimation subset: ital_score_generic."""
+    """Noisy user models (general / motivated), the change-estimation subset and the Monte-Carlo switches
+    (patterns / feedback sampled from numpy's global RNG in the reference's order): ital_score_generic."""
     _run_fixture(dev, golden_dir, name)
 
 
@@ -167,6 +169,11 @@ def test_against_oracle(dev, seed, n, d, k, mode):
     (4, 50, 4, 3, dict(change_estimation_subset=3, label_prob=0.8, mistake_prob=0.1)),
     (5, 64, 7, 3, dict(label_prob=0.6, mistake_prob=0.1, label_estimation="optimistic")),
     (6, 40, 3, 5, dict(change_estimation_subset=6)),
+    (7, 60, 5, 6, dict(monte_carlo_num_rel=1)),
+    (8, 40, 4, 4, dict(label_prob=0.6, mistake_prob=0.2, monte_carlo_num_rel=2, monte_carlo_num_fb=2)),
+    (9, 40, 4, 4, dict(change_estimation_subset=3, monte_carlo_num_rel=1)),
+    (10, 26, 3, 15, dict(monte_carlo_num_rel=1)),          # orthant dimensions up to 15 (lattice prime 1361)
+    (11, 24, 3, 5, dict(change_estimation_subset=12)),     # subset + batch = 17 dimensions
 ])
 def test_general_scorer_against_oracle(dev, seed, n, d, k, kw):
     from oracle import mvn as omvn

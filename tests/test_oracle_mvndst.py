@@ -20,6 +20,21 @@ def test_mvndst_stream_bit_exact(golden_dir):
         assert i == z["inform"][j], (j, n)
 
 
+def test_mvndst_stream_high_dimension(golden_dir):
+    """n = 13..18 incl. singular correlation matrices (duplicated variables): Korobov table beyond NDIM = 11, COVSRT's
+    zero-diagonal branch and MVNDFN's limit intersection."""
+    z = np.load(os.path.join(golden_dir, "mvndst_stream_hi.npz"))
+    mvn.rng_reset()
+    for j in range(len(z["n"])):
+        n = int(z["n"][j])
+        nc = n * (n - 1) // 2
+        e, v, i = mvn.mvndst(z["lower"][j, :n], z["lower"][j, :n], z["infin"][j, :n], z["correl"][j, :nc],
+                             maxpts=100 * n, abseps=1e-4, releps=1e-4)
+        assert v == z["val"][j], (j, n, v, z["val"][j])
+        assert e == z["err"][j], (j, n)
+        assert i == z["inform"][j], (j, n)
+
+
 def test_draw_count_per_call(golden_dir):
     z = np.load(os.path.join(golden_dir, "mvndst_stream.npz"))
     mvn.rng_reset()
