@@ -46,6 +46,65 @@ def qmc_pairs(t, n_cand):
     return n_cand * (2 ** t) * 16 * p * t
 
 
+def hbm_stream_probe(device, rows=1_000_000, d=DIM, m=21, reps=10):
+    """The HBM-bound streaming kernel of the path (one cross-covariance column: reads X and V once, writes one column)
+    at a size that leaves the caches: algorithmic bytes 8*(d + m + 1 + 1) per row, timed with HIP events
+    on the launch stream.  The benchmark workload itself (9298 rows, 19 MB per launch) is launch-latency bound."""
+    import torch
+    from ital_amd import _lib
+    from ital_amd.gp import _ptr, _stream
+    lib = _lib.lib()
+    ldv = (rows + 15) // 16 * 16
+    cap = 32
+    with torch.cuda.device(device):
+        X = torch.rand((rows, d), dtype=torch.float64, device=device)
+        xn = torch.empty(rows, dtype=torch.float64, device=device)
+        V = torch.rand((cap, ldv), dtype=torch.float64, device=device) * 0.01
+        out = torch.empty(ldv, dtype=torch.float64, device=device)
+        W = torch.rand(cap, dtype=torch.float64, device=device) * 0.01
+        sn = torch.empty(1, dtype=torch.float64, device=device)
+        st = _stream()
+        lib.ital_row_norms(_ptr(X), rows, d, _ptr(xn), st)
+        lib.ital_row_norms(_ptr(X), 1, d, _ptr(sn), st)
+
+        def launch():
+            _lib.check(lib.ital_cross_cov_cols(_ptr(X), _ptr(xn), rows, d, _ptr(X), _ptr(sn), 1, _ptr(W), cap, _ptr(V), ldv, m,
+                                               1.0, LENGTH_SCALE, _ptr(out), ldv, st))
+        launch()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            launch()
+        e1.record()
+        torch.cuda.synchronize()
+        sec = e0.elapsed_time(e1) * 1e-3 / reps
+    nbytes = 8.0 * rows * (d + m + 2)
+    ach = nbytes / sec / 1e9
+    return {"bound": "hbm", "kernel": "kcols_kernel (ital_cross_cov_cols, c=1)", "achieved": ach, "peak": HBM_PEAK_GBS,
+            "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": None, "avg_launch_ms": sec * 1e3,
+            "rows": rows, "d": d, "m": m, "algorithmic_bytes_per_launch": nbytes,
+            "note": "same kernel as the greedy steps' cross-covariance column, at 1M rows (2.2 GB per launch)"}
+
+
+def pmc_traffic(kernel_prefix):
+    """HBM bytes per launch of a kernel out of the committed PMC summary (profiles/, collected with tools/profile_gpu.sh
+    in separate passes and corrected as MI355X_MICROARCH.md prescribes), or None."""
+    import csv
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc_summary*.csv")))
+    if not files:
+        return None
+    with open(files[-1], newline="") as f:
+        for row in csv.DictReader(f):
+            if row["kernel"].startswith(kernel_prefix):
+                try:
+                    return float(row["fetch_bytes_corrected_avg"]) + float(row["write_bytes_avg"])
+                except (KeyError, ValueError):
+                    return None
+    return None
+
+
 def cpu_baseline(X, cores):
     """The oracle (CPU restatement of the reference, oracle/) in the reference's parallel mode on a bounded sample."""
     from oracle.ital import OracleITAL
@@ -148,7 +207,7 @@ def main():
             ach = flops / avg_s / 1e12
             roof = {"bound": "fp64-valu", "kernel": "score_qmc_kernel<%d>" % BATCH, "achieved": ach,
                     "peak": FP64_VALU_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach / FP64_VALU_PEAK_TFLOPS,
-                    "traffic": None, "avg_launch_ms": avg_s * 1e3,
+                    "traffic": pmc_traffic("void ital::score_qmc_kernel<%d>" % BATCH), "avg_launch_ms": avg_s * 1e3,
                     "pairs_per_s": qmc_pairs(BATCH, avg_c) / avg_s,
                     "note": "transcendental FP64 chains (Phi, Phi^-1): neither HBM nor MFMA bounds this kernel "
                             "(SURVEY.md 8d S-qmc); HBM-bound streaming kernel reported in roofline_hbm"}
@@ -171,7 +230,8 @@ def main():
                                       "fetch_unlabelled + update per step" % (ROWS_PER_GPU, DIM, BATCH),
                           "n": n_total, "d": DIM, "k": BATCH, "length_scale": LENGTH_SCALE,
                           "parallelism": "candidate rows sharded over %d GPU(s), 1 record all-gather per greedy step" % world},
-               "roofline": roof, "roofline_hbm": roof_hbm,
+               "roofline": roof, "roofline_hbm": hbm_stream_probe(device) if world == 1 else roof_hbm,
+               "roofline_hbm_at_workload_size": roof_hbm,
                "kernel_ms": {"%s_t%d" % k: float(np.mean([d for d, _ in v])) * 1e3 for k, v in sorted(prof.items())}}
         out["cpu_baseline"] = cpu_base
         if cpu_base:
