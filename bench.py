@@ -126,7 +126,10 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--rows", type=int, default=9298, help="rows per GPU (experiments; the default is the metric's workload)")
+    ap.add_argument("--batch", type=int, default=4, help="batch size k (experiments)")
     args = ap.parse_args()
+    globals().update(ROWS_PER_GPU=args.rows, BATCH=args.batch)
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))

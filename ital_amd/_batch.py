@@ -31,6 +31,7 @@ def make_batch_buffers(device, kmax, ldx, cap, ldc, world):
     b["rec"] = torch.zeros(rec_len, dtype=f64, device=device)
     b["rec_all"] = torch.zeros((world, rec_len), dtype=f64, device=device)
     b["jump"] = {}
+    b["jumplane"] = {}
     b["vk"] = {}
     b["batch"] = ItalBatch(kmax, ldx, cap, _ptr(b["bidx"]), _ptr(b["bgpos"]), _ptr(b["bsort"]), _ptr(b["bmu"]),
                            _ptr(b["sig"]), _ptr(b["XB"]), _ptr(b["XBn"]), _ptr(b["VB"]))

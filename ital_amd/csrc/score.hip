@@ -26,8 +26,14 @@
 #ifndef ITAL_QMC_NH
 #define ITAL_QMC_NH 2      // lattice items per lane and round (each with its antithetic partner)
 #endif
+#ifndef ITAL_EXPERIMENT
+#define ITAL_EXPERIMENT 0   // != 0: timing experiments with parts of the integrand removed (results are wrong)
+#endif
+#ifndef ITAL_QMC_COMPACT
+#define ITAL_QMC_COMPACT 1  // wave-level compaction of the Phi^-1 tail branch (0: plain divergent branch per chain)
+#endif
 #ifndef ITAL_QMC_WAVES
-#define ITAL_QMC_WAVES 3   // waves per SIMD the register allocation aims at (measured best: 2 items x 3 waves)
+#define ITAL_QMC_WAVES(T) ((T) <= 4 ? 3 : 2)   // waves per SIMD the register allocation aims at (measured)
 #endif
 
 namespace ital {
@@ -50,6 +56,7 @@ struct ScoreArgs {
     // MVNUNI replay
     int seed[6];            // generator state at the first call of this greedy step
     const long long* jump;  // [48][18]: transition matrices for 2^b calls (of this step's dimension)
+    const long long* jumplane;  // [64][18]: transition matrices for 0..63 calls
     const double* vk;       // [t-1] Korobov generators
     int* status;
 };
@@ -148,14 +155,15 @@ struct Qmc {
     static constexpr int SLAB_RAW = NCOV + 2 * T;            // packed factor, limits, expected values
     static constexpr int SLAB = SLAB_RAW | 1;                 // odd stride: conflict-free per-lane slabs
     static constexpr int NCALLS = 2 << T;                     // 2 * 2^T
-    static constexpr int CHUNK = T <= 5 ? (NCALLS < 64 ? NCALLS : 64) : 16;
+    static constexpr int CHUNK = T <= 7 ? 16 : 8;            // calls prepared per pass (LDS: slab + lattice per call)
+    static constexpr int CHUNK_LOG2 = T <= 7 ? 4 : 3;
     static constexpr int NCOR = T * (T - 1) / 2;
     // wave-shared candidate area (doubles): pivot, correl, mu0', G, sd', then ints perm
     static constexpr int A_PIVOT = 0, A_COR = A_PIVOT + T, A_MU0 = A_COR + NCOR, A_G = A_MU0 + T, A_SD = A_G + T * T,
                          A_SIZE = A_SD + T;
     static constexpr int LAT = 8 * NDIM * 2;                  // per call: permuted generators + shifts, 8 shifts
     static constexpr int TAILQ = 128 * ITAL_QMC_NH;           // compaction queue of the Phi^-1 tail branch (in place)
-    static constexpr int WAVE_DOUBLES = CHUNK * SLAB + A_SIZE + LAT + NDIM + T + TAILQ;  // + running vk + perm
+    static constexpr int WAVE_DOUBLES = CHUNK * (SLAB + LAT) + A_SIZE + T + TAILQ;  // + perm
 };
 
 // Swap rows/columns p < q of the packed lower-triangular matrix, the limits and the limit-type bits (RCSWP).
@@ -219,7 +227,7 @@ __device__ bool covsrt(double* cov, double* lim, double* y, unsigned& infi) {
 }
 
 template <int T>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(ITAL_QMC_WAVES, ITAL_QMC_WAVES))) void score_qmc_kernel(ScoreArgs a) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(ITAL_QMC_WAVES(T), ITAL_QMC_WAVES(T)))) void score_qmc_kernel(ScoreArgs a) {
     using Q = Qmc<T>;
     extern __shared__ double lds_all[];
     const int lane = threadIdx.x & 63;
@@ -230,10 +238,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(ITAL_QMC_WA
     double* W = lds_all + (size_t)wid * Q::WAVE_DOUBLES;
     double* slabs = W;
     double* area = W + Q::CHUNK * Q::SLAB;
-    double* lat = area + Q::A_SIZE;          // [8][NDIM] generators, then [8][NDIM] shifts
-    double* vkrun = lat + Q::LAT;            // running (shuffled) generator vector
-    int* perm = reinterpret_cast<int*>(vkrun + Q::NDIM);  // T ints: natural index held at each sorted slot
-    double* tailq = vkrun + Q::NDIM + T;
+    double* lats = area + Q::A_SIZE;         // per prepared call: [8][NDIM] generators, then [8][NDIM] shifts
+    int* perm = reinterpret_cast<int*>(lats + Q::CHUNK * Q::LAT);  // T ints: natural index held at each sorted slot
+    double* tailq = lats + Q::CHUNK * Q::LAT + T;
 
     const int row = a.cand[p];
     const int64_t gi = a.row_offset + row;
@@ -382,7 +389,30 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(ITAL_QMC_WA
                 if (lower) { if (!(lim[i] + bound < -37.0)) sat = false; }
                 else { if (!(lim[i] - bound > 37.0)) sat = false; }
             }
+            // the call's 8 randomly shifted lattices: this lane jumps to the call's place in MVNUNI's stream (every
+            // call draws 8*(2*NDIM-1) uniforms whether it is evaluated or not) and replays DKSMRC's draws -- per
+            // shift NDIM-1 for the random transposition of the generator vector, then NDIM shifts
+            if (!sat) {
+                MrgState st = rng;
+                mrg_apply(st, a.jumplane + lane * 18);
+                double* L = lats + lane * Q::LAT;
+                for (int j = 0; j < Q::NDIM; j++) L[j] = a.vk[j];
+                for (int sft = 0; sft < 8; sft++) {
+                    double* row = L + sft * Q::NDIM;
+                    if (sft > 0)
+                        for (int j = 0; j < Q::NDIM; j++) row[j] = row[j - Q::NDIM];
+                    for (int j = 1; j <= Q::NDIM - 1; j++) {
+                        const double u = mrg_next(st);
+                        const int jp = (int)(j + u * (Q::NDIM + 1 - j));
+                        const double xt = row[j - 1];
+                        row[j - 1] = row[jp - 1];
+                        row[jp - 1] = xt;
+                    }
+                    for (int j = 0; j < Q::NDIM; j++) L[8 * Q::NDIM + sft * Q::NDIM + j] = mrg_next(st);
+                }
+            }
         }
+        mrg_apply(rng, a.jump + Q::CHUNK_LOG2 * 18);   // the wave's base state moves on by CHUNK calls
         if (!okc) atomicOr(a.status, 2);  // singular conditional covariance: not supported by this kernel
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
@@ -397,22 +427,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(ITAL_QMC_WA
             double value;
             if (sat_c) {
                 value = 1.0;
-                mrg_apply(rng, a.jump);  // skip this call's draws
             } else {
-                // lattice generators for this dimension (floating-point Korobov recurrence, as SciPy's mvndst.f)
-                // and the 8 random shifts; every lane computes the same values
-                for (int j = 0; j < Q::NDIM; j++) vkrun[j] = a.vk[j];
-                for (int sft = 0; sft < 8; sft++) {
-                    for (int j = 1; j <= Q::NDIM - 1; j++) {
-                        const double u = mrg_next(rng);
-                        const int jp = (int)(j + u * (Q::NDIM + 1 - j));
-                        const double xt = vkrun[j - 1];
-                        vkrun[j - 1] = vkrun[jp - 1];
-                        vkrun[jp - 1] = xt;
-                    }
-                    for (int j = 0; j < Q::NDIM; j++) lat[sft * Q::NDIM + j] = vkrun[j];
-                    for (int j = 0; j < Q::NDIM; j++) lat[8 * Q::NDIM + sft * Q::NDIM + j] = mrg_next(rng);
-                }
+                const double* lat = lats + cl * Q::LAT;
                 // per-call constants out of the preparing lane's slab, as wave-uniform (scalar) values
                 const double* cov = slabs + cl * Q::SLAB;
                 double cf[Q::NCOR > 0 ? Q::NCOR : 1], lm[T];
@@ -454,7 +470,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(ITAL_QMC_WA
                             double sc = 0;
 #pragma unroll
                             for (int j = 0; j < i; j++) sc = fma(cf[i * (i - 1) / 2 + j], yy[c][j], sc);
+#if ITAL_EXPERIMENT == 2
+                            const double ph = 0.5 + 1e-3 * (lm[i] - sc);     // timing experiment only: no Phi
+#else
                             const double ph = mvn_phi(lm[i] - sc);
+#endif
                             const double d = lower ? ph : 0.0;
                             const double w = lower ? 1.0 - ph : ph;
                             dead[c] = dead[c] || !(w > 0);
@@ -462,10 +482,21 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(ITAL_QMC_WA
                             if (i < T - 1) pin[c] = fma(xx[c][i], w, d);   // a dead chain (w == 0) just inverts d: finite, discarded
                         }
                         if (i < T - 1) {
+#if ITAL_EXPERIMENT == 1
+#pragma unroll
+                            for (int c = 0; c < NC; c++) yy[c][i] = pin[c] - 0.5;   // timing experiment only: no Phi^-1
+#elif ITAL_EXPERIMENT == 4
+#pragma unroll
+                            for (int c = 0; c < NC; c++) yy[c][i] = phinv_central(pin[c]);   // timing experiment only: no tails
+#elif ITAL_QMC_COMPACT
                             double out[NC];
                             phinv_wave<NC>(pin, out, tailq, lane);
 #pragma unroll
                             for (int c = 0; c < NC; c++) yy[c][i] = out[c];
+#else
+#pragma unroll
+                            for (int c = 0; c < NC; c++) yy[c][i] = mvn_phinv(pin[c]);
+#endif
                         }
                     }
 #pragma unroll
@@ -514,7 +545,7 @@ extern "C" int ital_score_step(const ital_score_desc* d, hipStream_t stream) {
     ScoreArgs a = {};
     a.t = d->t; a.n_cand = d->n_cand; a.cand = d->cand; a.alive = d->alive; a.mu = d->mu; a.s2 = d->s2; a.C = d->C;
     a.ldc = d->ldc; a.row_offset = d->row_offset; a.pos_offset = d->pos_offset; a.b = d->batch; a.noise = d->noise;
-    a.eps = d->eps; a.label_mode = d->label_mode; a.mi = d->mi; a.jump = d->jump; a.vk = d->vk; a.status = d->status;
+    a.eps = d->eps; a.label_mode = d->label_mode; a.mi = d->mi; a.jump = d->jump; a.jumplane = d->jumplane; a.vk = d->vk; a.status = d->status;
     for (int i = 0; i < 6; i++) a.seed[i] = d->seed[i];
     if (d->t == 1) {
         hipLaunchKernelGGL(score_t1_kernel, dim3((unsigned)((d->n_cand + 255) / 256)), dim3(256), 0, stream, a);
@@ -524,7 +555,7 @@ extern "C" int ital_score_step(const ital_score_desc* d, hipStream_t stream) {
         hipLaunchKernelGGL(score_t2_kernel, dim3((unsigned)((d->n_cand * 4 + 255) / 256)), dim3(256), 0, stream, a);
         return ital_check_launch("ital_score_step(t=2)");
     }
-    if (!d->jump || !d->vk) return ital_fail(-22, "ital_score_step: jump table / generators missing for t >= 3");
+    if (!d->jump || !d->jumplane || !d->vk) return ital_fail(-22, "ital_score_step: jump tables / generators missing for t >= 3");
     switch (d->t) {
         case 3: return launch_qmc<3>(a, stream);
         case 4: return launch_qmc<4>(a, stream);

@@ -201,8 +201,9 @@ class ITAL(ActiveRetrievalBase):
                 if t >= 3:
                     if t not in b["jump"]:
                         b["jump"][t] = torch.from_numpy(mvn_stream.jump_table(t, ITAL_JUMP_BITS)).to(dev)
+                        b["jumplane"][t] = torch.from_numpy(mvn_stream.jump_lane_table(t, 64)).to(dev)
                         b["vk"][t] = torch.from_numpy(mvn_stream.korobov_vk(t)).to(dev)
-                    desc.jump, desc.vk = _ptr(b["jump"][t]), _ptr(b["vk"][t])
+                    desc.jump, desc.jumplane, desc.vk = _ptr(b["jump"][t]), _ptr(b["jumplane"][t]), _ptr(b["vk"][t])
                     for j in range(6):
                         desc.seed[j] = stream.state[j]
                 ev0 = self._mark()

@@ -103,6 +103,22 @@ def jump_table(n, bits=48):
     return _jump_cache[key]
 
 
+def jump_lane_table(n, lanes=64):
+    """int64 [lanes][18]: transition matrices of both components for 0..lanes-1 calls of dimension n."""
+    key = ("lane", n, lanes)
+    if key not in _jump_cache:
+        d = draws_per_call(n)
+        j1, j2 = _matpow(A1, d, M1), _matpow(A2, d, M2)
+        c1 = c2 = ((1, 0, 0), (0, 1, 0), (0, 0, 1))
+        out = np.empty((lanes, 18), dtype=np.int64)
+        for l in range(lanes):
+            out[l, :9] = np.array(c1, dtype=np.int64).ravel()
+            out[l, 9:] = np.array(c2, dtype=np.int64).ravel()
+            c1, c2 = _matmul(j1, c1, M1), _matmul(j2, c2, M2)
+        _jump_cache[key] = out
+    return _jump_cache[key]
+
+
 def jump1_table(bits=48):
     """int64 [bits][18]: transition matrices of both components for 2^b uniforms."""
     key = ("single", bits)
