@@ -128,6 +128,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--rows", type=int, default=9298, help="rows per GPU (experiments; the default is the metric's workload)")
     ap.add_argument("--batch", type=int, default=4, help="batch size k (experiments)")
+    ap.add_argument("--label-prob", type=float, default=1.0, help="user model (experiments; != 1 selects the general scorer)")
+    ap.add_argument("--mistake-prob", type=float, default=0.0)
     args = ap.parse_args()
     globals().update(ROWS_PER_GPU=args.rows, BATCH=args.batch)
 
@@ -156,7 +158,8 @@ def main():
     n_total = ROWS_PER_GPU * world
     X = make_data(n_total, DIM, seed=0)
     rel = np.where(X[:, 0] > 0.5, 1.0, -1.0)
-    learner = ITAL(X, length_scale=LENGTH_SCALE, device=device, rank=rank, world=world, group=group)
+    learner = ITAL(X, length_scale=LENGTH_SCALE, label_prob=args.label_prob, mistake_prob=args.mistake_prob, device=device,
+                   rank=rank, world=world, group=group)
 
     def barrier():
         torch.cuda.synchronize()

@@ -20,9 +20,13 @@ namespace ital {
 #define ITAL_FMA_K 0   // measured on MI355X: the scalar-addend form is slower (the scalar unit becomes the co-bottleneck)
 #endif
 __device__ __forceinline__ double fma_k(double acc, double x, double K) {
-#if ITAL_FMA_K
+#if ITAL_FMA_K == 1
     double r;
     asm("v_fma_f64 %0, %1, %2, %3" : "=v"(r) : "v"(acc), "v"(x), "s"(K));
+    return r;
+#elif ITAL_FMA_K == 2   // three-address form with the coefficient in a vector register pair
+    double r;
+    asm("v_fma_f64 %0, %1, %2, %3" : "=v"(r) : "v"(acc), "v"(x), "v"(K));
     return r;
 #else
     return fma(acc, x, K);

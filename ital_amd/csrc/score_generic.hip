@@ -40,7 +40,8 @@ struct GArgs {
     ital_gscore_desc d;
     int chunk;         // calls prepared per pass (<= 64)
     int stride;        // doubles per preparing lane (odd)
-    int slab;          // of which the COVSRT slab (packed factor, limits, expected values); the rest is update scratch
+    int slab;          // of which the COVSRT slab (packed factor, limits, expected values), then the update scratch,
+    int lat;           // then (at this offset) the call's 8 shifted lattices
     int wave_doubles;  // LDS doubles per wave
 };
 
@@ -521,9 +522,7 @@ __global__ __launch_bounds__(128) void score_generic_kernel(GArgs a) {
     double* SigU = muU + GN;
     int* usort = reinterpret_cast<int*>(SigU + GN * GN);
     int* ipos = usort + GN;
-    double* lat = SigU + GN * GN + (GN + GR + 1) / 2;
-    double* vkrun = lat + 16 * (GN - 1);
-    double* tailq = vkrun + GN;
+    double* tailq = SigU + GN * GN + (GN + GR + 1) / 2;
     double* slabs = tailq + 512;
 
     const int row = d.cand[p];
@@ -591,6 +590,45 @@ __global__ __launch_bounds__(128) void score_generic_kernel(GArgs a) {
             if (ci.kind == K_SKIP) { pp.flags = 16; }
             else pp = prepare_call(d, ci, nU, nr, muU, SigU, usort, ipos, clamp_prior, slab, slab + a.slab);
         }
+        // lattices of the calls that are evaluated, generated lane-parallel: every dimension >= 3 call (evaluated or
+        // saturated) takes 8*(2*NDIM-1) uniforms from MVNUNI; lane l jumps ahead by what the calls before it in this chunk
+        // consume, the wave's base state by the chunk's total
+        {
+            const bool draws_any = pp.n >= 3 && !(pp.flags & (1 | 16));
+            const int my_draws = draws_any ? 8 * (2 * (pp.n - 1) - 1) : 0;
+            int incl = my_draws;
+#pragma unroll
+            for (int off = 1; off < 64; off <<= 1) {
+                const int o = __shfl_up(incl, off, 64);
+                if (lane >= off) incl += o;
+            }
+            const int total_draws = __builtin_amdgcn_readlane(incl, 63);
+            if (draws_any && !(pp.flags & 6)) {
+                MrgState st = rng;
+                unsigned before = (unsigned)(incl - my_draws);
+                for (int bit = 0; before != 0; bit++, before >>= 1)
+                    if (before & 1u) mrg_apply(st, d.jump1 + bit * 18);
+                const int ndim = pp.n - 1;
+                double* L = slabs + (size_t)lane * a.stride + a.lat;
+                for (int j = 0; j < ndim; j++) L[j] = d.vk[pp.n * GN + j];
+                for (int sft = 0; sft < 8; sft++) {
+                    double* row = L + sft * ndim;
+                    if (sft > 0)
+                        for (int j = 0; j < ndim; j++) row[j] = row[j - ndim];
+                    for (int j = 1; j <= ndim - 1; j++) {
+                        const double u = mrg_next(st);
+                        const int jp = (int)(j + u * (ndim + 1 - j));
+                        const double xt = row[j - 1];
+                        row[j - 1] = row[jp - 1];
+                        row[jp - 1] = xt;
+                    }
+                    for (int j = 0; j < ndim; j++) L[8 * ndim + sft * ndim + j] = mrg_next(st);
+                }
+            }
+            unsigned adv = (unsigned)total_draws;
+            for (int bit = 0; adv != 0; bit++, adv >>= 1)
+                if (adv & 1u) mrg_apply(rng, d.jump1 + bit * 18);
+        }
         wave_sync();
         // ---------------- Phase C
         for (int cl = 0; cl < a.chunk && chunk0 + cl < total; cl++) {
@@ -604,24 +642,9 @@ __global__ __launch_bounds__(128) void score_generic_kernel(GArgs a) {
                 value = readlane_f64(pp.value, cl);
             } else if (fl_c & 6) {
                 value = (fl_c & 2) ? 1.0 : 0.0;
-                mrg_apply(rng, d.skip + n_c * 18);
             } else {
-                const int ndim = n_c - 1;
-                for (int j = 0; j < ndim; j++) vkrun[j] = d.vk[n_c * GN + j];
-                for (int sft = 0; sft < 8; sft++) {
-                    for (int j = 1; j <= ndim - 1; j++) {
-                        const double u = mrg_next(rng);
-                        const int jp = (int)(j + u * (ndim + 1 - j));
-                        const double xt = vkrun[j - 1];
-                        vkrun[j - 1] = vkrun[jp - 1];
-                        vkrun[jp - 1] = xt;
-                    }
-                    for (int j = 0; j < ndim; j++) lat[sft * ndim + j] = vkrun[j];
-                    for (int j = 0; j < ndim; j++) lat[8 * ndim + sft * ndim + j] = mrg_next(rng);
-                }
-                wave_sync();
-                value = qmc_eval<NMAX, NH>(n_c, slabs + (size_t)cl * a.stride, infi_c, closes_c, lat, lane, tailq);
-                wave_sync();
+                const double* slab_c = slabs + (size_t)cl * a.stride;
+                value = qmc_eval<NMAX, NH>(n_c, slab_c, infi_c, closes_c, slab_c + a.lat, lane, tailq);
             }
             const CallInfo ci = decode_call(d, p, chunk0 + cl, cpp, npre, nr, npat);
             if (ci.kind == K_PRIOR) {
@@ -678,14 +701,15 @@ extern "C" int ital_score_generic(const ital_gscore_desc* d, hipStream_t stream)
     GArgs a;
     a.d = *d;
     const int slab = nUmax * (nUmax + 1) / 2 + 2 * nUmax;
-    int stride = slab + fs_doubles(nr);
+    int stride = slab + fs_doubles(nr) + 16 * (nUmax - 1);
     stride |= 1;
     int chunk = 64;
-    while (chunk > 4 && chunk * stride > 3072) chunk >>= 1;
+    while (chunk > 4 && chunk * stride > 3584) chunk >>= 1;
     a.chunk = chunk;
     a.stride = stride;
     a.slab = slab;
-    const int fixed = GN + GN * GN + (GN + GR + 1) / 2 + 16 * (GN - 1) + GN + 512;
+    a.lat = slab + fs_doubles(nr);
+    const int fixed = GN + GN * GN + (GN + GR + 1) / 2 + 512;
     a.wave_doubles = fixed + chunk * stride;
     const size_t lds = (size_t)2 * a.wave_doubles * sizeof(double);
     if (lds > 160 * 1024) return ital_fail(-12, "ital_score_generic: LDS budget exceeded");
