@@ -1,0 +1,120 @@
+"""Harness counterpart (ital_amd/harness.py): config semantics, datasets, metrics, the simulated-feedback loop.
+CPU: host logic + the loop driven with the ORACLE learners against end-to-end tables of the real reference
+(tests/golden/make_golden_harness.py).  GPU: the same tables through the device learners."""
+import io
+import json
+import os
+
+import numpy as np
+import pytest
+
+from ital_amd import harness
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CONF = os.path.join(HERE, "golden", "conf")
+
+
+def _golden(name):
+    with open(os.path.join(HERE, "golden", name + ".json")) as fh:
+        return json.load(fh)
+
+
+def test_config_casting_imports_overrides():
+    cfg = harness.read_config_file(os.path.join(CONF, "harness_noisy.conf"), "EXPERIMENT", {"rounds": "5"})
+    exp = cfg["EXPERIMENT"]
+    assert exp["batch_size"] == 3 and isinstance(exp["batch_size"], int)
+    assert exp["label_prob"] == 0.7 and isinstance(exp["label_prob"], float)
+    assert exp["avg_class_perf"] is False
+    assert exp["rounds"] == 5                                   # override, cast like every other value
+    assert cfg["METHOD_DEFAULTS"]["length_scale"] == 0.2        # from the imported file
+    assert cfg["METHOD_DEFAULTS"]["noise"] == 1e-5
+    assert cfg["Iris"]["test_size"] == 0.3
+    assert cfg.get("EXPERIMENT", "query_classes") == "0 2"
+
+
+def test_iris_dataset_and_metrics():
+    ds = harness.load_dataset("Iris")
+    assert ds.X_train_norm.shape == (120, 4) and ds.X_test_norm.shape == (30, 4)
+    assert ds.X_train_norm.min() == 0.0 and ds.X_train_norm.max() == 1.0
+    rel, rel_test = ds.class_relevance[1]
+    assert set(np.unique(rel)) == {-1, 1} and len(rel_test) == 30
+    with pytest.raises(ValueError):
+        harness.load_dataset("NoSuchThing")
+    # NDCG: perfect ranking = 1, unknown (0) labels are skipped
+    assert harness.ndcg([1, -1, 1, 0], [0.9, 0.1, 0.8, 0.95]) == 1.0
+    assert 0 < harness.ndcg([1, -1, 1, -1], [0.1, 0.9, 0.8, 0.7]) < 1
+    assert abs(harness.area_under_curve([0.5, 1.0, 1.0, 0.5]) - 0.625) < 1e-15
+
+
+def test_simulated_user_consumes_rng_like_the_reference():
+    labels = np.array([1, -1, 0, 1, -1, 1])
+    np.random.seed(3)
+    fb = harness.simulate_retrieval_feedback(labels, [0, 1, 2, 3, 4, 5], label_prob=0.7, mistake_prob=0.3)
+    np.random.seed(3)
+    want = []
+    for i in range(6):                       # run_experiment.py:37-46 spelled out
+        if np.random.rand() >= 0.7:
+            want.append(0)
+        elif np.random.rand() >= 0.3:
+            want.append(labels[i])
+        elif labels[i] == 0:
+            want.append(np.random.choice([-1, 1]))
+        else:
+            want.append(-1 if labels[i] > 0 else 1)
+    assert fb == want
+
+
+def test_baselines_are_rejected_explicitly(tmp_path):
+    conf = tmp_path / "b.conf"
+    conf.write_text("[EXPERIMENT]\ndataset = Iris\nmethod = EMOC\nbatch_size = 2\n[Iris]\n")
+    with pytest.raises(NotImplementedError, match="baseline"):
+        harness.load_config(str(conf))
+
+
+def _run(name, learners):
+    g = _golden(name)
+    cfg = harness.read_config_file(os.path.join(CONF, name + ".conf"), "EXPERIMENT", {})
+    ds = harness.load_dataset(cfg["EXPERIMENT"]["dataset"], **cfg[cfg["EXPERIMENT"]["dataset"]])
+    assert len(ds.X_train_norm) == g["n_train"]
+    method = cfg["EXPERIMENT"]["method"]
+    kw = dict(cfg["METHOD_DEFAULTS"]) if "METHOD_DEFAULTS" in cfg else {}
+    if method in cfg:
+        kw.update(cfg[method])
+    learner = learners[method](ds.X_train_norm, **kw)
+    trace, buf = [], io.StringIO()
+    harness.run_retrieval_experiment(cfg, ds, learner, out=buf, trace=trace)
+    assert [t[3] for t in trace] == [t["ret"] for t in g["trace"]]          # every fetched batch
+    assert [t[4] for t in trace] == [t["fb"] for t in g["trace"]]           # every simulated feedback
+    assert buf.getvalue() == g["table"]                                       # the printed AP / NDCG table
+    return learner
+
+
+@pytest.mark.parametrize("name", ["harness_noisy", "harness_mcmi"])
+def test_loop_with_oracle_learners_reproduces_reference_tables(name):
+    from oracle import mvn
+    from oracle.ital import OracleITAL, OracleMCMI
+    mvn.rng_reset()
+    _run(name, {"ITAL": OracleITAL, "MCMI": OracleMCMI})
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["harness_iris", "harness_noisy", "harness_mcmi"])
+def test_loop_with_device_learners_reproduces_reference_tables(name):
+    torch = pytest.importorskip("torch")
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from ital_amd import ITAL, MCMI_min, mvn_stream
+    mvn_stream.GLOBAL.reset()
+    _run(name, {"ITAL": ITAL, "MCMI": MCMI_min})
+
+
+@pytest.mark.gpu
+def test_cli_entry_point(capsys):
+    torch = pytest.importorskip("torch")
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from ital_amd import mvn_stream
+    mvn_stream.GLOBAL.reset()
+    harness.main([os.path.join(CONF, "harness_mcmi.conf"), "--rounds=1", "--repetitions=1"])
+    out = capsys.readouterr().out.strip().splitlines()
+    assert out[0] == "Round;Median_AP;Mean_AP;AP_SD;Median_NDCG;Mean_NDCG;NDCG_SD" and len(out) == 3
