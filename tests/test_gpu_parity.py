@@ -233,9 +233,13 @@ def test_api_edge_cases(dev):
     L.reset()
     assert L.rounds == 0 and L.gp.m == 0 and L.rel_mean is None
     with pytest.raises(NotImplementedError):
-        M = ITAL(X, length_scale=0.7, monte_carlo_num_rel=2, device=dev)
+        M = ITAL(X, length_scale=0.7, change_estimation_subset=None, device=dev)   # whole candidate set as subset
         M.update({0: 1})
         M.fetch_unlabelled(2)
+    with pytest.raises(NotImplementedError):
+        M = ITAL(X, length_scale=0.7, clip_cov=0.5, change_estimation_subset=4, device=dev)   # grouped orthants
+        M.update({0: 1})
+        M.fetch_unlabelled(3)
 
 
 def test_queries_constructor(dev):
