@@ -24,7 +24,7 @@ def make_batch_buffers(device, kmax, ldx, cap, ldc, world):
     b["XBn"] = torch.zeros(kmax, dtype=f64, device=device)
     b["VB"] = torch.zeros((kmax, cap), dtype=f64, device=device)
     b["C"] = torch.zeros((kmax, ldc), dtype=f64, device=device)
-    b["ret"] = torch.zeros(kmax, dtype=i64, device=device)
+    b["ret"] = torch.zeros(kmax + 1, dtype=i64, device=device)   # last slot: copy of the status word (one download)
     b["work"] = torch.zeros(2 * 1024, dtype=f64, device=device)
     rec_len = ITAL_REC_HEADER + ldx + cap + kmax
     b["rec_len"] = rec_len

@@ -55,6 +55,7 @@ class ITAL(ActiveRetrievalBase):
         self.keep_scores = False
         self.force_generic = False  # route the perfect-user case through the general scorer too (cross-check in tests)
         self._ce_subset = None
+        self.event_pool = []     # pre-created timing events (bench.py)
         self.profile = None      # list to receive (stage, t, size, start_event, end_event) per launch (bench.py)
         self._fetch_bufs = None
 
@@ -113,10 +114,11 @@ class ITAL(ActiveRetrievalBase):
                 or self.monte_carlo_num_rel is not None or self.monte_carlo_num_fb is not None)
 
     def _mark(self, stage=None, t=0, size=0, start=None):
-        """HIP event on the launch stream (only when bench.py asked for per-kernel timings)."""
+        """HIP event on the launch stream (only when bench.py asked for per-kernel timings).  Events come from
+        `event_pool` when the caller filled it (creating a timing event costs ~0.3 ms on a loaded host)."""
         if self.profile is None:
             return None
-        ev = torch.cuda.Event(enable_timing=True)
+        ev = self.event_pool.pop() if self.event_pool else torch.cuda.Event(enable_timing=True)
         ev.record()
         if start is not None:
             self.profile.append((stage, t, size, start, ev))
@@ -131,9 +133,10 @@ class ITAL(ActiveRetrievalBase):
         self._fetch_bufs = b
         return b
 
-    def _candidate_list(self):
-        """Candidate list in the reference's order (ital.py:98, :111-117)."""
-        candidates = self.get_unseen()
+    def _candidate_list(self, candidates=None):
+        """Candidate list in the reference's order (ital.py:98, :111-117) as an int64 array."""
+        if candidates is None:
+            candidates = self._unseen_array()
         # change-estimation subset: drawn from the unrestricted candidate list on the global numpy RNG (ital.py:103-108)
         if self.change_estimation_subset is not None and self.change_estimation_subset > 0:
             self._ce_subset = sorted(int(i) for i in np.random.choice(
@@ -146,9 +149,8 @@ class ITAL(ActiveRetrievalBase):
                 labelled = len(self.queries) + len(self.relevant_ids) + len(self.irrelevant_ids)
                 top_candidates = min(len(candidates), int(self.top_candidates * labelled))
             if (top_candidates > 0) and (top_candidates < len(candidates)):
-                cand_arr = np.asarray(candidates)
-                top_ind = np.argpartition(self.rel_mean[cand_arr], -top_candidates)[-top_candidates:]
-                candidates = cand_arr[top_ind].tolist()
+                top_ind = np.argpartition(self.rel_mean[candidates], -top_candidates)[-top_candidates:]
+                candidates = candidates[top_ind]
         return candidates
 
     # ------------------------------------------------------------------ the hot path
@@ -160,13 +162,14 @@ class ITAL(ActiveRetrievalBase):
         if gp.m == 0:
             raise RuntimeError("fetch_unlabelled() needs a fitted relevance model: call update() first or pass queries "
                                "(the reference fails with an AttributeError at gp.py:222)")
-        k = min(int(k), len(self.get_unseen()))
+        unseen = self._unseen_array()
+        k = min(int(k), len(unseen))
         if k <= 0:
             return []
         why = self._unsupported(k)
         if why is not None:
             raise NotImplementedError("ital_amd device scorer: %s is not implemented" % why)
-        candidates = self._candidate_list()
+        candidates = self._candidate_list(unseen)
         if self._needs_generic():
             return self._fetch_generic(k, candidates)
         lib = _lib.lib()
@@ -229,14 +232,17 @@ class ITAL(ActiveRetrievalBase):
                 # the reference's serial loop has now consumed this many uniforms of mvndst's stream
                 stream.advance(n_alive * (2 << t) * mvn_stream.draws_per_call(t))
                 n_alive -= 1
-            ret = b["ret"][:k].cpu().tolist()  # the only synchronisation of the round
-            if int(gp.status.item()) & 2:
+            b["ret"][b["kmax"]:].copy_(gp.status)
+            host = b["ret"].cpu().tolist()     # the only synchronisation of the round: the picks and the status word
+            ret, status = host[:k], host[b["kmax"]]
+            if status & 2:
                 # linearly dependent variables inside a batch (duplicate samples): the fast scorer does not carry
                 # MVNDFN's limit-intersection logic; redo the round with the general scorer from the same stream position
                 gp.status.zero_()
                 stream.state, stream.draws = saved_stream
                 return self._fetch_generic(k, candidates)
-        gp.check_status()
+        if status:
+            gp.check_status()
         return [int(i) for i in ret]
 
     # ------------------------------------------------------------------ general scorer (noisy users, estimation subset)
@@ -257,7 +263,7 @@ class ITAL(ActiveRetrievalBase):
             st = _stream()
             b = make_batch_buffers(dev, max(kmax_e, 4), gp.ldx, gp.cap, gp.ldv, gp.world)
             cand = np.asarray(candidates, dtype=np.int64)
-            pos_of = {int(c): i for i, c in enumerate(candidates)}
+            pos_of = {int(c): i for i, c in enumerate(cand.tolist())}
             loc_rows, pos_offset = sharding.shard_candidates(cand, gp.row0, gp.row1)
             n_loc = len(loc_rows)
             cand_d = torch.from_numpy((loc_rows - gp.row0).astype(np.int32)).to(dev) if n_loc else \

@@ -60,13 +60,16 @@ class ActiveRetrievalBase(object):
         return ind[:k] if k is not None else ind
 
     def get_unseen(self):
-        """reference retrieval_base.py:78-87 (ascending sample indices)."""
+        """reference retrieval_base.py:78-87 (ascending sample indices, python ints)."""
+        return self._unseen_array().tolist()
+
+    def _unseen_array(self):
         seen = self.relevant_ids | self.irrelevant_ids | self.unnameable_ids
         if not seen:
-            return list(range(len(self.data)))
+            return np.arange(len(self.data), dtype=np.int64)
         mask = np.ones(len(self.data), dtype=bool)
         mask[np.fromiter(seen, dtype=np.int64, count=len(seen))] = False
-        return np.flatnonzero(mask).tolist()
+        return np.flatnonzero(mask)
 
     def fetch_unlabelled(self, k):
         raise NotImplementedError('fetch_unlabelled() has to be implemented in a derived class.')
