@@ -135,6 +135,14 @@ int ital_select_local(const double* mi, const int32_t* cand, const uint8_t* aliv
 int ital_select_resolve(const double* records, int world, int rec_len, int rank, int mode, int slot,
                         ital_batch batch, uint8_t* alive, int64_t* ret, hipStream_t stream);
 
+/* ital_select_local + ital_select_resolve for ONE rank in a single launch (small problems are launch-latency bound).
+ * Same semantics; `record` is scratch of 8 + ldx + ldw + kmax doubles. */
+int ital_select_fused(const double* mi, const int32_t* cand, uint8_t* alive, int64_t n_cand, int64_t pos_offset,
+                      int64_t row_offset, int rank, int mode, const double* mu, const double* s2, const double* X,
+                      const double* xnorm, int ldx, const double* V, int64_t ldv, int m, int ldw, const double* C,
+                      int64_t ldc, int nprev, int slot, ital_batch batch, double* record, int64_t* ret,
+                      hipStream_t stream);
+
 /* ---- MCMI[min] (pairwise objective) ---------------------------------------------------------------------- */
 
 /* Dense posterior covariance block out[i][j] = k(a_i, b_j) - Va[:,i].Vb[:,j] between na and nb points (FP64 MFMA).

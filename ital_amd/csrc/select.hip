@@ -80,15 +80,10 @@ struct RecordArgs {
     const double* work; double* record;
 };
 
-__global__ __launch_bounds__(256) void select_record_kernel(RecordArgs a) {
+// Packs the record of the winner `v` (valid in thread 0 of the block).
+__device__ void record_body(const RecordArgs& a, Best v) {
     __shared__ int64_t s_pos;
     __shared__ double s_val;
-    Best v = {0.0, -1};
-    for (int i = threadIdx.x; i < a.nparts; i += blockDim.x) {
-        Best c = {a.work[2 * i], (int64_t)a.work[2 * i + 1]};
-        if (better(c, v, a.mode)) v = c;
-    }
-    v = block_best(v, a.mode);
     if (threadIdx.x == 0) { s_pos = v.pos; s_val = v.val; }
     __syncthreads();
     const int64_t gpos = s_pos;
@@ -117,9 +112,18 @@ __global__ __launch_bounds__(256) void select_record_kernel(RecordArgs a) {
         rec[ITAL_REC_HEADER + a.ldx + a.ldw + b] = b < a.nprev ? a.C[(int64_t)b * a.ldc + row] : 0.0;
 }
 
-__global__ __launch_bounds__(256) void select_resolve_kernel(const double* __restrict__ records, int world, int rec_len,
-                                                             int rank, int mode, int slot, ital_batch b,
-                                                             uint8_t* __restrict__ alive, int64_t* __restrict__ ret) {
+__global__ __launch_bounds__(256) void select_record_kernel(RecordArgs a) {
+    Best v = {0.0, -1};
+    for (int i = threadIdx.x; i < a.nparts; i += blockDim.x) {
+        Best c = {a.work[2 * i], (int64_t)a.work[2 * i + 1]};
+        if (better(c, v, a.mode)) v = c;
+    }
+    v = block_best(v, a.mode);
+    record_body(a, v);
+}
+
+__device__ void resolve_body(const double* __restrict__ records, int world, int rec_len, int rank, int mode, int slot,
+                             ital_batch b, uint8_t* __restrict__ alive, int64_t* __restrict__ ret) {
     __shared__ int s_win;
     if (threadIdx.x == 0) {
         Best v = {0.0, -1};
@@ -161,6 +165,30 @@ __global__ __launch_bounds__(256) void select_resolve_kernel(const double* __res
     for (int q = threadIdx.x; q < b.ldw; q += blockDim.x) b.VB[(int64_t)slot * b.ldw + q] = r[ITAL_REC_HEADER + b.ldx + q];
 }
 
+__global__ __launch_bounds__(256) void select_resolve_kernel(const double* __restrict__ records, int world, int rec_len,
+                                                             int rank, int mode, int slot, ital_batch b,
+                                                             uint8_t* __restrict__ alive, int64_t* __restrict__ ret) {
+    resolve_body(records, world, rec_len, rank, mode, slot, b, alive, ret);
+}
+
+// One rank: arg-extreme over all positions, record and resolve in ONE single-workgroup launch (three launches otherwise;
+// the greedy steps of small problems are launch-latency bound).
+__global__ __launch_bounds__(1024) void select_fused_kernel(const double* __restrict__ mi, int64_t n_cand, RecordArgs a,
+                                                            int slot, ital_batch b, uint8_t* alive, int64_t* __restrict__ ret) {
+    Best v = {0.0, -1};
+    for (int64_t p = threadIdx.x; p < n_cand; p += blockDim.x) {
+        if (!alive[p]) continue;
+        Best c = {mi[p], a.pos_offset + p};
+        if (better(c, v, a.mode)) v = c;
+    }
+    v = block_best(v, a.mode);
+    record_body(a, v);
+    __threadfence_block();
+    __syncthreads();
+    const int rec_len = ITAL_REC_HEADER + a.ldx + a.ldw + a.kmax;
+    resolve_body(a.record, 1, rec_len, a.rank, a.mode, slot, b, alive, ret);
+}
+
 }  // namespace ital
 
 using namespace ital;
@@ -182,6 +210,21 @@ extern "C" int ital_select_local(const double* mi, const int32_t* cand, const ui
                     C, ldc, nprev, kmax, work, record};
     hipLaunchKernelGGL(select_record_kernel, dim3(1), dim3(256), 0, stream, a);
     return ital_check_launch("ital_select_local(record)");
+}
+
+extern "C" int ital_select_fused(const double* mi, const int32_t* cand, uint8_t* alive, int64_t n_cand, int64_t pos_offset,
+                                 int64_t row_offset, int rank, int mode, const double* mu, const double* s2, const double* X,
+                                 const double* xnorm, int ldx, const double* V, int64_t ldv, int m, int ldw, const double* C,
+                                 int64_t ldc, int nprev, int slot, ital_batch batch, double* record, int64_t* ret,
+                                 hipStream_t stream) {
+    if (mode != 0 && mode != 1) return ital_fail(-22, "ital_select_fused: mode must be 0 (argmax) or 1 (argmin)");
+    if (m > ldw) return ital_fail(-22, "ital_select_fused: m exceeds ldw");
+    if (slot < 0 || slot >= batch.kmax) return ital_fail(-22, "ital_select_fused: slot outside the batch capacity");
+    if (ldx != batch.ldx || ldw != batch.ldw) return ital_fail(-22, "ital_select_fused: batch layout mismatch");
+    RecordArgs a = {cand, pos_offset, row_offset, rank, mode, 0, mu, s2, X, xnorm, ldx, V, ldv, m, ldw,
+                    C, ldc, nprev, batch.kmax, nullptr, record};
+    hipLaunchKernelGGL(select_fused_kernel, dim3(1), dim3(1024), 0, stream, mi, n_cand, a, slot, batch, alive, ret);
+    return ital_check_launch("ital_select_fused");
 }
 
 extern "C" int ital_select_resolve(const double* records, int world, int rec_len, int rank, int mode, int slot,

@@ -24,6 +24,7 @@ from .gp import _pad16, _ptr, _stream
 from .retrieval_base import ActiveRetrievalBase
 
 _LABEL_MODES = {"mean": 0, "optimistic": 1, "pessimistic": 2}
+_FUSED_SELECT_MAX = 1 << 18   # one rank, up to this many candidates: arg-max + record + resolve in a single launch
 
 
 class ITAL(ActiveRetrievalBase):
@@ -184,7 +185,7 @@ class ITAL(ActiveRetrievalBase):
             cand_d = torch.from_numpy((loc_rows - gp.row0).astype(np.int32)).to(dev) if n_loc else \
                 torch.zeros(1, dtype=torch.int32, device=dev)
             alive = torch.ones(max(n_loc, 1), dtype=torch.uint8, device=dev)
-            mi = torch.zeros(max(n_loc, 1), dtype=torch.float64, device=dev)
+            mi = torch.empty(max(n_loc, 1), dtype=torch.float64, device=dev)   # every live position is written by the scorer
             self.last_scores = []
             stream = mvn_stream.GLOBAL
             saved_stream = (stream.state, stream.draws)
@@ -214,13 +215,19 @@ class ITAL(ActiveRetrievalBase):
                 self._mark("score", t, n_alive, ev0)
                 if self.keep_scores:
                     self.last_scores.append(mi.clone())
-                check(lib.ital_select_local(_ptr(mi), _ptr(cand_d), _ptr(alive), n_loc, pos_offset, gp.row0, gp.rank, 0,
-                                            _ptr(gp.mu), _ptr(gp.s2), _ptr(gp.Xd), _ptr(gp.xnorm), gp.ldx, _ptr(gp.V),
-                                            gp.ldv, gp.m, gp.cap, _ptr(b["C"]), gp.ldv, t - 1, b["kmax"], _ptr(b["work"]),
-                                            _ptr(b["rec"]), st))
-                recs = sharding.gather_records(b["rec"], b["rec_all"], gp.group) if gp.world > 1 else b["rec"]
-                check(lib.ital_select_resolve(_ptr(recs), gp.world, b["rec_len"], gp.rank, 0, t - 1, b["batch"],
-                                              _ptr(alive), _ptr(b["ret"]), st))
+                if gp.world == 1 and n_loc <= _FUSED_SELECT_MAX:
+                    check(lib.ital_select_fused(_ptr(mi), _ptr(cand_d), _ptr(alive), n_loc, pos_offset, gp.row0, gp.rank, 0,
+                                                _ptr(gp.mu), _ptr(gp.s2), _ptr(gp.Xd), _ptr(gp.xnorm), gp.ldx, _ptr(gp.V),
+                                                gp.ldv, gp.m, gp.cap, _ptr(b["C"]), gp.ldv, t - 1, t - 1, b["batch"],
+                                                _ptr(b["rec"]), _ptr(b["ret"]), st))
+                else:
+                    check(lib.ital_select_local(_ptr(mi), _ptr(cand_d), _ptr(alive), n_loc, pos_offset, gp.row0, gp.rank, 0,
+                                                _ptr(gp.mu), _ptr(gp.s2), _ptr(gp.Xd), _ptr(gp.xnorm), gp.ldx, _ptr(gp.V),
+                                                gp.ldv, gp.m, gp.cap, _ptr(b["C"]), gp.ldv, t - 1, b["kmax"],
+                                                _ptr(b["work"]), _ptr(b["rec"]), st))
+                    recs = sharding.gather_records(b["rec"], b["rec_all"], gp.group) if gp.world > 1 else b["rec"]
+                    check(lib.ital_select_resolve(_ptr(recs), gp.world, b["rec_len"], gp.rank, 0, t - 1, b["batch"],
+                                                  _ptr(alive), _ptr(b["ret"]), st))
                 if t < k:
                     slot = t - 1
                     ev0 = self._mark()
