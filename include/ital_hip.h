@@ -111,6 +111,11 @@ typedef struct ital_score_desc {
     const long long* jumplane; /* [64][18] transition matrices for 0..63 calls of dimension t */
     const double* vk;       /* [t-1] Korobov generator vector of this dimension */
     int* status;            /* |= 2: singular conditional covariance met */
+    /* t >= 3, label_mode 0: a candidate's 2*2^t calls may be split over up to `split` waves (rounded down to a power of
+     * two, at least 8 calls per wave) to even out the grid's last scheduling round; partial sums go through `partial`
+     * ([n_cand][split] doubles) and are added in a fixed order.  split <= 1 or partial == NULL: one wave per candidate. */
+    int split;
+    double* partial;
 } ital_score_desc;
 
 /* Scores every live candidate position: mi[p] = MI(batch + candidate p).

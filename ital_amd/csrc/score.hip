@@ -57,6 +57,8 @@ struct ScoreArgs {
     int seed[6];            // generator state at the first call of this greedy step
     const long long* jump;  // [48][18]: transition matrices for 2^b calls (of this step's dimension)
     const long long* jumplane;  // [64][18]: transition matrices for 0..63 calls
+    int nsplit;             // work items per candidate (label_mode 0 only; power of two <= NCALLS / CHUNK)
+    double* part;           // [n_cand][nsplit] partial sums when nsplit > 1
     const double* vk;       // [t-1] Korobov generators
     int* status;
 };
@@ -155,8 +157,9 @@ struct Qmc {
     static constexpr int SLAB_RAW = NCOV + 2 * T;            // packed factor, limits, expected values
     static constexpr int SLAB = SLAB_RAW | 1;                 // odd stride: conflict-free per-lane slabs
     static constexpr int NCALLS = 2 << T;                     // 2 * 2^T
-    static constexpr int CHUNK = T <= 7 ? 16 : 8;            // calls prepared per pass (LDS: slab + lattice per call)
-    static constexpr int CHUNK_LOG2 = T <= 7 ? 4 : 3;
+    static constexpr int CHUNK = 8;                           // calls prepared per pass (LDS: slab + lattice per call)
+    static constexpr int CHUNK_LOG2 = 3;
+    static constexpr int NCHUNK = NCALLS / CHUNK;             // work items a candidate can be split into
     static constexpr int NCOR = T * (T - 1) / 2;
     // wave-shared candidate area (doubles): pivot, correl, mu0', G, sd', then ints perm
     static constexpr int A_PIVOT = 0, A_COR = A_PIVOT + T, A_MU0 = A_COR + NCOR, A_G = A_MU0 + T, A_SD = A_G + T * T,
@@ -232,7 +235,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(ITAL_QMC_WA
     extern __shared__ double lds_all[];
     const int lane = threadIdx.x & 63;
     const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int64_t p = (int64_t)blockIdx.x * 4 + wid;  // list position handled by this wave
+    // work item of this wave: candidate position p, chunks [part * cpi, (part + 1) * cpi) of its calls.  Splitting the
+    // candidates evens out the last scheduling round of the grid (9298 one-candidate waves on 3072 wave slots take as
+    // long as 12288 would); the partial sums are combined in a fixed order by score_combine_kernel.
+    const int64_t item = (int64_t)blockIdx.x * 4 + wid;
+    const int64_t p = item / a.nsplit;
+    const int part = (int)(item - p * a.nsplit);
+    const int chunk_lo = part * (Q::NCALLS / a.nsplit), chunk_hi = chunk_lo + Q::NCALLS / a.nsplit;
     if (p >= a.n_cand) return;
     if (!a.alive[p]) return;
     double* W = lds_all + (size_t)wid * Q::WAVE_DOUBLES;
@@ -334,7 +343,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(ITAL_QMC_WA
         int64_t gpos = a.pos_offset + p;
         int64_t before = gpos;
         for (int i = 0; i < T - 1; i++) before -= (a.b.bgpos[i] < gpos) ? 1 : 0;
-        uint64_t calls_before = (uint64_t)before * (uint64_t)Q::NCALLS;
+        uint64_t calls_before = (uint64_t)before * (uint64_t)Q::NCALLS + (uint64_t)chunk_lo;
         for (int bit = 0; calls_before != 0; bit++, calls_before >>= 1)
             if (calls_before & 1) mrg_apply(rng, a.jump + bit * 18);
     }
@@ -344,7 +353,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(ITAL_QMC_WA
 
     double mi = 0.0;
     double pr_cur = 0.0;
-    for (int chunk = 0; chunk < Q::NCALLS; chunk += Q::CHUNK) {
+    for (int chunk = chunk_lo; chunk < chunk_hi; chunk += Q::CHUNK) {
         // ---------------- Phase B: lane l prepares call chunk + l (limits, pattern bits, COVSRT) in its LDS slab
         bool sat = false, okc = true;
         unsigned infi = 0;
@@ -514,14 +523,27 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(ITAL_QMC_WA
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     }
-    if (lane == 0) a.mi[p] = mi;
+    if (lane == 0) {
+        if (a.nsplit == 1) a.mi[p] = mi;
+        else a.part[p * a.nsplit + part] = mi;
+    }
+}
+
+// mi[p] = sum of the partial sums of position p, in part order (deterministic).
+__global__ __launch_bounds__(256) void score_combine_kernel(const double* __restrict__ part, const uint8_t* __restrict__ alive,
+                                                            int64_t n_cand, int nsplit, double* __restrict__ mi) {
+    const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= n_cand || !alive[p]) return;
+    double s = 0.0;
+    for (int j = 0; j < nsplit; j++) s += part[p * nsplit + j];
+    mi[p] = s;
 }
 
 template <int T>
 static int launch_qmc(const ScoreArgs& a, hipStream_t stream) {
     using Q = Qmc<T>;
     const size_t lds = (size_t)4 * Q::WAVE_DOUBLES * sizeof(double);
-    const int64_t blocks = (a.n_cand + 3) / 4;
+    const int64_t blocks = (a.n_cand * a.nsplit + 3) / 4;
     static bool attr_done = false;
     if (!attr_done && lds > 48 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&score_qmc_kernel<T>),
@@ -530,7 +552,11 @@ static int launch_qmc(const ScoreArgs& a, hipStream_t stream) {
         attr_done = true;
     }
     hipLaunchKernelGGL(score_qmc_kernel<T>, dim3((unsigned)blocks), dim3(256), lds, stream, a);
-    return ital_check_launch("ital_score_step(qmc)");
+    int rc = ital_check_launch("ital_score_step(qmc)");
+    if (rc || a.nsplit == 1) return rc;
+    hipLaunchKernelGGL(score_combine_kernel, dim3((unsigned)((a.n_cand + 255) / 256)), dim3(256), 0, stream, a.part, a.alive,
+                       a.n_cand, a.nsplit, a.mi);
+    return ital_check_launch("ital_score_step(combine)");
 }
 
 }  // namespace ital
@@ -556,6 +582,15 @@ extern "C" int ital_score_step(const ital_score_desc* d, hipStream_t stream) {
         return ital_check_launch("ital_score_step(t=2)");
     }
     if (!d->jump || !d->jumplane || !d->vk) return ital_fail(-22, "ital_score_step: jump tables / generators missing for t >= 3");
+    a.nsplit = 1;
+    a.part = nullptr;
+    if (d->split > 1 && d->partial && d->label_mode == 0) {
+        const int max_split = (2 << d->t) / 8;   // NCALLS / CHUNK
+        int ns = 1;
+        while (ns * 2 <= d->split && ns * 2 <= max_split) ns *= 2;
+        a.nsplit = ns;
+        a.part = d->partial;
+    }
     switch (d->t) {
         case 3: return launch_qmc<3>(a, stream);
         case 4: return launch_qmc<4>(a, stream);

@@ -56,6 +56,7 @@ class ITAL(ActiveRetrievalBase):
         self.keep_scores = False
         self.force_generic = False  # route the perfect-user case through the general scorer too (cross-check in tests)
         self._ce_subset = None
+        self.qmc_split = 8       # waves a candidate's orthant calls may be spread over (t >= 3, label_estimation 'mean')
         self.event_pool = []     # pre-created timing events (bench.py)
         self.profile = None      # list to receive (stage, t, size, start_event, end_event) per launch (bench.py)
         self._fetch_bufs = None
@@ -210,6 +211,10 @@ class ITAL(ActiveRetrievalBase):
                     desc.jump, desc.jumplane, desc.vk = _ptr(b["jump"][t]), _ptr(b["jumplane"][t]), _ptr(b["vk"][t])
                     for j in range(6):
                         desc.seed[j] = stream.state[j]
+                    if self.qmc_split > 1 and n_loc:
+                        if b.get("partial") is None or b["partial"].numel() < n_loc * self.qmc_split:
+                            b["partial"] = torch.empty(n_loc * self.qmc_split, dtype=torch.float64, device=dev)
+                        desc.split, desc.partial = self.qmc_split, _ptr(b["partial"])
                 ev0 = self._mark()
                 check(lib.ital_score_step(ctypes.byref(desc), st))
                 self._mark("score", t, n_alive, ev0)
