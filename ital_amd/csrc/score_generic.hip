@@ -42,6 +42,7 @@ struct GArgs {
     int stride;        // doubles per preparing lane (odd)
     int slab;          // of which the COVSRT slab (packed factor, limits, expected values), then the update scratch,
     int lat;           // then (at this offset) the call's 8 shifted lattices
+    int ldS;           // leading dimension of the joint covariance in LDS (largest |U|)
     int wave_doubles;  // LDS doubles per wave
 };
 
@@ -240,7 +241,7 @@ struct Prep {
 };
 
 // Prepares one call in the lane's slab: cov (packed, n(n+1)/2), lim (n), y (n); scratch fs for the update.
-__device__ Prep prepare_call(const ital_gscore_desc& d, const CallInfo& ci, int nU, int nr, const double* muU,
+__device__ Prep prepare_call(const ital_gscore_desc& d, const CallInfo& ci, int nU, int nr, int ldS, const double* muU,
                              const double* SigU, const int* usort, const int* ipos, bool clamp_prior, double* slab,
                              double* fs) {
     Prep out;
@@ -276,7 +277,7 @@ __device__ Prep prepare_call(const ital_gscore_desc& d, const CallInfo& ci, int 
         FOR_BITS(Fm, ua, qa) {
             FOR_BITS(Fm, ub, qb) {
                 if (qb > qa) break;
-                M[qa * nf + qb] = SigU[ua * GN + ub] + (qa == qb ? s : 0.0);
+                M[qa * nf + qb] = SigU[ua * ldS + ub] + (qa == qb ? s : 0.0);
             }
         }
         for (int i = 0; i < nf; i++)
@@ -333,7 +334,7 @@ __device__ Prep prepare_call(const ital_gscore_desc& d, const CallInfo& ci, int 
             mean = (((Fp >> ua) & 1u) ? 1.0 : -1.0) - s * gv[qa];
         } else {
             mean = muU[ua];
-            FOR_BITS(Fm, uf, q) mean += SigU[ua * GN + uf] * gv[q];
+            FOR_BITS(Fm, uf, q) mean += SigU[ua * ldS + uf] * gv[q];
         }
         lim[a] = mean;
         out.infi |= ((relU >> ua) & 1u) << a;
@@ -343,25 +344,25 @@ __device__ Prep prepare_call(const ital_gscore_desc& d, const CallInfo& ci, int 
             const unsigned qb = __builtin_popcount(Fm & ((1u << ub) - 1u));
             double v;
             if (nf == 0) {
-                v = SigU[ua * GN + ub];
+                v = SigU[ua * ldS + ub];
             } else if (aF && bF) {
                 v = s * ((qa == qb ? 1.0 : 0.0) - s * Wat(qa, qb));
             } else if (bF) {
                 double acc = 0;
-                FOR_BITS(Fm, uf, q) acc += SigU[ua * GN + uf] * Wat(q, qb);
+                FOR_BITS(Fm, uf, q) acc += SigU[ua * ldS + uf] * Wat(q, qb);
                 v = s * acc;
             } else if (aF) {
                 double acc = 0;
-                FOR_BITS(Fm, uf, q) acc += SigU[ub * GN + uf] * Wat(q, qa);
+                FOR_BITS(Fm, uf, q) acc += SigU[ub * ldS + uf] * Wat(q, qa);
                 v = s * acc;
             } else {
                 double acc = 0;
                 FOR_BITS(Fm, uf, q) {
                     double inner = 0;
-                    FOR_BITS(Fm, ug, q2) inner += Wat(q, q2) * SigU[ug * GN + ub];
-                    acc += SigU[ua * GN + uf] * inner;
+                    FOR_BITS(Fm, ug, q2) inner += Wat(q, q2) * SigU[ug * ldS + ub];
+                    acc += SigU[ua * ldS + uf] * inner;
                 }
-                v = SigU[ua * GN + ub] - acc;
+                v = SigU[ua * ldS + ub] - acc;
             }
             cov[pidx(a, b)] = v;
         }
@@ -502,14 +503,86 @@ __device__ double qmc_eval(int n, const double* __restrict__ slab, unsigned infi
     return wave_sum(acc) / (16.0 * prime);
 }
 
+// One MVNDST pass for a call of compile-time dimension T whose rows all close their own group (no linearly dependent
+// variable): the evaluator of the perfect-user fast path (score.hip) -- factor and limits as wave-uniform scalars, fully
+// unrolled, 2 lattice items x antithetic partner per lane.
+template <int T>
+__device__ double qmc_eval_fixed(const double* __restrict__ slab, unsigned infi, const double* __restrict__ lat, int lane,
+                                 double* __restrict__ tailq) {
+    constexpr int NDIM = T - 1, NCOV = T * (T + 1) / 2, NCOR = T * (T - 1) / 2;
+    constexpr int PRIME = P_TAB[(NDIM < 10 ? NDIM : 10) - 1];
+    constexpr int NH = 2, NC = 4;
+    double cf[NCOR > 0 ? NCOR : 1], lm[T];
+#pragma unroll
+    for (int i = 0; i < T; i++) {
+        lm[i] = uniform_f64(slab[NCOV + i]);
+#pragma unroll
+        for (int j = 0; j < i; j++) cf[i * (i - 1) / 2 + j] = uniform_f64(slab[pidx(i, j)]);
+    }
+    double acc = 0.0;
+    for (int base = 0; base < 8 * PRIME; base += 64 * NH) {
+        double xx[NC][NDIM], yy[NC][NDIM], ff[NC];
+        bool dead[NC];
+#pragma unroll
+        for (int h = 0; h < NH; h++) {
+            const int item = base + 64 * h + lane;
+            const bool ok = item < 8 * PRIME;
+            const int it = ok ? item : 0;
+            const int sft = it / PRIME;
+            const int k = it - sft * PRIME + 1;
+#pragma unroll
+            for (int j = 0; j < NDIM; j++) {
+                const double v = k * lat[sft * NDIM + j] + lat[8 * NDIM + sft * NDIM + j];
+                const double fr = v - floor(v);
+                xx[2 * h][j] = fabs(2 * fr - 1);
+                xx[2 * h + 1][j] = 1 - xx[2 * h][j];
+            }
+            ff[2 * h] = ff[2 * h + 1] = 1.0;
+            dead[2 * h] = dead[2 * h + 1] = !ok;
+        }
+#pragma unroll
+        for (int i = 0; i < T; i++) {
+            const bool lower = (infi >> i) & 1u;
+            double pin[NC];
+#pragma unroll
+            for (int c = 0; c < NC; c++) {
+                double sc = 0;
+#pragma unroll
+                for (int j = 0; j < i; j++) sc = fma(cf[i * (i - 1) / 2 + j], yy[c][j], sc);
+                const double ph = mvn_phi(lm[i] - sc);
+                const double dd = lower ? ph : 0.0;
+                const double w = lower ? 1.0 - ph : ph;
+                dead[c] = dead[c] || !(w > 0);
+                ff[c] *= w;
+                if (i < T - 1) pin[c] = fma(xx[c][i], w, dd);
+            }
+            if (i < T - 1) {
+                double outv[NC];
+                phinv_wave<NC>(pin, outv, tailq, lane);
+#pragma unroll
+                for (int c = 0; c < NC; c++) yy[c][i] = outv[c];
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < NC; c++) acc += dead[c] ? 0.0 : ff[c];
+    }
+    return wave_sum(acc) / (16.0 * PRIME);
+}
+
 __device__ __forceinline__ void wave_sync() {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-template <int NMAX, int NH>
-__global__ __launch_bounds__(128) void score_generic_kernel(GArgs a) {
+#ifndef ITAL_EXPERIMENT
+#define ITAL_EXPERIMENT 0
+#endif
+#ifndef ITAL_GEN_WAVES
+#define ITAL_GEN_WAVES 3
+#endif
+template <int NMAX, int NH, int TFIX>
+__global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(ITAL_GEN_WAVES, ITAL_GEN_WAVES))) void score_generic_kernel(GArgs a) {
     extern __shared__ double lds_all[];
     const ital_gscore_desc& d = a.d;
     const int lane = threadIdx.x & 63;
@@ -519,11 +592,12 @@ __global__ __launch_bounds__(128) void score_generic_kernel(GArgs a) {
     if (!d.alive[p]) return;
     double* W = lds_all + (size_t)wid * a.wave_doubles;
     double* muU = W;
-    double* SigU = muU + GN;
-    int* usort = reinterpret_cast<int*>(SigU + GN * GN);
+    const int ldS = a.ldS;                       // = largest |U| of this launch
+    double* SigU = muU + ldS;
+    int* usort = reinterpret_cast<int*>(SigU + ldS * ldS);
     int* ipos = usort + GN;
-    double* tailq = SigU + GN * GN + (GN + GR + 1) / 2;
-    double* slabs = tailq + 512;
+    double* tailq = SigU + ldS * ldS + (GN + GR + 1) / 2;
+    double* slabs = tailq + 256;
 
     const int row = d.cand[p];
     const int64_t gi = d.row_offset + row;
@@ -544,7 +618,7 @@ __global__ __launch_bounds__(128) void score_generic_kernel(GArgs a) {
         if (r < nE && c < nE) v = d.E_sig[r * d.ldE + c];
         else if (r == c) v = d.s2[row];                         // not clamped (gp.py:254)
         else v = d.C[(int64_t)(r < c ? r : c) * d.ldc + row];
-        SigU[r * GN + c] = v;
+        SigU[r * ldS + c] = v;
     }
     for (int e = lane; e < nU; e += 64) muU[e] = e < nE ? d.E_mu[e] : d.mu[row];
     if (lane == 0) {
@@ -588,7 +662,7 @@ __global__ __launch_bounds__(128) void score_generic_kernel(GArgs a) {
             const CallInfo ci = decode_call(d, p, chunk0 + lane, cpp, npre, nr, npat);
             double* slab = slabs + (size_t)lane * a.stride;
             if (ci.kind == K_SKIP) { pp.flags = 16; }
-            else pp = prepare_call(d, ci, nU, nr, muU, SigU, usort, ipos, clamp_prior, slab, slab + a.slab);
+            else pp = prepare_call(d, ci, nU, nr, ldS, muU, SigU, usort, ipos, clamp_prior, slab, slab + a.slab);
         }
         // lattices of the calls that are evaluated, generated lane-parallel: every dimension >= 3 call (evaluated or
         // saturated) takes 8*(2*NDIM-1) uniforms from MVNUNI; lane l jumps ahead by what the calls before it in this chunk
@@ -644,7 +718,14 @@ __global__ __launch_bounds__(128) void score_generic_kernel(GArgs a) {
                 value = (fl_c & 2) ? 1.0 : 0.0;
             } else {
                 const double* slab_c = slabs + (size_t)cl * a.stride;
-                value = qmc_eval<NMAX, NH>(n_c, slab_c, infi_c, closes_c, slab_c + a.lat, lane, tailq);
+#if ITAL_EXPERIMENT == 5
+                value = 0.5;   // timing experiment only: preparation cost without the lattice evaluation
+#else
+                if (TFIX > 0 && n_c == TFIX && closes_c == (1u << (TFIX > 0 ? TFIX : 1)) - 1u)
+                    value = qmc_eval_fixed<(TFIX > 0 ? TFIX : 3)>(slab_c, infi_c, slab_c + a.lat, lane, tailq);
+                else
+                    value = qmc_eval<NMAX, NH>(n_c, slab_c, infi_c, closes_c, slab_c + a.lat, lane, tailq);
+#endif
             }
             const CallInfo ci = decode_call(d, p, chunk0 + cl, cpp, npre, nr, npat);
             if (ci.kind == K_PRIOR) {
@@ -704,32 +785,40 @@ extern "C" int ital_score_generic(const ital_gscore_desc* d, hipStream_t stream)
     int stride = slab + fs_doubles(nr) + 16 * (nUmax - 1);
     stride |= 1;
     int chunk = 64;
-    while (chunk > 4 && chunk * stride > 3584) chunk >>= 1;
+    while (chunk > 4 && chunk * stride > 1536) chunk >>= 1;   // ~14 KB of LDS per wave (measured best: 16 preparing lanes at t = 4)
     a.chunk = chunk;
     a.stride = stride;
     a.slab = slab;
     a.lat = slab + fs_doubles(nr);
-    const int fixed = GN + GN * GN + (GN + GR + 1) / 2 + 512;
+    const int fixed = nUmax + nUmax * nUmax + (GN + GR + 1) / 2 + 256;
+    a.ldS = nUmax;
     a.wave_doubles = fixed + chunk * stride;
     const size_t lds = (size_t)2 * a.wave_doubles * sizeof(double);
     if (lds > 160 * 1024) return ital_fail(-12, "ital_score_generic: LDS budget exceeded");
     const int64_t blocks = (d->n_cand + 1) / 2;
-    static bool attr_done = false;
-    if (!attr_done) {
-        hipError_t e1 = hipFuncSetAttribute(reinterpret_cast<const void*>(&score_generic_kernel<6, 2>),
-                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        hipError_t e2 = hipFuncSetAttribute(reinterpret_cast<const void*>(&score_generic_kernel<12, 1>),
-                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        hipError_t e3 = hipFuncSetAttribute(reinterpret_cast<const void*>(&score_generic_kernel<ITAL_GENERIC_MAX_DIM, 1>),
-                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        if (e1 != hipSuccess || e2 != hipSuccess || e3 != hipSuccess) return ital_fail(-12, "ital_score_generic: cannot raise the dynamic LDS limit");
-        attr_done = true;
+    // plain mode (no subset): every call of dimension >= 3 has dimension n_picks + 1 -> compile-time evaluator
+    const int tfix = (!d->subset_mode && nUmax >= 3 && nUmax <= 6) ? nUmax : 0;
+#define ITAL_GEN_LAUNCH(NMAX_, NH_, TFIX_)                                                                             \
+    do {                                                                                                               \
+        static bool attr_done = false;                                                                                 \
+        if (!attr_done) {                                                                                              \
+            if (hipFuncSetAttribute(reinterpret_cast<const void*>(&score_generic_kernel<NMAX_, NH_, TFIX_>),            \
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)             \
+                return ital_fail(-12, "ital_score_generic: cannot raise the dynamic LDS limit");                        \
+            attr_done = true;                                                                                          \
+        }                                                                                                              \
+        hipLaunchKernelGGL((score_generic_kernel<NMAX_, NH_, TFIX_>), dim3((unsigned)blocks), dim3(128), lds, stream, a); \
+    } while (0)
+    switch (tfix) {
+        case 3: ITAL_GEN_LAUNCH(6, 2, 3); break;
+        case 4: ITAL_GEN_LAUNCH(6, 2, 4); break;
+        case 5: ITAL_GEN_LAUNCH(6, 2, 5); break;
+        case 6: ITAL_GEN_LAUNCH(6, 2, 6); break;
+        default:
+            if (nUmax <= 6) ITAL_GEN_LAUNCH(6, 2, 0);
+            else if (nUmax <= 12) ITAL_GEN_LAUNCH(12, 1, 0);
+            else ITAL_GEN_LAUNCH(ITAL_GENERIC_MAX_DIM, 1, 0);
     }
-    if (nUmax <= 6)
-        hipLaunchKernelGGL((score_generic_kernel<6, 2>), dim3((unsigned)blocks), dim3(128), lds, stream, a);
-    else if (nUmax <= 12)
-        hipLaunchKernelGGL((score_generic_kernel<12, 1>), dim3((unsigned)blocks), dim3(128), lds, stream, a);
-    else
-        hipLaunchKernelGGL((score_generic_kernel<ITAL_GENERIC_MAX_DIM, 1>), dim3((unsigned)blocks), dim3(128), lds, stream, a);
+#undef ITAL_GEN_LAUNCH
     return ital_check_launch("ital_score_generic");
 }
