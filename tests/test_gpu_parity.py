@@ -207,6 +207,60 @@ def test_general_scorer_against_oracle(dev, seed, n, d, k, kw):
     assert mvn_stream.GLOBAL.draws == omvn.rng_draws()
 
 
+def test_batch_of_eight_against_oracle(dev):
+    """Full enumeration up to ITAL_MAX_T = 8 (512 orthant calls of dimension 8 per candidate at the last step)."""
+    from oracle import mvn as omvn
+    from oracle.ital import OracleITAL
+    ITAL, _, mvn_stream = _learners()
+    rng = np.random.default_rng(21)
+    X = rng.random((13, 3))
+    mvn_stream.GLOBAL.reset()
+    omvn.rng_reset()
+    A = ITAL(X, length_scale=0.5, device=dev)
+    A.keep_scores = True
+    B = OracleITAL(X, length_scale=0.5)
+    A.update({0: 1, 1: -1})
+    B.update({0: 1, 1: -1})
+    got = A.fetch_unlabelled(8)
+    want = [int(i) for i in B.fetch_unlabelled(8)]
+    pos = {c: i for i, c in enumerate(B.trace[0][0])}
+    for t, (cand, vals, _) in enumerate(B.trace):
+        mine = A.last_scores[t].cpu().numpy()[[pos[c] for c in cand]]
+        np.testing.assert_allclose(mine, vals, rtol=1e-8, atol=1e-10, err_msg=f"step {t}")
+    assert got == want
+    assert mvn_stream.GLOBAL.draws == omvn.rng_draws()
+
+
+def test_duplicates_of_labelled_rows_nan_semantics(dev):
+    """Exact duplicates of labelled samples: zero predictive variance -> norm.cdf(0, mu, 0) = NaN, and a NaN wins
+    np.argmax (reference ital.py:130, :367).  Duplicates inside a batch exercise the
+    linearly-dependent branch of MVNDST."""
+    from oracle import mvn as omvn
+    from oracle.ital import OracleITAL
+    ITAL, _, mvn_stream = _learners()
+    rng = np.random.default_rng(33)
+    X = rng.random((40, 4))
+    X[7] = X[3]          # 3 gets labelled: 7 is an exact duplicate of a labelled row
+    X[20] = X[11]        # two identical unlabelled rows: both can enter one batch
+    for noise in (1e-6, 1e-2):
+        mvn_stream.GLOBAL.reset()
+        omvn.rng_reset()
+        A = ITAL(X, length_scale=0.8, noise=noise, device=dev)
+        A.keep_scores = True
+        B = OracleITAL(X, length_scale=0.8, noise=noise)
+        A.update({3: 1, 30: -1})
+        B.update({3: 1, 30: -1})
+        got = A.fetch_unlabelled(4)
+        want = [int(i) for i in B.fetch_unlabelled(4)]
+        pos = {c: i for i, c in enumerate(B.trace[0][0])}
+        for t, (cand, vals, _) in enumerate(B.trace):
+            mine = A.last_scores[t].cpu().numpy()[[pos[c] for c in cand]]
+            assert np.array_equal(np.isnan(mine), np.isnan(vals)), f"noise {noise} step {t}"
+            ok = ~np.isnan(vals)
+            np.testing.assert_allclose(mine[ok], vals[ok], rtol=1e-6, atol=1e-9, err_msg=f"noise {noise} step {t}")
+        assert got == want, (noise, got, want)
+
+
 # ------------------------------------------------------------------------------------------ API behaviour / edge cases
 def test_api_edge_cases(dev):
     ITAL, _, mvn_stream = _learners()
