@@ -29,9 +29,11 @@ LENGTH_SCALE = 3.0
 FP64_VALU_PEAK_TFLOPS = 78.6   # MI355X vector FP64 (= half the 157.3 TF FP32 vector rate of MI355X_MICROARCH.md)
 HBM_PEAK_GBS = 8000.0
 PRIMES = (31, 47, 73, 113, 173, 263, 397, 593, 907, 1361)
-# FP64 VALU flops per (Phi, Phi^-1) pair of the lattice integrand, counted from the gfx950 ISA of
-# score_qmc_kernel<4> (DESIGN.md section "Kernels": FMA = 2 flops)
-FLOP_PER_PAIR = 2.0 * 118
+# Algorithmic FP64 work of one (Phi, Phi^-1) pair of the lattice integrand, in flops (FMA = 2): Hart's Phi = 46
+# instruction slots (exp 19, two polynomials 13, division 7, rest 7), AS241's central Phi^-1 = 26, its log/sqrt tail
+# branch 70 for the 15 % of the arguments that need it -- the instruction counts of the isolated chain
+# (tools/ubench/phi_ubench.hip), not of the kernel, so bookkeeping the kernel adds does not count as achieved work.
+FLOP_PER_PAIR = 2.0 * (46 + 26 + 0.15 * 70)
 
 
 def make_data(n, d, seed):
@@ -40,10 +42,11 @@ def make_data(n, d, seed):
 
 
 def qmc_pairs(t, n_cand):
-    """(Phi, Phi^-1) evaluations the scorer of greedy step t performs: 2^t prior orthant probabilities per candidate,
-    16*P lattice evaluations each, t variables (the 2^t post-update probabilities are provably 1 and cost none)."""
+    """(Phi, Phi^-1) pairs the scorer of greedy step t must evaluate: 2^t prior orthant probabilities per candidate,
+    16*P lattice evaluations each, t - 1 pairs per evaluation (the first variable's Phi is the same for every point
+    and the last variable needs no Phi^-1; the 2^t post-update probabilities are provably 1 and cost none)."""
     p = PRIMES[min(t - 1, 10) - 1]
-    return n_cand * (2 ** t) * 16 * p * t
+    return n_cand * (2 ** t) * 16 * p * (t - 1)
 
 
 def hbm_stream_probe(device, rows=1_000_000, d=DIM, m=21, reps=10):
@@ -217,8 +220,10 @@ def main():
                     "peak": FP64_VALU_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach / FP64_VALU_PEAK_TFLOPS,
                     "traffic": pmc_traffic("void ital::score_qmc_kernel<%d>" % BATCH), "avg_launch_ms": avg_s * 1e3,
                     "pairs_per_s": qmc_pairs(BATCH, avg_c) / avg_s,
+                    "flop_per_pair": FLOP_PER_PAIR,
                     "note": "transcendental FP64 chains (Phi, Phi^-1): neither HBM nor MFMA bounds this kernel "
-                            "(SURVEY.md 8d S-qmc); HBM-bound streaming kernel reported in roofline_hbm"}
+                            "(SURVEY.md 8d S-qmc), so the peak is the FP64 vector rate; achieved = algorithmic pairs x "
+                            "flops of the isolated chain / launch time; HBM-bound streaming kernel in roofline_hbm"}
         cc = prof.get(("cross_cov", 1), []) + prof.get(("cross_cov", 2), []) + prof.get(("cross_cov", 3), [])
         roof_hbm = None
         if cc:

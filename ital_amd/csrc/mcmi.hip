@@ -114,10 +114,13 @@ struct McmiArgs {
     double* ce;
 };
 
+// q log(q + eps) + (1 - q) log(1 - q + eps) with q = Phi(z).  Phi through Hart's rational (mvn_phi, ~1e-15 relative, a
+// third of the instructions of the erf/erfc library route behind scipy's ndtr) and the short logarithm of
+// device_math.h; agrees with the reference's value to ~1e-15, far inside the 1e-8 test tolerance.
 __device__ __forceinline__ double entropy_term(double z, double eps) {
-    const double q = ndtr(z);
+    const double q = mvn_phi(z);
     const double p = 1.0 - q;
-    return q * log(q + eps) + p * log(p + eps);
+    return q * log_pos(q + eps) + p * log_pos(p + eps);
 }
 
 // One workgroup per candidate i; the 256 threads stride over the candidates j.  Patterns are enumerated in
