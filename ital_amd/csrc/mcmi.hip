@@ -23,7 +23,10 @@ typedef double d4 __attribute__((ext_vector_type(4)));
 
 // ---------------------------------------------------------------------------------------------------------
 // out[i][j] = var*exp((|a_i|^2 + |b_j|^2 - 2 a_i.b_j)/s) - sum_r Va[r][i] Vb[r][j]
-// Block = 4 waves, tile 64 (i) x 64 (j): wave w owns i-rows 16w..16w+15 and all four 16-wide j tiles.
+// Block = 4 waves stacked along i; every wave owns a (16 MI) x (16 MJ) register tile of MFMA
+// tiles (v_mfma_f64_16x16x4_f64), so one 16-wide k step costs MI + MJ operand loads (32 B per lane each, 128-B row
+// segments) for 4 MI MJ MFMAs; the kernel values replace the dot products in place and the whitened part is subtracted
+// into the same accumulators; operands come straight from L1/L2 (the rows of a tile are shared by the neighbouring workgroups).
 struct CovArgs {
     const double *Xa, *an; int64_t na;
     const double *Xb, *bn; int64_t nb;
@@ -35,72 +38,109 @@ struct CovArgs {
     double* out; int64_t ldo;
 };
 
+#ifndef ITAL_COV_MI
+#define ITAL_COV_MI 2
+#endif
+#ifndef ITAL_COV_MJ
+#define ITAL_COV_MJ 4
+#endif
+constexpr int COV_MI = ITAL_COV_MI, COV_MJ = ITAL_COV_MJ;
+
 __global__ __launch_bounds__(256) void cov_block_kernel(CovArgs a) {
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
     const int col = lane & 15;
     const int kg = lane >> 4;
-    const int64_t i0 = (int64_t)blockIdx.y * 64 + wave * 16;
-    const int64_t j0 = (int64_t)blockIdx.x * 64;
+    const int64_t i0 = (int64_t)blockIdx.y * (64 * COV_MI) + wave * (16 * COV_MI);
+    const int64_t j0 = (int64_t)blockIdx.x * (16 * COV_MJ);
     if (i0 >= a.na) return;
-    const int64_t ia = i0 + col;
-    const bool a_ok = ia < a.na;
-    const double* arow = a.Xa + (a_ok ? ia : 0) * a.ldx;
-    const double* brow[4];
-    bool b_ok[4];
-    int64_t jb[4];
+    const double* arow[COV_MI];
+    const double* brow[COV_MJ];
+    bool a_ok[COV_MI], b_ok[COV_MJ];
+    int64_t ia[COV_MI], jb[COV_MJ];
 #pragma unroll
-    for (int q = 0; q < 4; q++) {
+    for (int p = 0; p < COV_MI; p++) {
+        ia[p] = i0 + 16 * p + col;
+        a_ok[p] = ia[p] < a.na;
+        arow[p] = a.Xa + (a_ok[p] ? ia[p] : 0) * a.ldx;
+    }
+#pragma unroll
+    for (int q = 0; q < COV_MJ; q++) {
         jb[q] = j0 + 16 * q + col;
         b_ok[q] = jb[q] < a.nb;
         brow[q] = a.Xb + (b_ok[q] ? jb[q] : 0) * a.ldx;
     }
-    d4 dot[4], sv[4];
+    d4 acc[COV_MI][COV_MJ];
 #pragma unroll
-    for (int q = 0; q < 4; q++) { dot[q] = (d4){0, 0, 0, 0}; sv[q] = (d4){0, 0, 0, 0}; }
+    for (int p = 0; p < COV_MI; p++)
+#pragma unroll
+        for (int q = 0; q < COV_MJ; q++) acc[p][q] = (d4){0, 0, 0, 0};
     for (int k0 = 0; k0 < a.ldx; k0 += 16) {
         const int kk = k0 + 4 * kg;
-        double2 a01 = {0, 0}, a23 = {0, 0};
-        if (a_ok) {
-            a01 = *reinterpret_cast<const double2*>(arow + kk);
-            a23 = *reinterpret_cast<const double2*>(arow + kk + 2);
+        double2 a01[COV_MI], a23[COV_MI], b01[COV_MJ], b23[COV_MJ];
+#pragma unroll
+        for (int p = 0; p < COV_MI; p++) {
+            a01[p] = a23[p] = (double2){0, 0};
+            if (a_ok[p]) {
+                a01[p] = *reinterpret_cast<const double2*>(arow[p] + kk);
+                a23[p] = *reinterpret_cast<const double2*>(arow[p] + kk + 2);
+            }
         }
 #pragma unroll
-        for (int q = 0; q < 4; q++) {
-            double2 b01 = {0, 0}, b23 = {0, 0};
+        for (int q = 0; q < COV_MJ; q++) {
+            b01[q] = b23[q] = (double2){0, 0};
             if (b_ok[q]) {
-                b01 = *reinterpret_cast<const double2*>(brow[q] + kk);
-                b23 = *reinterpret_cast<const double2*>(brow[q] + kk + 2);
+                b01[q] = *reinterpret_cast<const double2*>(brow[q] + kk);
+                b23[q] = *reinterpret_cast<const double2*>(brow[q] + kk + 2);
             }
-            dot[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(a01.x, b01.x, dot[q], 0, 0, 0);
-            dot[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(a01.y, b01.y, dot[q], 0, 0, 0);
-            dot[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(a23.x, b23.x, dot[q], 0, 0, 0);
-            dot[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(a23.y, b23.y, dot[q], 0, 0, 0);
         }
+#pragma unroll
+        for (int p = 0; p < COV_MI; p++)
+#pragma unroll
+            for (int q = 0; q < COV_MJ; q++) {
+                acc[p][q] = __builtin_amdgcn_mfma_f64_16x16x4f64(a01[p].x, b01[q].x, acc[p][q], 0, 0, 0);
+                acc[p][q] = __builtin_amdgcn_mfma_f64_16x16x4f64(a01[p].y, b01[q].y, acc[p][q], 0, 0, 0);
+                acc[p][q] = __builtin_amdgcn_mfma_f64_16x16x4f64(a23[p].x, b23[q].x, acc[p][q], 0, 0, 0);
+                acc[p][q] = __builtin_amdgcn_mfma_f64_16x16x4f64(a23[p].y, b23[q].y, acc[p][q], 0, 0, 0);
+            }
     }
+    // dot products -> kernel values in place (D layout: reg -> row (i) = kg + 4*reg, column (j) = col) ...
+#pragma unroll
+    for (int q = 0; q < COV_MJ; q++) {
+        const double bnj = b_ok[q] ? a.bn[jb[q]] : 0.0;
+#pragma unroll
+        for (int p = 0; p < COV_MI; p++)
+#pragma unroll
+            for (int reg = 0; reg < 4; reg++) {
+                const int64_t i = i0 + 16 * p + kg + 4 * reg;
+                const double ani = i < a.na ? a.an[i] : 0.0;
+                acc[p][q][reg] = a.var * exp((ani + bnj - 2 * acc[p][q][reg]) / a.s);
+            }
+    }
+    // ... then the whitened part is subtracted by the matrix cores into the same accumulators: acc += (-Va)^T Vb
     for (int r0 = 0; r0 < a.m; r0 += 4) {
         const int r = r0 + kg;
         const bool r_ok = r < a.m;
-        const double av = (r_ok && a_ok) ? a.Va[(int64_t)r * a.ldva + ia] : 0.0;
+        double av[COV_MI], bv[COV_MJ];
 #pragma unroll
-        for (int q = 0; q < 4; q++) {
-            const double bv = (r_ok && b_ok[q]) ? a.Vb[(int64_t)r * a.ldvb + jb[q]] : 0.0;
-            sv[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, sv[q], 0, 0, 0);
-        }
+        for (int p = 0; p < COV_MI; p++) av[p] = (r_ok && a_ok[p]) ? -a.Va[(int64_t)r * a.ldva + ia[p]] : 0.0;
+#pragma unroll
+        for (int q = 0; q < COV_MJ; q++) bv[q] = (r_ok && b_ok[q]) ? a.Vb[(int64_t)r * a.ldvb + jb[q]] : 0.0;
+#pragma unroll
+        for (int p = 0; p < COV_MI; p++)
+#pragma unroll
+            for (int q = 0; q < COV_MJ; q++)
+                acc[p][q] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[p], bv[q], acc[p][q], 0, 0, 0);
     }
-    // D layout: reg -> row (i) = kg + 4*reg, column (j) = col
 #pragma unroll
-    for (int q = 0; q < 4; q++) {
-        const double bnj = b_ok[q] ? a.bn[jb[q]] : 0.0;
+    for (int q = 0; q < COV_MJ; q++)
 #pragma unroll
-        for (int reg = 0; reg < 4; reg++) {
-            const int64_t i = i0 + kg + 4 * reg;
-            if (i < a.na && b_ok[q]) {
-                const double ani = a.an[i];
-                a.out[i * a.ldo + jb[q]] = a.var * exp((ani + bnj - 2 * dot[q][reg]) / a.s) - sv[q][reg];
+        for (int p = 0; p < COV_MI; p++)
+#pragma unroll
+            for (int reg = 0; reg < 4; reg++) {
+                const int64_t i = i0 + 16 * p + kg + 4 * reg;
+                if (i < a.na && b_ok[q]) a.out[i * a.ldo + jb[q]] = acc[p][q][reg];
             }
-        }
-    }
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -268,8 +308,8 @@ extern "C" int ital_cov_block(const double* Xa, const double* an, int64_t na, co
     if (ldx % 16 != 0) return ital_fail(-22, "ital_cov_block: ldx must be a multiple of 16");
     if (m < 0 || (m > 0 && (!Va || !Vb))) return ital_fail(-22, "ital_cov_block: whitened blocks missing");
     if (ldo < nb) return ital_fail(-22, "ital_cov_block: ldo smaller than nb");
-    const int64_t gx = (nb + 63) / 64, gy = (na + 63) / 64;
-    if (gy > 65535) return ital_fail(-22, "ital_cov_block: more than 65535*64 rows per call");
+    const int64_t gx = (nb + 16 * COV_MJ - 1) / (16 * COV_MJ), gy = (na + 64 * COV_MI - 1) / (64 * COV_MI);
+    if (gy > 65535) return ital_fail(-22, "ital_cov_block: too many rows per call");
     CovArgs a = {Xa, an, na, Xb, bn, nb, ldx, Va, ldva, Vb, ldvb, m, var, -2.0 * length_scale * length_scale, out, ldo};
     hipLaunchKernelGGL(cov_block_kernel, dim3((unsigned)gx, (unsigned)gy), dim3(256), 0, stream, a);
     return ital_check_launch("ital_cov_block");
