@@ -31,6 +31,10 @@
 #include "ital_internal.h"
 #include "qmc_common.h"
 
+#ifndef ITAL_GEN_EARLY
+#define ITAL_GEN_EARLY 1   // decide saturated calls from the standardised limits, before COVSRT
+#endif
+
 namespace ital {
 
 constexpr int GN = ITAL_GENERIC_MAX_DIM;  // largest orthant dimension
@@ -324,7 +328,29 @@ __device__ Prep prepare_call(const ital_gscore_desc& d, const CallInfo& ci, int 
     auto upos_of = [&](int a) -> int {
         return ci.kind == K_PRIOR_SUB ? ipos[a] : (ci.kind == K_UPDATED ? usort[a] : a);
     };
-    // posterior mean (into lim) and covariance (packed) of the call's variables, then standardise
+    // posterior mean (into lim) and covariance (packed) of the call's variables, then standardise.  First the means
+    // and the diagonal only: they decide, for most updated calls, that the integrand is identically 0 or 1.
+    auto cov_entry = [&](int ua, bool aF, unsigned qa, int ub, bool bF, unsigned qb) -> double {
+        if (nf == 0) return SigU[ua * ldS + ub];
+        if (aF && bF) return s * ((qa == qb ? 1.0 : 0.0) - s * Wat(qa, qb));
+        if (bF) {
+            double acc = 0;
+            FOR_BITS(Fm, uf, q) acc += SigU[ua * ldS + uf] * Wat(q, qb);
+            return s * acc;
+        }
+        if (aF) {
+            double acc = 0;
+            FOR_BITS(Fm, uf, q) acc += SigU[ub * ldS + uf] * Wat(q, qa);
+            return s * acc;
+        }
+        double acc = 0;
+        FOR_BITS(Fm, uf, q) {
+            double inner = 0;
+            FOR_BITS(Fm, ug, q2) inner += Wat(q, q2) * SigU[ug * ldS + ub];
+            acc += SigU[ua * ldS + uf] * inner;
+        }
+        return SigU[ua * ldS + ub] - acc;
+    };
     for (int a = 0; a < n; a++) {
         const int ua = upos_of(a);
         const bool aF = (Fm >> ua) & 1u;
@@ -338,34 +364,7 @@ __device__ Prep prepare_call(const ital_gscore_desc& d, const CallInfo& ci, int 
         }
         lim[a] = mean;
         out.infi |= ((relU >> ua) & 1u) << a;
-        for (int b = 0; b <= a; b++) {
-            const int ub = upos_of(b);
-            const bool bF = (Fm >> ub) & 1u;
-            const unsigned qb = __builtin_popcount(Fm & ((1u << ub) - 1u));
-            double v;
-            if (nf == 0) {
-                v = SigU[ua * ldS + ub];
-            } else if (aF && bF) {
-                v = s * ((qa == qb ? 1.0 : 0.0) - s * Wat(qa, qb));
-            } else if (bF) {
-                double acc = 0;
-                FOR_BITS(Fm, uf, q) acc += SigU[ua * ldS + uf] * Wat(q, qb);
-                v = s * acc;
-            } else if (aF) {
-                double acc = 0;
-                FOR_BITS(Fm, uf, q) acc += SigU[ub * ldS + uf] * Wat(q, qa);
-                v = s * acc;
-            } else {
-                double acc = 0;
-                FOR_BITS(Fm, uf, q) {
-                    double inner = 0;
-                    FOR_BITS(Fm, ug, q2) inner += Wat(q, q2) * SigU[ug * ldS + ub];
-                    acc += SigU[ua * ldS + uf] * inner;
-                }
-                v = SigU[ua * ldS + ub] - acc;
-            }
-            cov[pidx(a, b)] = v;
-        }
+        cov[pidx(a, a)] = cov_entry(ua, aF, qa, ua, aF, qa);
     }
     if (clamp_prior && ci.kind != K_UPDATED && n == 1) cov[0] = fmax(0.0, cov[0]);  // predict_stored 'diag' (gp.py:229)
     for (int a = 0; a < n; a++) y[a] = sqrt(cov[pidx(a, a)]);  // standard deviations, for now
@@ -375,9 +374,33 @@ __device__ Prep prepare_call(const ital_gscore_desc& d, const CallInfo& ci, int 
         out.flags = 1;
         return out;
     }
+    for (int a = 0; a < n; a++) lim[a] = -lim[a] / y[a];
+    if (ITAL_GEN_EARLY && n >= 3) {
+        // Early decision without COVSRT.  Whatever order COVSRT picks, the conditional limit of variable a is
+        // (lim_a - sum_j c_aj y_j) / c_aa with sum_j c_aj^2 + c_aa^2 = 1 and |y_j| <= 9, i.e. it stays beyond +-37 once
+        // |lim_a| > 37 + 9 sqrt(n - 1): one variable on the empty side makes every lattice point contribute exactly 0,
+        // all variables on the full side make every point contribute exactly 1 -- the values the full path returns.
+        const double thr = 37.0 + 9.0 * sqrt((double)(n - 1));
+        bool all_full = true, any_empty = false;
+        for (int a = 0; a < n; a++) {
+            const bool lower = (out.infi >> a) & 1u;
+            const double l = lower ? lim[a] : -lim[a];     // interval [l, inf) in the variable's own direction
+            if (l > thr) any_empty = true;
+            if (!(l < -thr)) all_full = false;
+        }
+        if (any_empty) { out.flags = 4; return out; }
+        if (all_full) { out.flags = 2; return out; }
+    }
     for (int a = 0; a < n; a++) {
-        lim[a] = -lim[a] / y[a];
-        for (int b = 0; b < a; b++) cov[pidx(a, b)] = cov[pidx(a, b)] / (y[a] * y[b]);
+        const int ua = upos_of(a);
+        const bool aF = (Fm >> ua) & 1u;
+        const unsigned qa = __builtin_popcount(Fm & ((1u << ua) - 1u));
+        for (int b = 0; b < a; b++) {
+            const int ub = upos_of(b);
+            const bool bF = (Fm >> ub) & 1u;
+            const unsigned qb = __builtin_popcount(Fm & ((1u << ub) - 1u));
+            cov[pidx(a, b)] = cov_entry(ua, aF, qa, ub, bF, qb) / (y[a] * y[b]);
+        }
     }
     for (int a = 0; a < n; a++) cov[pidx(a, a)] = 1.0;
     if (n == 2) {
