@@ -11,6 +11,8 @@ GPU, the row shard of X and the Cholesky-whitened block
 so an update appends c rows (rank-c Cholesky append) and N never appears squared.  All arithmetic runs in
 the HIP kernels of libital_hip.so; torch only owns the device buffers and the stream.
 """
+import os
+
 import numpy as np
 import torch
 
@@ -49,6 +51,9 @@ class GaussianProcess(object):
         self._lib = _lib.lib()
         self.device = torch.device(device if device is not None else "cuda:0")
         self.rank, self.world, self.group = int(rank), int(world), group
+        # the exchange steps run whenever there is more than one rank -- or, with ITAL_FORCE_COLLECTIVES=1, also on a
+        # one-rank process group (lets a single-GPU box drive the RCCL code path end to end)
+        self.collective = self.world > 1 or (group is not None and os.environ.get("ITAL_FORCE_COLLECTIVES") == "1")
         data = np.asarray(data, dtype=np.float64)
         if data.ndim != 2:
             raise ValueError("data must be an n-by-d array")
@@ -144,13 +149,13 @@ class GaussianProcess(object):
     def _gather_rows(self, ind):
         """Feature rows of global indices, replicated on every rank (owners contribute, the rest adds zeros)."""
         idx = torch.as_tensor(ind, dtype=torch.int64, device=self.device)
-        if self.world == 1:
+        if not self.collective:
             return self.Xd.index_select(0, idx)       # every row is local: no ownership test, no host synchronisation
         rows = torch.zeros((len(ind), self.ldx), dtype=torch.float64, device=self.device)
         own = (idx >= self.row0) & (idx < self.row1)
         if bool(own.any()):
             rows[own] = self.Xd.index_select(0, idx[own] - self.row0)
-        if self.world > 1:
+        if self.collective:
             sharding.all_reduce_sum(rows, self.group)
         return rows
 
@@ -163,7 +168,7 @@ class GaussianProcess(object):
         if bool(own.any()):
             sel = torch.nonzero(own).squeeze(1)
             out[:, sel] = mat.index_select(1, idx[own] - self.row0)
-        if self.world > 1:
+        if self.collective:
             sharding.all_reduce_sum(out, self.group)
         return out
 
@@ -202,7 +207,7 @@ class GaussianProcess(object):
     def _full(self, t):
         """Local shard vector -> full-length numpy array (all ranks)."""
         loc = t[: self.n]
-        if self.world == 1:
+        if not self.collective:
             return loc.cpu().numpy()
         sizes = [b - a for a, b in (sharding.row_range(self.n_total, self.world, r) for r in range(self.world))]
         return sharding.all_gather_parts(loc, sizes, self.group).cpu().numpy()

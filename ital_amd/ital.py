@@ -220,7 +220,7 @@ class ITAL(ActiveRetrievalBase):
                 self._mark("score", t, n_alive, ev0)
                 if self.keep_scores:
                     self.last_scores.append(mi.clone())
-                if gp.world == 1 and n_loc <= _FUSED_SELECT_MAX:
+                if not gp.collective and n_loc <= _FUSED_SELECT_MAX:
                     check(lib.ital_select_fused(_ptr(mi), _ptr(cand_d), _ptr(alive), n_loc, pos_offset, gp.row0, gp.rank, 0,
                                                 _ptr(gp.mu), _ptr(gp.s2), _ptr(gp.Xd), _ptr(gp.xnorm), gp.ldx, _ptr(gp.V),
                                                 gp.ldv, gp.m, gp.cap, _ptr(b["C"]), gp.ldv, t - 1, t - 1, b["batch"],
@@ -230,7 +230,7 @@ class ITAL(ActiveRetrievalBase):
                                                 _ptr(gp.mu), _ptr(gp.s2), _ptr(gp.Xd), _ptr(gp.xnorm), gp.ldx, _ptr(gp.V),
                                                 gp.ldv, gp.m, gp.cap, _ptr(b["C"]), gp.ldv, t - 1, b["kmax"],
                                                 _ptr(b["work"]), _ptr(b["rec"]), st))
-                    recs = sharding.gather_records(b["rec"], b["rec_all"], gp.group) if gp.world > 1 else b["rec"]
+                    recs = sharding.gather_records(b["rec"], b["rec_all"], gp.group) if gp.collective else b["rec"]
                     check(lib.ital_select_resolve(_ptr(recs), gp.world, b["rec_len"], gp.rank, 0, t - 1, b["batch"],
                                                   _ptr(alive), _ptr(b["ret"]), st))
                 if t < k:
@@ -375,7 +375,7 @@ class ITAL(ActiveRetrievalBase):
                                             _ptr(gp.mu), _ptr(gp.s2), _ptr(gp.Xd), _ptr(gp.xnorm), gp.ldx, _ptr(gp.V),
                                             gp.ldv, gp.m, gp.cap, _ptr(C), gp.ldv, nE, b["kmax"], _ptr(b["work"]),
                                             _ptr(b["rec"]), st))
-                recs = sharding.gather_records(b["rec"], b["rec_all"], gp.group) if gp.world > 1 else b["rec"].unsqueeze(0)
+                recs = sharding.gather_records(b["rec"], b["rec_all"], gp.group) if gp.collective else b["rec"].unsqueeze(0)
                 recs_h = recs.cpu().numpy()          # host synchronisation of this greedy step
                 w = sharding.winner(recs_h, 0)
                 rec = recs_h[w]

@@ -64,7 +64,7 @@ class MCMI_min(ActiveRetrievalBase):
         Xc = torch.zeros((nc, gp.ldx), dtype=torch.float64, device=dev)
         Vc = torch.zeros((max(gp.m, 1), ldc), dtype=torch.float64, device=dev)
         vec = torch.zeros((3, nc), dtype=torch.float64, device=dev)  # |x|^2, mean, variance
-        if gp.world == 1:
+        if not gp.collective:
             Xc.copy_(gp.Xd.index_select(0, loc))
             Vc[: gp.m, :nc] = gp.V[: gp.m].index_select(1, loc)
             vec[0], vec[1], vec[2] = gp.xnorm[loc], gp.mu[loc], gp.s2[loc]
@@ -129,7 +129,7 @@ class MCMI_min(ActiveRetrievalBase):
                 self._mark("mcmi_score", t, nc - (t - 1), ev0)
                 if self.keep_scores:
                     self.last_scores.append(ce.clone())
-                if gp.world == 1 and n_i <= (1 << 18):
+                if not gp.collective and n_i <= (1 << 18):
                     check(lib.ital_select_fused(_ptr(ce), _ptr(pos_d), _ptr(alive), n_i, i0, 0, gp.rank, 1, _ptr(muc),
                                                 _ptr(s2c), _ptr(Xc), _ptr(xnc), gp.ldx, _ptr(Vc), ldc, gp.m, gp.cap,
                                                 _ptr(b["C"]), ldc, t - 1, t - 1, b["batch"], _ptr(b["rec"]), _ptr(b["ret"]), st))
@@ -137,7 +137,7 @@ class MCMI_min(ActiveRetrievalBase):
                     check(lib.ital_select_local(_ptr(ce), _ptr(pos_d), _ptr(alive), n_i, i0, 0, gp.rank, 1, _ptr(muc),
                                                 _ptr(s2c), _ptr(Xc), _ptr(xnc), gp.ldx, _ptr(Vc), ldc, gp.m, gp.cap,
                                                 _ptr(b["C"]), ldc, t - 1, b["kmax"], _ptr(b["work"]), _ptr(b["rec"]), st))
-                    recs = sharding.gather_records(b["rec"], b["rec_all"], gp.group) if gp.world > 1 else b["rec"]
+                    recs = sharding.gather_records(b["rec"], b["rec_all"], gp.group) if gp.collective else b["rec"]
                     check(lib.ital_select_resolve(_ptr(recs), gp.world, b["rec_len"], gp.rank, 1, t - 1, b["batch"],
                                                   _ptr(alive), _ptr(b["ret"]), st))
                 if t < k:

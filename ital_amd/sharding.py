@@ -37,7 +37,7 @@ def gather_records(record, out, group=None):
     `record` [R], `out` [world, R] (same dtype/device)."""
     import torch.distributed as dist
     world = out.shape[0]
-    if world == 1:
+    if world == 1 and (group is None or not dist.is_initialized()):
         out[0].copy_(record)
         return out
     if _host_staged(record, group):

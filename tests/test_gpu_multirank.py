@@ -68,3 +68,48 @@ def test_two_ranks_match_golden(name):
     np.testing.assert_allclose(r0[1], z["final_rel_mean"], rtol=0, atol=1e-9)
     np.testing.assert_array_equal(r0[1], r1[1])
     assert r0[2][0] == 0 and r0[2][1] == r1[2][0] and r1[2][1] == len(z["X"])   # each rank held half of the rows
+
+
+def _nccl_worker(rank, world, port, name, out):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    os.environ["ITAL_FORCE_COLLECTIVES"] = "1"
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", 0))
+    try:
+        from ital_amd import ITAL, MCMI_min, mvn_stream
+        z = np.load(os.path.join(HERE, "golden", name + ".npz"))
+        spec = make_golden.FIXTURES[name]
+        cls = ITAL if spec["learner"] == "ITAL" else MCMI_min
+        np.random.seed(0)
+        mvn_stream.GLOBAL.reset()
+        L = cls(z["X"], length_scale=float(z["length_scale"]), device="cuda:0", rank=rank, world=world,
+                group=dist.group.WORLD, **spec["kw"])
+        assert L.gp.collective
+        L.update({int(z["query"]): 1})
+        rel = z["rel"]
+        picks = []
+        for r in range(int(z["rounds"])):
+            ret = L.fetch_unlabelled(int(z["k"]))
+            picks.append(ret)
+            L.update({int(i): float(rel[i]) for i in ret})
+        out[rank] = (picks, np.asarray(L.rel_mean).copy())
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("name", ["usps500", "synth300_mcmi"])
+def test_rccl_code_path_on_a_one_rank_group(name):
+    """The collectives of the sharded path (record all-gather, row all-reduce, vector all-gather) through RCCL itself --
+    on a one-rank "nccl" process group, which is all a one-GPU box can host."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    z = np.load(os.path.join(HERE, "golden", name + ".npz"))
+    port = _free_port()
+    with mp.Manager() as mgr:
+        out = mgr.dict()
+        mp.spawn(_nccl_worker, args=(1, port, name, out), nprocs=1, join=True)
+        r0 = out[0]
+    assert r0[0] == [z[f"r{r}_ret"].tolist() for r in range(int(z["rounds"]))]
+    np.testing.assert_allclose(r0[1], z["final_rel_mean"], rtol=0, atol=1e-9)
