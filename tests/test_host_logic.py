@@ -80,3 +80,70 @@ def test_struct_layout_matches_header():
     assert ctypes.sizeof(_lib.ItalBatch) == 16 + 8 * 8
     d = _lib.ItalScoreDesc
     assert d.batch.offset % 8 == 0 and d.seed.size == 24
+
+
+def _bare_ital(**kw):
+    """An ITAL instance without a device (only the option logic is exercised)."""
+    from ital_amd.ital import ITAL
+    L = object.__new__(ITAL)
+    opts = dict(label_prob=1.0, mistake_prob=0.0, top_candidates=None, change_estimation_subset=0, clip_cov=0,
+                label_estimation="mean", monte_carlo_num_rel=None, monte_carlo_num_fb=None, force_generic=False)
+    opts.update(kw)
+    for k, v in opts.items():
+        setattr(L, k, v)
+    return L
+
+
+def test_monte_carlo_plan_follows_the_reference_thresholds():
+    """rel_iter samples once 2^(n-1) >= n*mc (ital.py:293-295); fb_iter once 2^(n-1) >= n*mc for the motivated user
+    (:318-320) and 3^n >= 2*n*mc for the general one (:331-333)."""
+    L = _bare_ital(monte_carlo_num_rel=2, monte_carlo_num_fb=2)
+    assert [L._mc_plan(n, 0)[:2] for n in (1, 3, 4, 5)] == [(False, 2), (False, 8), (True, 8), (True, 10)]
+    assert [L._mc_plan(n, 1)[2:] for n in (1, 3, 4)] == [(False, 2), (False, 8), (True, 8)]
+    assert [L._mc_plan(n, 2)[2:] for n in (1, 2, 3)] == [(False, 2), (True, 4), (True, 6)]
+    assert _bare_ital()._mc_plan(5, 2) == (False, 32, False, 242)
+
+
+def test_unsupported_option_combinations_are_named():
+    assert _bare_ital()._unsupported(8) is None
+    assert "monte_carlo_num_rel" in _bare_ital()._unsupported(9)
+    assert _bare_ital(monte_carlo_num_rel=1)._unsupported(16) is None
+    assert "larger than 16" in _bare_ital(monte_carlo_num_rel=1)._unsupported(17)
+    assert _bare_ital(change_estimation_subset=5)._unsupported(4) is None
+    assert "dimension" in _bare_ital(change_estimation_subset=18)._unsupported(4)
+    assert "change_estimation_subset=None" in _bare_ital(change_estimation_subset=None)._unsupported(2)
+    assert _bare_ital(clip_cov=0.5)._unsupported(4) is None               # cannot trigger below 6 dimensions
+    assert "clip_cov" in _bare_ital(clip_cov=0.5)._unsupported(6)
+    assert "label_estimation" in _bare_ital(label_estimation="median")._unsupported(2)
+    assert "orthant probabilities per candidate" in _bare_ital(label_prob=0.5)._unsupported(12)
+    assert _bare_ital(label_prob=0.5, monte_carlo_num_rel=1, monte_carlo_num_fb=1)._unsupported(12) is None
+
+
+def test_stream_tables_are_consistent():
+    """jump tables: 2^b calls, 0..63 calls and single draws describe the same generator."""
+    from ital_amd import mvn_stream as ms
+    n = 5
+    d = ms.draws_per_call(n)
+    s = ms.MvnStream()
+    base = s.state
+    jl = ms.jump_lane_table(n, 64)
+    j2 = ms.jump_table(n, 8)
+    j1 = ms.jump1_table(16)
+
+    def apply(row, st):
+        a = [sum(int(row[3 * i + k]) * st[k] for k in range(3)) % ms.M1 for i in range(3)]
+        b = [sum(int(row[9 + 3 * i + k]) * st[3 + k] for k in range(3)) % ms.M2 for i in range(3)]
+        return tuple(a + b)
+
+    assert apply(jl[0], base) == base
+    assert apply(jl[5], base) == s.peek(5 * d)
+    assert apply(j2[3], base) == s.peek(8 * d)
+    st = base
+    for bit in range(16):
+        if (37 >> bit) & 1:
+            st = apply(j1[bit], st)
+    assert st == s.peek(37)
+    sk = ms.skip_table(6)
+    assert apply(sk[2], base) == base and apply(sk[6], base) == s.peek(ms.draws_per_call(6))
+    vk = ms.vk_table(6)
+    assert np.all(vk[:3] == 0) and np.array_equal(vk[5, :4], ms.korobov_vk(5))
