@@ -402,8 +402,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(ITAL_QMC_WA
             // call draws 8*(2*NDIM-1) uniforms whether it is evaluated or not) and replays DKSMRC's draws -- per
             // shift NDIM-1 for the random transposition of the generator vector, then NDIM shifts
             if (!sat) {
-                MrgState st = rng;
-                mrg_apply(st, a.jumplane + lane * 18);
+                MrgState sti = rng;
+                mrg_apply(sti, a.jumplane + lane * 18);
+                MrgStateF st = mrg_to_f(sti);
                 double* L = lats + lane * Q::LAT;
                 for (int j = 0; j < Q::NDIM; j++) L[j] = a.vk[j];
                 for (int sft = 0; sft < 8; sft++) {
@@ -411,13 +412,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(ITAL_QMC_WA
                     if (sft > 0)
                         for (int j = 0; j < Q::NDIM; j++) row[j] = row[j - Q::NDIM];
                     for (int j = 1; j <= Q::NDIM - 1; j++) {
-                        const double u = mrg_next(st);
+                        const double u = mrg_next_f(st);
                         const int jp = (int)(j + u * (Q::NDIM + 1 - j));
                         const double xt = row[j - 1];
                         row[j - 1] = row[jp - 1];
                         row[jp - 1] = xt;
                     }
-                    for (int j = 0; j < Q::NDIM; j++) L[8 * Q::NDIM + sft * Q::NDIM + j] = mrg_next(st);
+                    for (int j = 0; j < Q::NDIM; j++) L[8 * Q::NDIM + sft * Q::NDIM + j] = mrg_next_f(st);
                 }
             }
         }

@@ -701,10 +701,11 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(ITAL_GEN_WA
             }
             const int total_draws = __builtin_amdgcn_readlane(incl, 63);
             if (draws_any && !(pp.flags & 6)) {
-                MrgState st = rng;
+                MrgState sti = rng;
                 unsigned before = (unsigned)(incl - my_draws);
                 for (int bit = 0; before != 0; bit++, before >>= 1)
-                    if (before & 1u) mrg_apply(st, d.jump1 + bit * 18);
+                    if (before & 1u) mrg_apply(sti, d.jump1 + bit * 18);
+                MrgStateF st = mrg_to_f(sti);
                 const int ndim = pp.n - 1;
                 double* L = slabs + (size_t)lane * a.stride + a.lat;
                 for (int j = 0; j < ndim; j++) L[j] = d.vk[pp.n * GN + j];
@@ -713,13 +714,13 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(ITAL_GEN_WA
                     if (sft > 0)
                         for (int j = 0; j < ndim; j++) row[j] = row[j - ndim];
                     for (int j = 1; j <= ndim - 1; j++) {
-                        const double u = mrg_next(st);
+                        const double u = mrg_next_f(st);
                         const int jp = (int)(j + u * (ndim + 1 - j));
                         const double xt = row[j - 1];
                         row[j - 1] = row[jp - 1];
                         row[jp - 1] = xt;
                     }
-                    for (int j = 0; j < ndim; j++) L[8 * ndim + sft * ndim + j] = mrg_next(st);
+                    for (int j = 0; j < ndim; j++) L[8 * ndim + sft * ndim + j] = mrg_next_f(st);
                 }
             }
             unsigned adv = (unsigned)total_draws;
