@@ -116,6 +116,7 @@ typedef struct ital_score_desc {
      * ([n_cand][split] doubles) and are added in a fixed order.  split <= 1 or partial == NULL: one wave per candidate. */
     int split;
     double* partial;
+    int* seeds;             /* t >= 3: scratch of n_cand * max(split, 1) * 6 ints (generator state per work item) */
 } ital_score_desc;
 
 /* Scores every live candidate position: mi[p] = MI(batch + candidate p).

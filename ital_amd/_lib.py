@@ -29,7 +29,7 @@ class ItalScoreDesc(ctypes.Structure):
                 ("s2", c_void_p), ("C", c_void_p), ("ldc", c_int64), ("row_offset", c_int64),
                 ("pos_offset", c_int64), ("batch", ItalBatch), ("noise", c_double), ("eps", c_double),
                 ("label_mode", c_int), ("mi", c_void_p), ("seed", c_int * 6), ("jump", c_void_p), ("jumplane", c_void_p),
-                ("vk", c_void_p), ("status", c_void_p), ("split", c_int), ("partial", c_void_p)]
+                ("vk", c_void_p), ("status", c_void_p), ("split", c_int), ("partial", c_void_p), ("seeds", c_void_p)]
 
 
 class ItalGscoreDesc(ctypes.Structure):

@@ -57,6 +57,7 @@ struct ScoreArgs {
     int seed[6];            // generator state at the first call of this greedy step
     const long long* jump;  // [48][18]: transition matrices for 2^b calls (of this step's dimension)
     const long long* jumplane;  // [64][18]: transition matrices for 0..63 calls
+    int* seeds;             // [n_cand * nsplit][6] generator state at the first call of every work item
     int nsplit;             // work items per candidate (label_mode 0 only; power of two <= NCALLS / CHUNK)
     double* part;           // [n_cand][nsplit] partial sums when nsplit > 1
     const double* vk;       // [t-1] Korobov generators
@@ -229,6 +230,26 @@ __device__ bool covsrt(double* cov, double* lim, double* y, unsigned& infi) {
     return ok;
 }
 
+// MVNUNI state at the first call of every work item (candidate position p, part): the step's seed advanced by
+// (rank of p among the live positions) * ncalls + part * ncalls / nsplit calls.  One thread per item: the jump-ahead
+// (a 3x3 matrix product mod m per set bit of the offset) costs ~5000 scalar instructions when a wave does it for itself,
+// which at 12 waves per CU on one scalar unit was ~10 % of the scorer's time.
+__global__ __launch_bounds__(256) void qmc_seed_kernel(ScoreArgs a, int ncalls, int* __restrict__ seeds) {
+    const int64_t item = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t p = item / a.nsplit;
+    if (p >= a.n_cand || !a.alive[p]) return;
+    const int part = (int)(item - p * a.nsplit);
+    const int64_t gpos = a.pos_offset + p;
+    int64_t before = gpos;
+    for (int i = 0; i < a.t - 1; i++) before -= (a.b.bgpos[i] < gpos) ? 1 : 0;
+    uint64_t calls_before = (uint64_t)before * (uint64_t)ncalls + (uint64_t)(part * (ncalls / a.nsplit));
+    MrgState rng = {a.seed[0], a.seed[1], a.seed[2], a.seed[3], a.seed[4], a.seed[5]};
+    for (int bit = 0; calls_before != 0; bit++, calls_before >>= 1)
+        if (calls_before & 1) mrg_apply(rng, a.jump + bit * 18);
+    int* sp = seeds + item * 6;
+    sp[0] = rng.x10; sp[1] = rng.x11; sp[2] = rng.x12; sp[3] = rng.x20; sp[4] = rng.x21; sp[5] = rng.x22;
+}
+
 template <int T>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(ITAL_QMC_WAVES(T), ITAL_QMC_WAVES(T)))) void score_qmc_kernel(ScoreArgs a) {
     using Q = Qmc<T>;
@@ -337,15 +358,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(ITAL_QMC_WA
             perm[s] = src;
         }
     }
-    // ---------------- stream position of this candidate: rank among the positions still alive
-    MrgState rng = {a.seed[0], a.seed[1], a.seed[2], a.seed[3], a.seed[4], a.seed[5]};
+    // ---------------- stream position of this work item (prepared by qmc_seed_kernel, one thread per item)
+    MrgState rng;
     {
-        int64_t gpos = a.pos_offset + p;
-        int64_t before = gpos;
-        for (int i = 0; i < T - 1; i++) before -= (a.b.bgpos[i] < gpos) ? 1 : 0;
-        uint64_t calls_before = (uint64_t)before * (uint64_t)Q::NCALLS + (uint64_t)chunk_lo;
-        for (int bit = 0; calls_before != 0; bit++, calls_before >>= 1)
-            if (calls_before & 1) mrg_apply(rng, a.jump + bit * 18);
+        const int* sp = a.seeds + item * 6;
+        rng.x10 = __builtin_amdgcn_readfirstlane(sp[0]); rng.x11 = __builtin_amdgcn_readfirstlane(sp[1]);
+        rng.x12 = __builtin_amdgcn_readfirstlane(sp[2]); rng.x20 = __builtin_amdgcn_readfirstlane(sp[3]);
+        rng.x21 = __builtin_amdgcn_readfirstlane(sp[4]); rng.x22 = __builtin_amdgcn_readfirstlane(sp[5]);
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
@@ -437,6 +456,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(ITAL_QMC_WA
             double value;
             if (sat_c) {
                 value = 1.0;
+#if ITAL_EXPERIMENT == 6
+            } else if (true) {
+                value = 0.5;   // timing experiment only: phases A and B without the lattice evaluation
+#endif
             } else {
                 const double* lat = lats + cl * Q::LAT;
                 // per-call constants out of the preparing lane's slab, as wave-uniform (scalar) values
@@ -552,6 +575,10 @@ static int launch_qmc(const ScoreArgs& a, hipStream_t stream) {
         if (e != hipSuccess) return ital_fail(-12, "score_qmc: cannot raise the dynamic LDS limit");
         attr_done = true;
     }
+    const int64_t items = a.n_cand * a.nsplit;
+    hipLaunchKernelGGL(qmc_seed_kernel, dim3((unsigned)((items + 255) / 256)), dim3(256), 0, stream, a, Q::NCALLS, a.seeds);
+    int rc0 = ital_check_launch("ital_score_step(seeds)");
+    if (rc0) return rc0;
     hipLaunchKernelGGL(score_qmc_kernel<T>, dim3((unsigned)blocks), dim3(256), lds, stream, a);
     int rc = ital_check_launch("ital_score_step(qmc)");
     if (rc || a.nsplit == 1) return rc;
@@ -583,6 +610,8 @@ extern "C" int ital_score_step(const ital_score_desc* d, hipStream_t stream) {
         return ital_check_launch("ital_score_step(t=2)");
     }
     if (!d->jump || !d->jumplane || !d->vk) return ital_fail(-22, "ital_score_step: jump tables / generators missing for t >= 3");
+    if (!d->seeds) return ital_fail(-22, "ital_score_step: seeds buffer missing for t >= 3");
+    a.seeds = d->seeds;
     a.nsplit = 1;
     a.part = nullptr;
     if (d->split > 1 && d->partial && d->label_mode == 0) {

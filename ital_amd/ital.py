@@ -211,10 +211,11 @@ class ITAL(ActiveRetrievalBase):
                     desc.jump, desc.jumplane, desc.vk = _ptr(b["jump"][t]), _ptr(b["jumplane"][t]), _ptr(b["vk"][t])
                     for j in range(6):
                         desc.seed[j] = stream.state[j]
-                    if self.qmc_split > 1 and n_loc:
-                        if b.get("partial") is None or b["partial"].numel() < n_loc * self.qmc_split:
-                            b["partial"] = torch.empty(n_loc * self.qmc_split, dtype=torch.float64, device=dev)
-                        desc.split, desc.partial = self.qmc_split, _ptr(b["partial"])
+                    nsp = max(int(self.qmc_split), 1)
+                    if b.get("partial") is None or b["partial"].numel() < max(n_loc, 1) * nsp:
+                        b["partial"] = torch.empty(max(n_loc, 1) * nsp, dtype=torch.float64, device=dev)
+                        b["seeds"] = torch.empty(max(n_loc, 1) * nsp * 6, dtype=torch.int32, device=dev)
+                    desc.split, desc.partial, desc.seeds = nsp, _ptr(b["partial"]), _ptr(b["seeds"])
                 ev0 = self._mark()
                 check(lib.ital_score_step(ctypes.byref(desc), st))
                 self._mark("score", t, n_alive, ev0)
