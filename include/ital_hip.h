@@ -108,7 +108,7 @@ typedef struct ital_score_desc {
     /* t >= 3: replay of SciPy mvndst's MVNUNI stream (serial evaluation order of the reference) */
     int seed[6];            /* generator state before the first call of this greedy step */
     const long long* jump;  /* [ITAL_JUMP_BITS][18] transition matrices for 2^b calls of dimension t */
-    const long long* jumplane; /* [64][18] transition matrices for 0..63 calls of dimension t */
+    const long long* jumplane; /* [64][18] transition matrices for 0..63 lattice shifts (2(t-1)-1 uniforms each; 8 = one call) */
     const double* vk;       /* [t-1] Korobov generator vector of this dimension */
     int* status;            /* |= 2: singular conditional covariance met */
     /* t >= 3, label_mode 0: a candidate's 2*2^t calls may be split over up to `split` waves (rounded down to a power of

@@ -56,7 +56,7 @@ struct ScoreArgs {
     // MVNUNI replay
     int seed[6];            // generator state at the first call of this greedy step
     const long long* jump;  // [48][18]: transition matrices for 2^b calls (of this step's dimension)
-    const long long* jumplane;  // [64][18]: transition matrices for 0..63 calls
+    const long long* jumplane;  // [64][18]: transition matrices for 0..63 shifts (8 shifts = one call)
     int* seeds;             // [n_cand * nsplit][6] generator state at the first call of every work item
     int nsplit;             // work items per candidate (label_mode 0 only; power of two <= NCALLS / CHUNK)
     double* part;           // [n_cand][nsplit] partial sums when nsplit > 1
@@ -167,7 +167,8 @@ struct Qmc {
                          A_SIZE = A_SD + T;
     static constexpr int LAT = 8 * NDIM * 2;                  // per call: permuted generators + shifts, 8 shifts
     static constexpr int TAILQ = 128 * ITAL_QMC_NH;           // compaction queue of the Phi^-1 tail branch (in place)
-    static constexpr int WAVE_DOUBLES = CHUNK * (SLAB + LAT) + A_SIZE + T + TAILQ;  // + perm
+    static constexpr int SWAPS = (CHUNK * 8 * NDIM + 1) / 2;  // ints: transposition targets of every (call, shift)
+    static constexpr int WAVE_DOUBLES = CHUNK * (SLAB + LAT) + A_SIZE + T + TAILQ + SWAPS;  // + perm
 };
 
 // Swap rows/columns p < q of the packed lower-triangular matrix, the limits and the limit-type bits (RCSWP).
@@ -271,6 +272,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(ITAL_QMC_WA
     double* lats = area + Q::A_SIZE;         // per prepared call: [8][NDIM] generators, then [8][NDIM] shifts
     int* perm = reinterpret_cast<int*>(lats + Q::CHUNK * Q::LAT);  // T ints: natural index held at each sorted slot
     double* tailq = lats + Q::CHUNK * Q::LAT + T;
+    int* swaps = reinterpret_cast<int*>(tailq + Q::TAILQ);
 
     const int row = a.cand[p];
     const int64_t gi = a.row_offset + row;
@@ -417,27 +419,43 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(ITAL_QMC_WA
                 if (lower) { if (!(lim[i] + bound < -37.0)) sat = false; }
                 else { if (!(lim[i] - bound > 37.0)) sat = false; }
             }
-            // the call's 8 randomly shifted lattices: this lane jumps to the call's place in MVNUNI's stream (every
-            // call draws 8*(2*NDIM-1) uniforms whether it is evaluated or not) and replays DKSMRC's draws -- per
-            // shift NDIM-1 for the random transposition of the generator vector, then NDIM shifts
-            if (!sat) {
+        }
+        // The 8 randomly shifted lattices of every call that is evaluated.  A call draws 8*(2*NDIM-1) uniforms from MVNUNI
+        // whether it is evaluated or not: per shift NDIM-1 for DKSMRC's random transposition of the generator vector, then
+        // NDIM shifts.  Lane 8c + s jumps to shift s of call c (one matrix product) and replays only that shift's draws;
+        // the transpositions, which accumulate from shift to shift, are then applied by the call's own lane.
+        {
+            const int c = lane >> 3, sft = lane & 7;
+            const bool sat_c = __shfl((int)sat, c, 64) != 0;
+            if (c < Q::CHUNK && !sat_c) {
                 MrgState sti = rng;
                 mrg_apply(sti, a.jumplane + lane * 18);
                 MrgStateF st = mrg_to_f(sti);
-                double* L = lats + lane * Q::LAT;
-                for (int j = 0; j < Q::NDIM; j++) L[j] = a.vk[j];
-                for (int sft = 0; sft < 8; sft++) {
-                    double* row = L + sft * Q::NDIM;
-                    if (sft > 0)
-                        for (int j = 0; j < Q::NDIM; j++) row[j] = row[j - Q::NDIM];
-                    for (int j = 1; j <= Q::NDIM - 1; j++) {
-                        const double u = mrg_next_f(st);
-                        const int jp = (int)(j + u * (Q::NDIM + 1 - j));
-                        const double xt = row[j - 1];
-                        row[j - 1] = row[jp - 1];
-                        row[jp - 1] = xt;
-                    }
-                    for (int j = 0; j < Q::NDIM; j++) L[8 * Q::NDIM + sft * Q::NDIM + j] = mrg_next_f(st);
+                int* sw = swaps + (c * 8 + sft) * Q::NDIM;
+                for (int j = 1; j <= Q::NDIM - 1; j++) {
+                    const double u = mrg_next_f(st);
+                    sw[j - 1] = (int)(j + u * (Q::NDIM + 1 - j));
+                }
+                double* L = lats + c * Q::LAT;
+                for (int j = 0; j < Q::NDIM; j++) L[8 * Q::NDIM + sft * Q::NDIM + j] = mrg_next_f(st);
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        if (lane < Q::CHUNK && !sat) {
+            double* L = lats + lane * Q::LAT;
+            for (int j = 0; j < Q::NDIM; j++) L[j] = a.vk[j];
+            for (int sft = 0; sft < 8; sft++) {
+                double* row = L + sft * Q::NDIM;
+                if (sft > 0)
+                    for (int j = 0; j < Q::NDIM; j++) row[j] = row[j - Q::NDIM];
+                const int* sw = swaps + (lane * 8 + sft) * Q::NDIM;
+                for (int j = 1; j <= Q::NDIM - 1; j++) {
+                    const int jp = sw[j - 1];
+                    const double xt = row[j - 1];
+                    row[j - 1] = row[jp - 1];
+                    row[jp - 1] = xt;
                 }
             }
         }

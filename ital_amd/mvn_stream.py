@@ -104,10 +104,11 @@ def jump_table(n, bits=48):
 
 
 def jump_lane_table(n, lanes=64):
-    """int64 [lanes][18]: transition matrices of both components for 0..lanes-1 calls of dimension n."""
+    """int64 [lanes][18]: transition matrices of both components for 0..lanes-1 lattice shifts of a call of dimension n
+    (a shift draws 2(n-1)-1 uniforms, a call consists of 8 shifts)."""
     key = ("lane", n, lanes)
     if key not in _jump_cache:
-        d = draws_per_call(n)
+        d = draws_per_call(n) // 8
         j1, j2 = _matpow(A1, d, M1), _matpow(A2, d, M2)
         c1 = c2 = ((1, 0, 0), (0, 1, 0), (0, 0, 1))
         out = np.empty((lanes, 18), dtype=np.int64)

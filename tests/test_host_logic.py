@@ -136,7 +136,7 @@ def test_stream_tables_are_consistent():
         return tuple(a + b)
 
     assert apply(jl[0], base) == base
-    assert apply(jl[5], base) == s.peek(5 * d)
+    assert apply(jl[5], base) == s.peek(5 * d // 8) and apply(jl[16], base) == s.peek(2 * d)
     assert apply(j2[3], base) == s.peek(8 * d)
     st = base
     for bit in range(16):
