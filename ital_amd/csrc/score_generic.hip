@@ -70,10 +70,10 @@ __device__ bool covsrt_n(int n, double* cov, double* lim, double* y, unsigned& i
         for (int j = i; j < n; j++) {
             const double cjj = cov[pidx(j, j)];
             if (cjj > EPS) {
-                const double sumsq = sqrt(cjj);
+                const double sumsq = sqrt_pos(cjj);
                 double sum = 0;
                 for (int k = 0; k < i; k++) sum += cov[pidx(j, k)] * y[k];
-                const double z = (lim[j] - sum) / sumsq;
+                const double z = fast_div(lim[j] - sum, sumsq);
                 const double ph = mvn_phi(z);
                 const bool lower = (infi >> j) & 1u;
                 const double d = lower ? ph : 0.0;
@@ -84,20 +84,21 @@ __device__ bool covsrt_n(int n, double* cov, double* lim, double* y, unsigned& i
         if (jmin > i) rcswp_n(n, i, jmin, cov, lim, infi);
         cov[pidx(i, i)] = cvdiag;
         if (cvdiag > 0) {
+            const double rdiag = fast_div(1.0, cvdiag);   // cvdiag in (1e-5, 1]: well scaled
             for (int l = i + 1; l < n; l++) {
-                cov[pidx(l, i)] = cov[pidx(l, i)] / cvdiag;
+                cov[pidx(l, i)] = cov[pidx(l, i)] * rdiag;
                 for (int j = i + 1; j <= l; j++) cov[pidx(l, j)] -= cov[pidx(l, i)] * cov[pidx(j, i)];
             }
             const bool lower = (infi >> i) & 1u;
             if (emin > dmin + EPS) {
-                const double dens = -exp(-zmin * zmin / 2) / SQTWPI;
+                const double dens = -exp_neg(-zmin * zmin / 2) * (1.0 / SQTWPI);
                 const double yl = lower ? dens : 0.0, yu = lower ? 0.0 : dens;
-                y[i] = (yu - yl) / (emin - dmin);
+                y[i] = fast_div(yu - yl, emin - dmin);
             } else {
                 y[i] = zmin;
             }
-            for (int j = 0; j <= i; j++) cov[pidx(i, j)] = cov[pidx(i, j)] / cvdiag;
-            lim[i] = lim[i] / cvdiag;
+            for (int j = 0; j <= i; j++) cov[pidx(i, j)] = cov[pidx(i, j)] * rdiag;
+            lim[i] = lim[i] * rdiag;
         } else {
             // zero diagonal (linearly dependent variable): Genz's COVSRT expresses the row through the last earlier
             // variable it depends on and moves it right behind that variable; MVNDFN then intersects the limits
