@@ -12,83 +12,10 @@
 
 namespace ital {
 
-// acc * x + K with the constant K held in a scalar register pair.  Plain fma() lets the compiler park polynomial
-// coefficients in VGPRs and form v_fmac (dst tied to the addend), which costs a v_mov_b64 per Horner step to keep the
-// coefficient alive (measured: 188 of 1700 VALU instructions of the lattice loop); the three-address form with a scalar
-// addend is one VALU instruction, the s_mov pair that loads K issues on the scalar unit in the shadow of other waves.
-#ifndef ITAL_FMA_K
-#define ITAL_FMA_K 0   // measured on MI355X: the scalar-addend form is slower (the scalar unit becomes the co-bottleneck)
-#endif
-__device__ __forceinline__ double fma_k(double acc, double x, double K) {
-#if ITAL_FMA_K == 1
-    double r;
-    asm("v_fma_f64 %0, %1, %2, %3" : "=v"(r) : "v"(acc), "v"(x), "s"(K));
-    return r;
-#elif ITAL_FMA_K == 2   // three-address form with the coefficient in a vector register pair
-    double r;
-    asm("v_fma_f64 %0, %1, %2, %3" : "=v"(r) : "v"(acc), "v"(x), "v"(K));
-    return r;
-#else
-    return fma(acc, x, K);
-#endif
-}
-
-// Polynomial coefficients of the hot (Phi, Phi^-1) chain in constant memory: with ITAL_COEF_MEM the kernels fetch them with
-// wide scalar loads (s_load_dwordx8/x16: one scalar instruction per 4-8 coefficients) instead of two s_mov_b32 per
-// coefficient and use.
-#ifndef ITAL_COEF_MEM
-#define ITAL_COEF_MEM 0
-#endif
-__constant__ const double ITAL_COEF[44] = {
-    1.4426950408889634074,
-    6.93147180369123816490e-01,
-    1.90821492927058770002e-10,
-    1.0 / 6227020800.0,
-    1.0 / 479001600.0,
-    1.0 / 39916800.0,
-    1.0 / 3628800.0,
-    1.0 / 362880.0,
-    1.0 / 40320.0,
-    1.0 / 5040.0,
-    1.0 / 720.0,
-    1.0 / 120.0,
-    1.0 / 24.0,
-    1.0 / 6.0,
-    220.2068679123761,
-    221.2135961699311,
-    112.0792914978709,
-    33.91286607838300,
-    6.373962203531650,
-    .7003830644436881,
-    .03526249659989109,
-    440.4137358247522,
-    793.8265125199484,
-    637.3336333788311,
-    296.5642487796737,
-    86.78073220294608,
-    16.06417757920695,
-    1.755667163182642,
-    .08838834764831844,
-    3.3871328727963666080E0,
-    1.3314166789178437745E+2,
-    1.9715909503065514427E+3,
-    1.3731693765509461125E+4,
-    4.5921953931549871457E+4,
-    6.7265770927008700853E+4,
-    3.3430575583588128105E+4,
-    2.5090809287301226727E+3,
-    4.2313330701600911252E+1,
-    6.8718700749205790830E+2,
-    5.3941960214247511077E+3,
-    2.1213794301586595867E+4,
-    3.9307895800092710610E+4,
-    2.8729085735721942674E+4,
-    5.2264952788528545610E+3};
-#if ITAL_COEF_MEM
-#define KC(i, lit) (ITAL_COEF[i])
-#else
-#define KC(i, lit) (lit)
-#endif
+// Horner step acc * x + K.  Spelling the instruction out by inline asm was measured and rejected on MI355X: with K in a
+// scalar register pair the scalar unit becomes the co-bottleneck (two s_mov_b32 per step), with K in a vector register
+// pair the register file spills; the compiler's v_fmac + v_mov_b64 form (coefficients parked in VGPRs) is the fastest.
+__device__ __forceinline__ double fma_k(double acc, double x, double K) { return fma(acc, x, K); }
 
 // n / d for well-scaled d (polynomial denominators, no zero / inf / subnormal): hardware reciprocal seed, two
 // Newton steps and one residual correction -- ~1 ulp, about half the instructions of the IEEE division expansion.
@@ -103,21 +30,21 @@ __device__ __forceinline__ double fast_div(double n, double d) {
 // exp(x) for x in [-745, 0]: Cody-Waite reduction by ln2, degree-13 Taylor polynomial on |r| <= ln2/2 (relative error
 // < 1e-16), scaling by v_ldexp_f64.  19 VALU instructions against ~42 for the general-purpose library routine.
 __device__ __forceinline__ double exp_neg(double x) {
-    const double LOG2E = KC(0, 1.4426950408889634074), LN2_HI = KC(1, 6.93147180369123816490e-01), LN2_LO = KC(2, 1.90821492927058770002e-10);
+    const double LOG2E = 1.4426950408889634074, LN2_HI = 6.93147180369123816490e-01, LN2_LO = 1.90821492927058770002e-10;
     const double n = rint(x * LOG2E);
     double r = fma(-n, LN2_HI, x);
     r = fma(-n, LN2_LO, r);
-    double p = KC(3, 1.0 / 6227020800.0);
-    p = fma_k(p, r, KC(4, 1.0 / 479001600.0));
-    p = fma_k(p, r, KC(5, 1.0 / 39916800.0));
-    p = fma_k(p, r, KC(6, 1.0 / 3628800.0));
-    p = fma_k(p, r, KC(7, 1.0 / 362880.0));
-    p = fma_k(p, r, KC(8, 1.0 / 40320.0));
-    p = fma_k(p, r, KC(9, 1.0 / 5040.0));
-    p = fma_k(p, r, KC(10, 1.0 / 720.0));
-    p = fma_k(p, r, KC(11, 1.0 / 120.0));
-    p = fma_k(p, r, KC(12, 1.0 / 24.0));
-    p = fma_k(p, r, KC(13, 1.0 / 6.0));
+    double p = 1.0 / 6227020800.0;
+    p = fma_k(p, r, 1.0 / 479001600.0);
+    p = fma_k(p, r, 1.0 / 39916800.0);
+    p = fma_k(p, r, 1.0 / 3628800.0);
+    p = fma_k(p, r, 1.0 / 362880.0);
+    p = fma_k(p, r, 1.0 / 40320.0);
+    p = fma_k(p, r, 1.0 / 5040.0);
+    p = fma_k(p, r, 1.0 / 720.0);
+    p = fma_k(p, r, 1.0 / 120.0);
+    p = fma_k(p, r, 1.0 / 24.0);
+    p = fma_k(p, r, 1.0 / 6.0);
     p = fma(p, r, 0.5);
     p = fma(p, r, 1.0);
     p = fma(p, r, 1.0);
@@ -168,10 +95,10 @@ __device__ __forceinline__ double sqrt_pos(double a) {
 // MVNPHI (Hart 5666).  The far-tail continued fraction z + 1/(z + 2/(z + 3/(z + 4/(z + 0.65)))) is evaluated as the
 // ratio of its convergents' numerators N1/N2 (one division instead of six).
 __device__ __forceinline__ double mvn_phi(double z) {
-    const double P0 = KC(14, 220.2068679123761), P1 = KC(15, 221.2135961699311), P2 = KC(16, 112.0792914978709), P3 = KC(17, 33.91286607838300),
-                 P4 = KC(18, 6.373962203531650), P5 = KC(19, .7003830644436881), P6 = KC(20, .03526249659989109);
-    const double Q0 = KC(21, 440.4137358247522), Q1 = KC(22, 793.8265125199484), Q2 = KC(23, 637.3336333788311), Q3 = KC(24, 296.5642487796737),
-                 Q4 = KC(25, 86.78073220294608), Q5 = KC(26, 16.06417757920695), Q6 = KC(27, 1.755667163182642), Q7 = KC(28, .08838834764831844);
+    const double P0 = 220.2068679123761, P1 = 221.2135961699311, P2 = 112.0792914978709, P3 = 33.91286607838300,
+                 P4 = 6.373962203531650, P5 = .7003830644436881, P6 = .03526249659989109;
+    const double Q0 = 440.4137358247522, Q1 = 793.8265125199484, Q2 = 637.3336333788311, Q3 = 296.5642487796737,
+                 Q4 = 86.78073220294608, Q5 = 16.06417757920695, Q6 = 1.755667163182642, Q7 = .08838834764831844;
     const double ROOTPI = 2.506628274631001, CUTOFF = 7.071067811865475;
     const double zabs = fabs(z);
     double p;
@@ -201,11 +128,11 @@ __device__ __forceinline__ double mvn_phi(double z) {
 __device__ __forceinline__ bool phinv_is_central(double p) { return fabs(p - 0.5) <= 0.425; }
 
 __device__ __forceinline__ double phinv_central(double p) {
-    const double A0 = KC(29, 3.3871328727963666080E0), A1 = KC(30, 1.3314166789178437745E+2), A2 = KC(31, 1.9715909503065514427E+3),
-                 A3 = KC(32, 1.3731693765509461125E+4), A4 = KC(33, 4.5921953931549871457E+4), A5 = KC(34, 6.7265770927008700853E+4),
-                 A6 = KC(35, 3.3430575583588128105E+4), A7 = KC(36, 2.5090809287301226727E+3), B1 = KC(37, 4.2313330701600911252E+1),
-                 B2 = KC(38, 6.8718700749205790830E+2), B3 = KC(39, 5.3941960214247511077E+3), B4 = KC(40, 2.1213794301586595867E+4),
-                 B5 = KC(41, 3.9307895800092710610E+4), B6 = KC(42, 2.8729085735721942674E+4), B7 = KC(43, 5.2264952788528545610E+3);
+    const double A0 = 3.3871328727963666080E0, A1 = 1.3314166789178437745E+2, A2 = 1.9715909503065514427E+3,
+                 A3 = 1.3731693765509461125E+4, A4 = 4.5921953931549871457E+4, A5 = 6.7265770927008700853E+4,
+                 A6 = 3.3430575583588128105E+4, A7 = 2.5090809287301226727E+3, B1 = 4.2313330701600911252E+1,
+                 B2 = 6.8718700749205790830E+2, B3 = 5.3941960214247511077E+3, B4 = 2.1213794301586595867E+4,
+                 B5 = 3.9307895800092710610E+4, B6 = 2.8729085735721942674E+4, B7 = 5.2264952788528545610E+3;
     const double q = (2 * p - 1) / 2;
     const double r = 0.180625 - q * q;
     const double num = fma_k(fma_k(fma_k(fma_k(fma_k(fma_k(fma_k(A7, r, A6), r, A5), r, A4), r, A3), r, A2), r, A1), r, A0);

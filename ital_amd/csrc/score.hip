@@ -26,12 +26,6 @@
 #ifndef ITAL_QMC_NH
 #define ITAL_QMC_NH 2      // lattice items per lane and round (each with its antithetic partner)
 #endif
-#ifndef ITAL_EXPERIMENT
-#define ITAL_EXPERIMENT 0   // != 0: timing experiments with parts of the integrand removed (results are wrong)
-#endif
-#ifndef ITAL_QMC_COMPACT
-#define ITAL_QMC_COMPACT 1  // wave-level compaction of the Phi^-1 tail branch (0: plain divergent branch per chain)
-#endif
 #ifndef ITAL_QMC_WAVES
 #define ITAL_QMC_WAVES(T) ((T) <= 4 ? 3 : 2)   // waves per SIMD the register allocation aims at (measured)
 #endif
@@ -475,10 +469,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(ITAL_QMC_WA
             double value;
             if (sat_c) {
                 value = 1.0;
-#if ITAL_EXPERIMENT == 6
-            } else if (true) {
-                value = 0.5;   // timing experiment only: phases A and B without the lattice evaluation
-#endif
             } else {
                 const double* lat = lats + cl * Q::LAT;
                 // per-call constants out of the preparing lane's slab, as wave-uniform (scalar) values
@@ -522,11 +512,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(ITAL_QMC_WA
                             double sc = 0;
 #pragma unroll
                             for (int j = 0; j < i; j++) sc = fma(cf[i * (i - 1) / 2 + j], yy[c][j], sc);
-#if ITAL_EXPERIMENT == 2
-                            const double ph = 0.5 + 1e-3 * (lm[i] - sc);     // timing experiment only: no Phi
-#else
                             const double ph = mvn_phi(lm[i] - sc);
-#endif
                             const double d = lower ? ph : 0.0;
                             const double w = lower ? 1.0 - ph : ph;
                             dead[c] = dead[c] || !(w > 0);
@@ -534,21 +520,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(ITAL_QMC_WA
                             if (i < T - 1) pin[c] = fma(xx[c][i], w, d);   // a dead chain (w == 0) just inverts d: finite, discarded
                         }
                         if (i < T - 1) {
-#if ITAL_EXPERIMENT == 1
-#pragma unroll
-                            for (int c = 0; c < NC; c++) yy[c][i] = pin[c] - 0.5;   // timing experiment only: no Phi^-1
-#elif ITAL_EXPERIMENT == 4
-#pragma unroll
-                            for (int c = 0; c < NC; c++) yy[c][i] = phinv_central(pin[c]);   // timing experiment only: no tails
-#elif ITAL_QMC_COMPACT
                             double out[NC];
                             phinv_wave<NC>(pin, out, tailq, lane);
 #pragma unroll
                             for (int c = 0; c < NC; c++) yy[c][i] = out[c];
-#else
-#pragma unroll
-                            for (int c = 0; c < NC; c++) yy[c][i] = mvn_phinv(pin[c]);
-#endif
                         }
                     }
 #pragma unroll

@@ -31,6 +31,9 @@
 #include "ital_internal.h"
 #include "qmc_common.h"
 
+#ifndef ITAL_GEN_NH12
+#define ITAL_GEN_NH12 1   // lattice items per lane and round of the runtime-dimension evaluator up to 12 dimensions
+#endif
 #ifndef ITAL_GEN_EARLY
 #define ITAL_GEN_EARLY 1   // decide saturated calls from the standardised limits, before COVSRT
 #endif
@@ -599,9 +602,6 @@ __device__ __forceinline__ void wave_sync() {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-#ifndef ITAL_EXPERIMENT
-#define ITAL_EXPERIMENT 0
-#endif
 #ifndef ITAL_GEN_WAVES
 #define ITAL_GEN_WAVES 3
 #endif
@@ -743,14 +743,10 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(ITAL_GEN_WA
                 value = (fl_c & 2) ? 1.0 : 0.0;
             } else {
                 const double* slab_c = slabs + (size_t)cl * a.stride;
-#if ITAL_EXPERIMENT == 5
-                value = 0.5;   // timing experiment only: preparation cost without the lattice evaluation
-#else
                 if (TFIX > 0 && n_c == TFIX && closes_c == (1u << (TFIX > 0 ? TFIX : 1)) - 1u)
                     value = qmc_eval_fixed<(TFIX > 0 ? TFIX : 3)>(slab_c, infi_c, slab_c + a.lat, lane, tailq);
                 else
                     value = qmc_eval<NMAX, NH>(n_c, slab_c, infi_c, closes_c, slab_c + a.lat, lane, tailq);
-#endif
             }
             const CallInfo ci = decode_call(d, p, chunk0 + cl, cpp, npre, nr, npat);
             if (ci.kind == K_PRIOR) {
@@ -841,7 +837,7 @@ extern "C" int ital_score_generic(const ital_gscore_desc* d, hipStream_t stream)
         case 6: ITAL_GEN_LAUNCH(6, 2, 6); break;
         default:
             if (nUmax <= 6) ITAL_GEN_LAUNCH(6, 2, 0);
-            else if (nUmax <= 12) ITAL_GEN_LAUNCH(12, 1, 0);
+            else if (nUmax <= 12) ITAL_GEN_LAUNCH(12, ITAL_GEN_NH12, 0);
             else ITAL_GEN_LAUNCH(ITAL_GENERIC_MAX_DIM, 1, 0);
     }
 #undef ITAL_GEN_LAUNCH
