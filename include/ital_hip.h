@@ -207,7 +207,6 @@ typedef struct ital_gscore_desc {
     /* replay of mvndst's MVNUNI stream */
     int seed[6];            /* generator state before the first call of this greedy step */
     const long long* jump1; /* [ITAL_JUMP_BITS][18] transition matrices for 2^b uniforms */
-    const long long* skip;  /* [ITAL_GENERIC_MAX_DIM + 1][18] transition matrix of one call of dimension n */
     const double* vk;       /* [ITAL_GENERIC_MAX_DIM + 1][ITAL_GENERIC_MAX_DIM] Korobov generators of dimension n */
     int64_t draws_out;      /* uniforms one candidate outside E consumes */
     int64_t draws_in;       /* ... one live candidate that is a member of E */

@@ -799,7 +799,7 @@ extern "C" int ital_score_generic(const ital_gscore_desc* d, hipStream_t stream)
         if (npat * (2 + nfb) > (double)ITAL_GENERIC_MAX_CALLS)
             return ital_fail(-22, "ital_score_generic: more calls per candidate than ITAL_GENERIC_MAX_CALLS (use the monte-carlo switches)");
     }
-    if (!d->jump1 || !d->skip || !d->vk) return ital_fail(-22, "ital_score_generic: stream tables missing");
+    if (!d->jump1 || !d->vk) return ital_fail(-22, "ital_score_generic: stream tables missing");
     GArgs a;
     a.d = *d;
     const int slab = nUmax * (nUmax + 1) / 2 + 2 * nUmax;

@@ -284,7 +284,6 @@ class ITAL(ActiveRetrievalBase):
             alive = torch.ones(max(n_loc, 1), dtype=torch.uint8, device=dev)
             mi = torch.zeros(max(n_loc, 1), dtype=torch.float64, device=dev)
             jump1 = torch.from_numpy(mvn_stream.jump1_table(ITAL_JUMP_BITS)).to(dev)
-            skip = torch.from_numpy(mvn_stream.skip_table(GN)).to(dev)
             vk = torch.from_numpy(mvn_stream.vk_table(GN)).to(dev)
             C = b["C"]
             e_mu = np.zeros(kmax_e)
@@ -349,7 +348,7 @@ class ITAL(ActiveRetrievalBase):
                 desc.noise, desc.eps = float(self.noise), float(self.eps)
                 for j in range(6):
                     desc.seed[j] = stream.state[j]
-                desc.jump1, desc.skip, desc.vk = _ptr(jump1), _ptr(skip), _ptr(vk)
+                desc.jump1, desc.vk = _ptr(jump1), _ptr(vk)
                 desc.draws_out, desc.draws_in = draws_out, draws_in
                 desc.n_in, desc.in_pos, desc.n_dead, desc.dead_pos = len(in_pos), _ptr(t_in), len(dead_pos), _ptr(t_dead)
                 desc.mi, desc.status = _ptr(mi), _ptr(gp.status)

@@ -59,6 +59,24 @@ def korobov_vk(n):
     return vk
 
 
+_POW2 = {1: [A1], 2: [A2]}   # A^(2^b) of both components, extended on demand
+
+
+def _jump_state(vec, n, which, a, m):
+    """vec advanced by n steps of component `which`: one matrix-vector product per set bit of n (the squarings are
+    cached), instead of a fresh square-and-multiply of 3x3 matrices per call."""
+    pows = _POW2[which]
+    b = 0
+    while n:
+        if b >= len(pows):
+            pows.append(_matmul(pows[-1], pows[-1], m))
+        if n & 1:
+            vec = _apply(pows[b], vec, m)
+        n >>= 1
+        b += 1
+    return vec
+
+
 class MvnStream:
     """Position of the MVNUNI stream; `state` is the generator state after `draws` uniforms."""
 
@@ -73,16 +91,13 @@ class MvnStream:
         n = int(n)
         if n <= 0:
             return
-        s1 = _apply(_matpow(A1, n, M1), self.state[:3], M1)
-        s2 = _apply(_matpow(A2, n, M2), self.state[3:], M2)
-        self.state = s1 + s2
+        self.state = _jump_state(self.state[:3], n, 1, A1, M1) + _jump_state(self.state[3:], n, 2, A2, M2)
         self.draws += n
 
     def peek(self, n):
         """State after n more draws, without moving."""
-        s1 = _apply(_matpow(A1, int(n), M1), self.state[:3], M1)
-        s2 = _apply(_matpow(A2, int(n), M2), self.state[3:], M2)
-        return s1 + s2
+        n = int(n)
+        return _jump_state(self.state[:3], n, 1, A1, M1) + _jump_state(self.state[3:], n, 2, A2, M2)
 
 
 _jump_cache = {}
@@ -130,19 +145,6 @@ def jump1_table(bits=48):
             out[b, :9] = np.array(j1, dtype=np.int64).ravel()
             out[b, 9:] = np.array(j2, dtype=np.int64).ravel()
             j1, j2 = _matmul(j1, j1, M1), _matmul(j2, j2, M2)
-        _jump_cache[key] = out
-    return _jump_cache[key]
-
-
-def skip_table(nmax):
-    """int64 [nmax + 1][18]: transition matrix of the uniforms ONE call of dimension n consumes (identity, n <= 2)."""
-    key = ("skip", nmax)
-    if key not in _jump_cache:
-        out = np.empty((nmax + 1, 18), dtype=np.int64)
-        for n in range(nmax + 1):
-            d = draws_per_call(n)
-            out[n, :9] = np.array(_matpow(A1, d, M1), dtype=np.int64).ravel()
-            out[n, 9:] = np.array(_matpow(A2, d, M2), dtype=np.int64).ravel()
         _jump_cache[key] = out
     return _jump_cache[key]
 

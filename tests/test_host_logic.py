@@ -143,7 +143,5 @@ def test_stream_tables_are_consistent():
         if (37 >> bit) & 1:
             st = apply(j1[bit], st)
     assert st == s.peek(37)
-    sk = ms.skip_table(6)
-    assert apply(sk[2], base) == base and apply(sk[6], base) == s.peek(ms.draws_per_call(6))
     vk = ms.vk_table(6)
     assert np.all(vk[:3] == 0) and np.array_equal(vk[5, :4], ms.korobov_vk(5))
