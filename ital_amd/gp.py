@@ -253,6 +253,29 @@ class GaussianProcess(object):
             out[c0:c0 + c] = buf[:, : self.n].index_select(1, idx).cpu().numpy()
         return out
 
+    def updated_prediction(self, ind, y, pred_ind, cov_mode=None):
+        """Prediction for `pred_ind` after a simulated update with (ind, y), without updating (reference gp.py:295-344).
+        The scorers do this inside their kernels (closed form on the fed-back block); this API call, which the reference
+        exposes to callers, applies the same closed form on the host to the posterior block the device computes:
+        W = (Sigma_FF + noise I)^-1, mu' = mu_P + Sigma_PF W (y - mu_F), Sigma' = Sigma_PP - Sigma_PF W Sigma_FP."""
+        ind = [int(i) for i in ind]
+        pred = [int(i) for i in pred_ind]
+        y = np.asarray(y, dtype=np.float64).reshape(-1)
+        mean, cov = self.predict_stored(pred + ind, cov_mode="full")
+        n = len(pred)
+        s_ff = cov[n:, n:] + self.noise * np.eye(len(ind))
+        s_pf = cov[:n, n:]
+        sol = np.linalg.solve(s_ff, np.column_stack((y - mean[n:], s_pf.T)))
+        new_mean = mean[:n] + s_pf @ sol[:, 0]
+        if cov_mode is None:
+            return new_mean
+        new_cov = cov[:n, :n] - s_pf @ sol[:, 1:]
+        if cov_mode == "full":
+            return new_mean, new_cov
+        if cov_mode == "diag":
+            return new_mean, np.maximum(0, np.diag(new_cov))
+        raise ValueError("cov_mode must be None, 'diag' or 'full'")
+
     def rbf_cols(self, ind):
         """Kernel columns k(x_j, X) for a short index list (what replaces slicing K_all)."""
         rows = self._gather_rows([int(i) for i in ind])

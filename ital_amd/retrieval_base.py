@@ -85,6 +85,17 @@ class ActiveRetrievalBase(object):
             self.rounds += 1
         self.unnameable_ids.update(unnameable)
 
+    def updated_prediction(self, feedback, test_ind, cov_mode='full'):
+        """Prediction after a simulated update with `feedback`, without performing it (reference
+        retrieval_base.py:129-164)."""
+        rel, irr, _ = self.partition_feedback(feedback)
+        if len(rel) + len(irr) == 0:
+            return self.gp.predict_stored(test_ind, cov_mode=cov_mode)
+        rel.sort()
+        irr.sort()
+        return self.gp.updated_prediction(rel + irr, np.concatenate((np.ones(len(rel)), -1 * np.ones(len(irr)))),
+                                          test_ind, cov_mode=cov_mode)
+
     def partition_feedback(self, feedback):
         """reference retrieval_base.py:167-193"""
         rel, irr, unnameable = [], [], []

@@ -296,6 +296,29 @@ def test_api_edge_cases(dev):
         M.fetch_unlabelled(3)
 
 
+def test_updated_prediction_api(dev):
+    from oracle.ital import OracleITAL
+    ITAL, _, _ = _learners()
+    rng = np.random.default_rng(8)
+    X = rng.random((70, 5))
+    A = ITAL(X, length_scale=0.7, device=dev)
+    B = OracleITAL(X, length_scale=0.7)
+    A.update({1: 1, 2: -1, 3: 1})
+    B.update({1: 1, 2: -1, 3: 1})
+    fb = {10: 1, 20: -1, 30: 0, 40: 1}
+    test = [5, 10, 33, 40, 60]
+    for mode in (None, "diag", "full"):
+        got, want = A.updated_prediction(fb, test, cov_mode=mode), B.updated_prediction(fb, test, cov_mode=mode)
+        if mode is None:
+            np.testing.assert_allclose(got, want, rtol=0, atol=1e-8)
+        else:
+            np.testing.assert_allclose(got[0], want[0], rtol=0, atol=1e-8)
+            np.testing.assert_allclose(got[1], want[1], rtol=0, atol=1e-8)
+    m0 = A.updated_prediction({30: 0}, test, cov_mode=None)          # nothing labelled: the stored prediction
+    np.testing.assert_allclose(m0, A.rel_mean[test], rtol=0, atol=0)
+    assert A.gp.m == 3                                                # the model itself is untouched
+
+
 def test_queries_constructor(dev):
     from oracle.ital import OracleITAL
     ITAL, _, _ = _learners()
