@@ -105,6 +105,56 @@ class GaussianProcess(object):
         raise AttributeError("the dense N x N kernel matrix is never formed by ital_amd (reference gp.py:128 is "
                              "replaced by column streaming); use rbf_cols()")
 
+    # attributes of the reference's GP that derive from the m x m Gram matrix of the labelled samples: reconstructed on
+    # demand from the Cholesky factor kept on the device (K = L L^T includes the noise term, as gp.py:156)
+    def _factor(self):
+        return self.L[: self.m, : self.m].cpu().numpy()
+
+    @property
+    def K(self):
+        if self.m == 0:
+            return None
+        f = self._factor()
+        return f @ f.T
+
+    @property
+    def K_inv(self):
+        if self.m == 0:
+            return None
+        fi = np.linalg.inv(self._factor())
+        return fi.T @ fi
+
+    @property
+    def w(self):
+        if self.m == 0:
+            return None
+        import scipy.linalg
+        return scipy.linalg.solve_triangular(self._factor(), self.alpha[: self.m].cpu().numpy(), lower=True, trans="T")
+
+    def kernel(self, a, b=None):
+        """RBF kernel between the rows of `a` and of `b` (default: the labelled samples vs `a`, as reference
+        gp.py:390-416), computed by ital_cov_block (FP64 MFMA) with an empty whitened part."""
+        if b is None:
+            if self.m == 0:
+                raise RuntimeError("the GP has not been fitted")
+            a, b = self.XT[: self.m, : self.d].cpu().numpy(), a
+        a = np.atleast_2d(np.asarray(a, dtype=np.float64))
+        b = np.atleast_2d(np.asarray(b, dtype=np.float64))
+        dev = self.device
+        A = torch.zeros((len(a), self.ldx), dtype=torch.float64, device=dev)
+        B = torch.zeros((len(b), self.ldx), dtype=torch.float64, device=dev)
+        A[:, : self.d] = torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+        B[:, : self.d] = torch.from_numpy(np.ascontiguousarray(b)).to(dev)
+        an = torch.empty(len(a), dtype=torch.float64, device=dev)
+        bn = torch.empty(len(b), dtype=torch.float64, device=dev)
+        out = torch.empty((len(a), _pad16(len(b))), dtype=torch.float64, device=dev)
+        st = _stream()
+        check(self._lib.ital_row_norms(_ptr(A), len(a), self.ldx, _ptr(an), st))
+        check(self._lib.ital_row_norms(_ptr(B), len(b), self.ldx, _ptr(bn), st))
+        check(self._lib.ital_cov_block(_ptr(A), _ptr(an), len(a), _ptr(B), _ptr(bn), len(b), self.ldx, 0, 0, 0, 0, 0,
+                                       float(self.var), float(self.length_scale), _ptr(out), out.shape[1], st))
+        return out[:, : len(b)].cpu().numpy()
+
     def reset(self):
         """Back to the state right after __init__ (reference gp.py:132-138)."""
         self.ind = []

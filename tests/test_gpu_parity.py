@@ -296,6 +296,26 @@ def test_api_edge_cases(dev):
         M.fetch_unlabelled(3)
 
 
+def test_gp_attributes_of_the_reference(dev):
+    """K, K_inv, w and kernel() of reference ital/gp.py, rebuilt from the device state."""
+    from oracle.gp import OracleGP, rbf_kernel
+    _, GP, _ = _learners()
+    rng = np.random.default_rng(12)
+    X = rng.random((50, 6))
+    gp = GP(X, 0.9, var=1.1, noise=1e-4, device=dev)
+    ref = OracleGP(X, 0.9, var=1.1, noise=1e-4)
+    assert gp.K is None and gp.w is None
+    idx, y = [4, 9, 17, 30], [1.0, -1.0, 1.0, -1.0]
+    gp.update(idx, y)
+    ref.update(idx, y)
+    np.testing.assert_allclose(gp.K, ref.K, rtol=0, atol=1e-12)
+    np.testing.assert_allclose(gp.K_inv, ref.K_inv, rtol=1e-7, atol=1e-7)
+    np.testing.assert_allclose(gp.w, ref.w, rtol=1e-7, atol=1e-8)
+    Z = rng.random((7, 6))
+    np.testing.assert_allclose(gp.kernel(Z), rbf_kernel(X[idx], Z, 0.9, 1.1), rtol=1e-12, atol=1e-15)
+    np.testing.assert_allclose(gp.kernel(Z, X[:5]), rbf_kernel(Z, X[:5], 0.9, 1.1), rtol=1e-12, atol=1e-15)
+
+
 def test_updated_prediction_api(dev):
     from oracle.ital import OracleITAL
     ITAL, _, _ = _learners()
