@@ -57,19 +57,22 @@ def read_config_file(config_file, section, overrides):
 
 def _learners():
     from . import ITAL, MCMI_min
-    return {"ITAL": ITAL, "MCMI": MCMI_min}
+    from .baselines import LEARNERS as ranking
+    table = {"ITAL": ITAL, "MCMI": MCMI_min}
+    table.update(ranking)
+    return table
 
 
-BASELINES = ("random", "border", "border_div", "topscoring", "var", "unc", "entropy", "EMOC", "SUD", "RBMAL", "TCAL", "USDM",
-             "AdaptAL")
+BASELINES = ("border_div", "entropy", "EMOC", "SUD", "RBMAL", "TCAL", "USDM", "AdaptAL")
 
 
 def make_learner(method, data, learner_config, **placement):
     table = _learners()
     if method not in table:
         if method in BASELINES:
-            raise NotImplementedError("learner %r is one of the reference's comparison baselines; only ITAL and MCMI are "
-                                      "on the MI355X hot path" % method)
+            raise NotImplementedError("learner %r is one of the reference's comparison baselines that are not part of the "
+                                      "MI355X path (ITAL, MCMI and the ranking baselines random / topscoring / border / "
+                                      "var / unc are)" % method)
         raise KeyError("unknown learner %r" % method)
     return table[method](data, **learner_config, **placement)
 

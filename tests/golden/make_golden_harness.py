@@ -17,7 +17,8 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, HERE)
 import make_golden  # noqa: E402
 
-NAMES = ["harness_iris", "harness_noisy", "harness_mcmi"]
+NAMES = ["harness_iris", "harness_noisy", "harness_mcmi", "harness_topscoring", "harness_border", "harness_unc", "harness_random",
+         "harness_var"]
 
 
 def run(name):

@@ -71,7 +71,7 @@ def test_baselines_are_rejected_explicitly(tmp_path):
         harness.load_config(str(conf))
 
 
-def _run(name, learners):
+def _run(name, learners, ordered=True):
     g = _golden(name)
     cfg = harness.read_config_file(os.path.join(CONF, name + ".conf"), "EXPERIMENT", {})
     ds = harness.load_dataset(cfg["EXPERIMENT"]["dataset"], **cfg[cfg["EXPERIMENT"]["dataset"]])
@@ -83,8 +83,13 @@ def _run(name, learners):
     learner = learners[method](ds.X_train_norm, **kw)
     trace, buf = [], io.StringIO()
     harness.run_retrieval_experiment(cfg, ds, learner, out=buf, trace=trace)
-    assert [t[3] for t in trace] == [t["ret"] for t in g["trace"]]          # every fetched batch
-    assert [t[4] for t in trace] == [t["fb"] for t in g["trace"]]           # every simulated feedback
+    if ordered:
+        assert [t[3] for t in trace] == [t["ret"] for t in g["trace"]]          # every fetched batch
+        assert [t[4] for t in trace] == [t["fb"] for t in g["trace"]]           # every simulated feedback
+    else:
+        # ranking baselines: exact duplicates in the data (Iris has some) tie, and the order inside a batch then hangs on
+        # rounding noise of the reference's dense algebra -- the batches are compared as sets
+        assert [sorted(int(i) for i in t[3]) for t in trace] == [sorted(t["ret"]) for t in g["trace"]]
     assert buf.getvalue() == g["table"]                                       # the printed AP / NDCG table
     return learner
 
@@ -98,14 +103,15 @@ def test_loop_with_oracle_learners_reproduces_reference_tables(name):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("name", ["harness_iris", "harness_noisy", "harness_mcmi"])
+@pytest.mark.parametrize("name", ["harness_iris", "harness_noisy", "harness_mcmi", "harness_topscoring", "harness_border",
+                                  "harness_unc", "harness_random", "harness_var"])
 def test_loop_with_device_learners_reproduces_reference_tables(name):
     torch = pytest.importorskip("torch")
     if not torch.cuda.is_available():
         pytest.skip("no GPU")
-    from ital_amd import ITAL, MCMI_min, mvn_stream
+    from ital_amd import mvn_stream
     mvn_stream.GLOBAL.reset()
-    _run(name, {"ITAL": ITAL, "MCMI": MCMI_min})
+    _run(name, harness._learners(), ordered=name in ("harness_iris", "harness_noisy", "harness_mcmi"))
 
 
 @pytest.mark.gpu
