@@ -204,6 +204,8 @@ typedef struct ital_gscore_desc {
     double label_prob, mistake_prob;
     int label_mode;         /* 0 mean, 1 optimistic, 2 pessimistic (subset_mode 0 only) */
     double noise, eps;
+    double clip_cov;        /* 0 < clip_cov < 1: orthant probabilities above 5 dimensions factorise over the connected
+                               components of |correlation| > clip_cov (reference ital/ital.py:360-362, :386-429, :590-616) */
     /* replay of mvndst's MVNUNI stream */
     int seed[6];            /* generator state before the first call of this greedy step */
     const long long* jump1; /* [ITAL_JUMP_BITS][18] transition matrices for 2^b uniforms */
@@ -222,6 +224,8 @@ typedef struct ital_gscore_desc {
     const uint32_t* fb_samples;  /* [n_cand][patterns][mc_fb] low 16 bits: non-zero feedback (bit v), high 16: positive */
     const int64_t* draw_off;/* [n_cand] uniforms consumed before each candidate (replaces draws_out / draws_in when the
                                count per candidate varies: all-zero feedback samples are skipped without a call); or NULL */
+    int64_t* draw_count;    /* non-NULL: counting pass -- only writes the uniforms every live candidate consumes
+                               ([n_cand]; with clip_cov the count depends on the data) and scores nothing */
     double* mi;             /* [n_cand] out */
     int* status;
 } ital_gscore_desc;

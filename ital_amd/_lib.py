@@ -38,10 +38,10 @@ class ItalGscoreDesc(ctypes.Structure):
                 ("nE", c_int), ("E_idx", c_void_p), ("E_sort", c_void_p), ("E_mu", c_void_p), ("E_sig", c_void_p),
                 ("ldE", c_int), ("n_picks", c_int), ("pick_pos", c_void_p), ("subset_mode", c_int), ("fb_mode", c_int),
                 ("label_prob", c_double), ("mistake_prob", c_double), ("label_mode", c_int), ("noise", c_double),
-                ("eps", c_double), ("seed", c_int * 6), ("jump1", c_void_p), ("vk", c_void_p),
+                ("eps", c_double), ("clip_cov", c_double), ("seed", c_int * 6), ("jump1", c_void_p), ("vk", c_void_p),
                 ("draws_out", c_int64), ("draws_in", c_int64), ("n_in", c_int), ("in_pos", c_void_p),
                 ("n_dead", c_int), ("dead_pos", c_void_p), ("mc_rel", c_int), ("rel_samples", c_void_p),
-                ("mc_fb", c_int), ("fb_samples", c_void_p), ("draw_off", c_void_p), ("mi", c_void_p),
+                ("mc_fb", c_int), ("fb_samples", c_void_p), ("draw_off", c_void_p), ("draw_count", c_void_p), ("mi", c_void_p),
                 ("status", c_void_p)]
 
 

@@ -50,6 +50,7 @@ struct GArgs {
     int slab;          // of which the COVSRT slab (packed factor, limits, expected values), then the update scratch,
     int lat;           // then (at this offset) the call's 8 shifted lattices
     int ldS;           // leading dimension of the joint covariance in LDS (largest |U|)
+    int master;        // clip_cov: offset of the lane's copy of the standardised problem (0: clip_cov off)
     int wave_doubles;  // LDS doubles per wave
 };
 
@@ -244,16 +245,129 @@ struct Prep {
     int n;
     unsigned infi;
     unsigned closes; // rows that close a group of MVNDFN (all rows unless the covariance is singular)
-    int flags;       // 1 closed form (value valid), 2 integrand == 1, 4 integrand == 0
+    int flags;       // 1 closed form (value valid), 2 integrand == 1, 4 integrand == 0, 16 skipped, 32 clip_cov groups
+    int ng;          // clip_cov: number of independent groups (flags & 32)
+    int gdraws;      // clip_cov: uniforms the groups' calls consume in total
     double value;
 };
+
+// Early decision without COVSRT.  Whatever order COVSRT picks, the conditional limit of variable a is
+// (lim_a - sum_j c_aj y_j) / c_aa with sum_j c_aj^2 + c_aa^2 = 1 and |y_j| <= 9, i.e. it stays beyond +-37 once
+// |lim_a| > 37 + 9 sqrt(n - 1): one variable on the empty side makes every lattice point contribute exactly 0, all
+// variables on the full side make every point contribute exactly 1 -- the values the full path returns.
+// Returns 4 (== 0), 2 (== 1) or 0 (undecided).
+__device__ int early_decision(int n, const double* lim, unsigned infi) {
+    const double thr = 37.0 + 9.0 * sqrt((double)(n - 1));
+    bool all_full = true, any_empty = false;
+    for (int a = 0; a < n; a++) {
+        const bool lower = (infi >> a) & 1u;
+        const double l = lower ? lim[a] : -lim[a];     // interval [l, inf) in the variable's own direction
+        if (l > thr) any_empty = true;
+        if (!(l < -thr)) all_full = false;
+    }
+    return any_empty ? 4 : (all_full ? 2 : 0);
+}
+
+// Standardised problem (limits lim, packed correlations cov with unit diagonal, n >= 2) -> closed form (n = 2) or the
+// COVSRT-ed slab with its saturation verdict.
+__device__ void finish_call(int n, double* cov, double* lim, double* y, Prep& out) {
+    if (n == 2) {
+        out.value = bvn_orthant(lim[0], lim[1], out.infi & 1u, (out.infi >> 1) & 1u, cov[pidx(1, 0)]);
+        out.flags = 1;
+        return;
+    }
+    covsrt_n(n, cov, lim, y, out.infi);
+    out.closes = group_layout(n, cov);
+    bool sat1 = true, sat0 = false;
+    for (int i = 0; i < n; i++) {
+        double bound = 0;
+        for (int j = 0; j < i; j++) bound += fabs(cov[pidx(i, j)]) * 9.0;
+        const bool lower = (out.infi >> i) & 1u;
+        if (lower) {
+            if (!(lim[i] + bound < -37.0)) sat1 = false;
+            if (lim[i] - bound > 37.0) sat0 = true;
+        } else {
+            if (!(lim[i] - bound > 37.0)) sat1 = false;
+            if (lim[i] + bound < -37.0) sat0 = true;
+        }
+    }
+    if (sat0) out.flags = 4;
+    else if (sat1) out.flags = 2;
+}
+
+// clip_cov (reference ital/ital.py:386-429, :590-616): connected components of |corr| > clip over the n variables, in
+// group_cov's order -- seeds ascending, members in breadth-first layers, each layer ascending.  Writes the member order
+// and the group boundaries; returns the number of groups.
+__device__ int clip_groups(int n, const double* cor, double clip, int* adj, int* gorder, int* gstart) {
+    for (int a = 0; a < n; a++) {
+        unsigned m = 0;
+        for (int b = 0; b < n; b++) {
+            const double c = a == b ? 1.0 : (a > b ? cor[pidx(a, b)] : cor[pidx(b, a)]);
+            if (fabs(c) > clip) m |= 1u << b;
+        }
+        adj[a] = (int)m;
+    }
+    unsigned left = n >= 32 ? 0xffffffffu : ((1u << n) - 1u);
+    int ng = 0, pos = 0;
+    while (left) {
+        gstart[ng] = pos;
+        unsigned newm = (unsigned)adj[__builtin_ctz(left)];
+        unsigned grp = 0;
+        while (newm) {
+            for (unsigned m = newm; m; m &= m - 1) gorder[pos++] = __builtin_ctz(m);
+            grp |= newm;
+            left &= ~newm;
+            unsigned reach = 0;
+            for (unsigned m = grp; m; m &= m - 1) reach |= (unsigned)adj[__builtin_ctz(m)];
+            newm = reach & left;
+        }
+        ng++;
+    }
+    gstart[ng] = pos;
+    return ng;
+}
+
+// Sub-problem of group g of a clip_cov call: singleton -> norm.cdf, pair -> BVU, larger -> standardised slab + COVSRT.
+__device__ Prep build_group(int g, const double* mlim, const double* mcor, unsigned infi_full, const int* gorder,
+                            const int* gstart, double* slab) {
+    Prep out;
+    out.flags = 0; out.value = 0; out.infi = 0; out.closes = 0; out.ng = 0; out.gdraws = 0;
+    const int g0 = gstart[g], n = gstart[g + 1] - g0;
+    out.n = n;
+    if (n == 1) {
+        const int u = gorder[g0];
+        const double q = ndtr(mlim[u]);                       // norm.cdf(0, mean, sd), lim = -mean / sd
+        out.value = ((infi_full >> u) & 1u) ? 1.0 - q : q;
+        out.flags = 1;
+        return out;
+    }
+    double* cov = slab;
+    double* lim = slab + n * (n + 1) / 2;
+    double* y = lim + n;
+    for (int a = 0; a < n; a++) {
+        const int ua = gorder[g0 + a];
+        lim[a] = mlim[ua];
+        out.infi |= ((infi_full >> ua) & 1u) << a;
+        for (int b = 0; b < a; b++) {
+            const int ub = gorder[g0 + b];
+            cov[pidx(a, b)] = ua > ub ? mcor[pidx(ua, ub)] : mcor[pidx(ub, ua)];
+        }
+        cov[pidx(a, a)] = 1.0;
+    }
+    if (ITAL_GEN_EARLY && n >= 3) {
+        const int e = early_decision(n, lim, out.infi);
+        if (e) { out.flags = e; return out; }
+    }
+    finish_call(n, cov, lim, y, out);
+    return out;
+}
 
 // Prepares one call in the lane's slab: cov (packed, n(n+1)/2), lim (n), y (n); scratch fs for the update.
 __device__ Prep prepare_call(const ital_gscore_desc& d, const CallInfo& ci, int nU, int nr, int ldS, const double* muU,
                              const double* SigU, const int* usort, const int* ipos, bool clamp_prior, double* slab,
-                             double* fs) {
+                             double* fs, double* master) {
     Prep out;
-    out.flags = 0; out.value = 0; out.infi = 0; out.closes = 0;
+    out.flags = 0; out.value = 0; out.infi = 0; out.closes = 0; out.ng = 0; out.gdraws = 0;
     const bool subset = d.subset_mode != 0;
     const int n = ci.kind == K_PRIOR_SUB ? nr : nU;
     out.n = n;
@@ -379,21 +493,10 @@ __device__ Prep prepare_call(const ital_gscore_desc& d, const CallInfo& ci, int 
         return out;
     }
     for (int a = 0; a < n; a++) lim[a] = -lim[a] / y[a];
-    if (ITAL_GEN_EARLY && n >= 3) {
-        // Early decision without COVSRT.  Whatever order COVSRT picks, the conditional limit of variable a is
-        // (lim_a - sum_j c_aj y_j) / c_aa with sum_j c_aj^2 + c_aa^2 = 1 and |y_j| <= 9, i.e. it stays beyond +-37 once
-        // |lim_a| > 37 + 9 sqrt(n - 1): one variable on the empty side makes every lattice point contribute exactly 0,
-        // all variables on the full side make every point contribute exactly 1 -- the values the full path returns.
-        const double thr = 37.0 + 9.0 * sqrt((double)(n - 1));
-        bool all_full = true, any_empty = false;
-        for (int a = 0; a < n; a++) {
-            const bool lower = (out.infi >> a) & 1u;
-            const double l = lower ? lim[a] : -lim[a];     // interval [l, inf) in the variable's own direction
-            if (l > thr) any_empty = true;
-            if (!(l < -thr)) all_full = false;
-        }
-        if (any_empty) { out.flags = 4; return out; }
-        if (all_full) { out.flags = 2; return out; }
+    const bool clip_mode = master != nullptr && n > 5;        // prob_rel -> _grouped_prob_rel (ital.py:360-362)
+    if (ITAL_GEN_EARLY && n >= 3 && !clip_mode) {
+        const int e = early_decision(n, lim, out.infi);
+        if (e) { out.flags = e; return out; }
     }
     for (int a = 0; a < n; a++) {
         const int ua = upos_of(a);
@@ -407,28 +510,28 @@ __device__ Prep prepare_call(const ital_gscore_desc& d, const CallInfo& ci, int 
         }
     }
     for (int a = 0; a < n; a++) cov[pidx(a, a)] = 1.0;
-    if (n == 2) {
-        out.value = bvn_orthant(lim[0], lim[1], out.infi & 1u, (out.infi >> 1) & 1u, cov[pidx(1, 0)]);
-        out.flags = 1;
-        return out;
-    }
-    covsrt_n(n, cov, lim, y, out.infi);
-    out.closes = group_layout(n, cov);
-    bool sat1 = true, sat0 = false;
-    for (int i = 0; i < n; i++) {
-        double bound = 0;
-        for (int j = 0; j < i; j++) bound += fabs(cov[pidx(i, j)]) * 9.0;
-        const bool lower = (out.infi >> i) & 1u;
-        if (lower) {
-            if (!(lim[i] + bound < -37.0)) sat1 = false;
-            if (lim[i] - bound > 37.0) sat0 = true;
-        } else {
-            if (!(lim[i] - bound > 37.0)) sat1 = false;
-            if (lim[i] + bound < -37.0) sat0 = true;
+    if (clip_mode) {
+        double* mlim = master;
+        double* mcor = master + n;
+        int* adj = reinterpret_cast<int*>(mcor + n * (n + 1) / 2);
+        int* gorder = adj + n;
+        int* gstart = gorder + n;
+        const int ng = clip_groups(n, cov, d.clip_cov, adj, gorder, gstart);
+        if (ng > 1) {
+            for (int a = 0; a < n; a++) mlim[a] = lim[a];
+            for (int e = 0; e < n * (n + 1) / 2; e++) mcor[e] = cov[e];
+            int draws = 0;
+            for (int g = 0; g < ng; g++) {
+                const int sz = gstart[g + 1] - gstart[g];
+                if (sz >= 3) draws += 8 * (2 * (sz - 1) - 1);
+            }
+            out.flags = 32;
+            out.ng = ng;
+            out.gdraws = draws;
+            return out;
         }
     }
-    if (sat0) out.flags = 4;
-    else if (sat1) out.flags = 2;
+    finish_call(n, cov, lim, y, out);
     return out;
 }
 
@@ -602,6 +705,30 @@ __device__ __forceinline__ void wave_sync() {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
+// The 8 randomly shifted lattices of one call of dimension n, generated by the calling lane from the generator state
+// `base` advanced by `before` uniforms.
+__device__ void make_lattice(const ital_gscore_desc& d, const MrgState& base, unsigned before, int n, double* L) {
+    MrgState sti = base;
+    for (int bit = 0; before != 0; bit++, before >>= 1)
+        if (before & 1u) mrg_apply(sti, d.jump1 + bit * 18);
+    MrgStateF st = mrg_to_f(sti);
+    const int ndim = n - 1;
+    for (int j = 0; j < ndim; j++) L[j] = d.vk[n * GN + j];
+    for (int sft = 0; sft < 8; sft++) {
+        double* row = L + sft * ndim;
+        if (sft > 0)
+            for (int j = 0; j < ndim; j++) row[j] = row[j - ndim];
+        for (int j = 1; j <= ndim - 1; j++) {
+            const double u = mrg_next_f(st);
+            const int jp = (int)(j + u * (ndim + 1 - j));
+            const double xt = row[j - 1];
+            row[j - 1] = row[jp - 1];
+            row[jp - 1] = xt;
+        }
+        for (int j = 0; j < ndim; j++) L[8 * ndim + sft * ndim + j] = mrg_next_f(st);
+    }
+}
+
 #ifndef ITAL_GEN_WAVES
 #define ITAL_GEN_WAVES 3
 #endif
@@ -678,22 +805,24 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(ITAL_GEN_WA
     const bool clamp_prior = !subset && nr == 1;   // first greedy step: predict_stored(cov_mode='diag') (ital.py:558)
 
     double mi = 0.0, pr_cur = 0.0, logpr_cur = 0.0;
+    int64_t cand_draws = 0;     // uniforms this candidate's calls consume (reported by the counting pass)
     for (int chunk0 = 0; chunk0 < total; chunk0 += a.chunk) {
         // ---------------- Phase B: lane l prepares call chunk0 + l
         Prep pp;
-        pp.n = 0; pp.infi = 0; pp.flags = 0; pp.value = 0; pp.closes = 0;
+        pp.n = 0; pp.infi = 0; pp.flags = 0; pp.value = 0; pp.closes = 0; pp.ng = 0; pp.gdraws = 0;
         if (lane < a.chunk && chunk0 + lane < total) {
             const CallInfo ci = decode_call(d, p, chunk0 + lane, cpp, npre, nr, npat);
             double* slab = slabs + (size_t)lane * a.stride;
             if (ci.kind == K_SKIP) { pp.flags = 16; }
-            else pp = prepare_call(d, ci, nU, nr, ldS, muU, SigU, usort, ipos, clamp_prior, slab, slab + a.slab);
+            else pp = prepare_call(d, ci, nU, nr, ldS, muU, SigU, usort, ipos, clamp_prior, slab, slab + a.slab,
+                                       a.master ? slab + a.master : nullptr);
         }
         // lattices of the calls that are evaluated, generated lane-parallel: every dimension >= 3 call (evaluated or
         // saturated) takes 8*(2*NDIM-1) uniforms from MVNUNI; lane l jumps ahead by what the calls before it in this chunk
         // consume, the wave's base state by the chunk's total
         {
-            const bool draws_any = pp.n >= 3 && !(pp.flags & (1 | 16));
-            const int my_draws = draws_any ? 8 * (2 * (pp.n - 1) - 1) : 0;
+            const bool draws_any = pp.n >= 3 && !(pp.flags & (1 | 16 | 32));
+            const int my_draws = (pp.flags & 32) ? pp.gdraws : (draws_any ? 8 * (2 * (pp.n - 1) - 1) : 0);
             int incl = my_draws;
 #pragma unroll
             for (int off = 1; off < 64; off <<= 1) {
@@ -701,27 +830,58 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(ITAL_GEN_WA
                 if (lane >= off) incl += o;
             }
             const int total_draws = __builtin_amdgcn_readlane(incl, 63);
-            if (draws_any && !(pp.flags & 6)) {
-                MrgState sti = rng;
-                unsigned before = (unsigned)(incl - my_draws);
-                for (int bit = 0; before != 0; bit++, before >>= 1)
-                    if (before & 1u) mrg_apply(sti, d.jump1 + bit * 18);
-                MrgStateF st = mrg_to_f(sti);
-                const int ndim = pp.n - 1;
-                double* L = slabs + (size_t)lane * a.stride + a.lat;
-                for (int j = 0; j < ndim; j++) L[j] = d.vk[pp.n * GN + j];
-                for (int sft = 0; sft < 8; sft++) {
-                    double* row = L + sft * ndim;
-                    if (sft > 0)
-                        for (int j = 0; j < ndim; j++) row[j] = row[j - ndim];
-                    for (int j = 1; j <= ndim - 1; j++) {
-                        const double u = mrg_next_f(st);
-                        const int jp = (int)(j + u * (ndim + 1 - j));
-                        const double xt = row[j - 1];
-                        row[j - 1] = row[jp - 1];
-                        row[jp - 1] = xt;
+            cand_draws += total_draws;
+            if (d.draw_count) {      // counting pass: only the stream consumption is wanted
+                wave_sync();
+                continue;
+            }
+            const unsigned call_base = (unsigned)(incl - my_draws);
+            if (draws_any && !(pp.flags & 6))
+                make_lattice(d, rng, call_base, pp.n, slabs + (size_t)lane * a.stride + a.lat);
+            // clip_cov: calls that fall apart into independent groups (ital.py:413-429) are evaluated group by group --
+            // pass g prepares group g of every such call in the call's slab, the wave evaluates the ones that need the
+            // lattice rule, and the product of the group probabilities turns the call into a closed-form one
+            if (__any((pp.flags & 32) != 0)) {
+                int maxg = (pp.flags & 32) ? pp.ng : 0;
+#pragma unroll
+                for (int off = 32; off > 0; off >>= 1) {
+                    const int o = __shfl_xor(maxg, off, 64);
+                    maxg = o > maxg ? o : maxg;
+                }
+                double gprod = 1.0;
+                unsigned gdone = 0;
+                for (int g = 0; g < maxg; g++) {
+                    Prep gp;
+                    gp.n = 0; gp.infi = 0; gp.flags = 64; gp.value = 1.0; gp.closes = 0; gp.ng = 0; gp.gdraws = 0;
+                    if ((pp.flags & 32) && g < pp.ng) {
+                        double* slab = slabs + (size_t)lane * a.stride;
+                        const double* mlim = slab + a.master;
+                        const double* mcor = mlim + pp.n;
+                        const int* gorder = reinterpret_cast<const int*>(mcor + pp.n * (pp.n + 1) / 2) + pp.n;
+                        gp = build_group(g, mlim, mcor, pp.infi, gorder, gorder + pp.n, slab);
+                        if (gp.n >= 3) {
+                            if (!(gp.flags & 7)) make_lattice(d, rng, call_base + gdone, gp.n, slab + a.lat);
+                            gdone += 8 * (2 * (gp.n - 1) - 1);
+                        }
                     }
-                    for (int j = 0; j < ndim; j++) L[8 * ndim + sft * ndim + j] = mrg_next_f(st);
+                    wave_sync();
+                    double gval = (gp.flags & 1) ? gp.value : ((gp.flags & 2) ? 1.0 : ((gp.flags & 4) ? 0.0 : 1.0));
+                    for (int cl = 0; cl < a.chunk; cl++) {
+                        const int fl_c = __builtin_amdgcn_readlane(gp.flags, cl);
+                        if (fl_c != 0) continue;     // inactive, closed form or saturated
+                        const int n_c = __builtin_amdgcn_readlane(gp.n, cl);
+                        const unsigned infi_c = (unsigned)__builtin_amdgcn_readlane((int)gp.infi, cl);
+                        const unsigned closes_c = (unsigned)__builtin_amdgcn_readlane((int)gp.closes, cl);
+                        const double* slab_c = slabs + (size_t)cl * a.stride;
+                        const double v = qmc_eval<NMAX, NH>(n_c, slab_c, infi_c, closes_c, slab_c + a.lat, lane, tailq);
+                        if (lane == cl) gval = v;
+                    }
+                    if (!(gp.flags & 64)) gprod *= gval;
+                    wave_sync();
+                }
+                if (pp.flags & 32) {
+                    pp.value = gprod;
+                    pp.flags = 1;
                 }
             }
             unsigned adv = (unsigned)total_draws;
@@ -769,6 +929,10 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(ITAL_GEN_WA
         }
         wave_sync();
     }
+    if (d.draw_count) {
+        if (lane == 0) d.draw_count[p] = cand_draws;
+        return;
+    }
     if (d.mc_rel > 0) mi /= d.mc_rel;   // ital.py:221-222
     if (lane == 0) d.mi[p] = mi;
 }
@@ -803,7 +967,9 @@ extern "C" int ital_score_generic(const ital_gscore_desc* d, hipStream_t stream)
     GArgs a;
     a.d = *d;
     const int slab = nUmax * (nUmax + 1) / 2 + 2 * nUmax;
-    int stride = slab + fs_doubles(nr) + 16 * (nUmax - 1);
+    const bool clip = d->clip_cov > 0 && d->clip_cov < 1 && nUmax > 5;
+    const int master = clip ? slab + 2 * nUmax + 2 : 0;     // limits, packed correlations, adjacency / order / boundaries
+    int stride = slab + fs_doubles(nr) + 16 * (nUmax - 1) + master;
     stride |= 1;
     int chunk = 64;
     while (chunk > 4 && chunk * stride > 1536) chunk >>= 1;   // ~14 KB of LDS per wave (measured best: 16 preparing lanes at t = 4)
@@ -811,6 +977,7 @@ extern "C" int ital_score_generic(const ital_gscore_desc* d, hipStream_t stream)
     a.stride = stride;
     a.slab = slab;
     a.lat = slab + fs_doubles(nr);
+    a.master = clip ? slab + fs_doubles(nr) + 16 * (nUmax - 1) : 0;
     const int fixed = nUmax + nUmax * nUmax + (GN + GR + 1) / 2 + 256;
     a.ldS = nUmax;
     a.wave_doubles = fixed + chunk * stride;

@@ -93,8 +93,6 @@ class ITAL(ActiveRetrievalBase):
             return "change_estimation_subset=None (the whole candidate set as estimation subset)"
         sub = self.change_estimation_subset if self.change_estimation_subset > 0 else 0
         max_dim = sub + k
-        if self.clip_cov and 0 < self.clip_cov < 1 and max_dim > 5:
-            return "clip_cov with orthant dimensions above 5 (grouped probabilities, reference ital.py:386-429)"
         if self._needs_generic():
             if max_dim > ITAL_GENERIC_MAX_DIM:
                 return "orthant dimension %d (subset + batch) above %d" % (max_dim, ITAL_GENERIC_MAX_DIM)
@@ -112,8 +110,12 @@ class ITAL(ActiveRetrievalBase):
         return None
 
     def _needs_generic(self):
-        return (self._subset_mode() or not self._perfect_user() or self.force_generic
+        return (self._subset_mode() or not self._perfect_user() or self.force_generic or self._clip_active()
                 or self.monte_carlo_num_rel is not None or self.monte_carlo_num_fb is not None)
+
+    def _clip_active(self):
+        """clip_cov only ever acts on orthants of more than 5 dimensions, between 0 and 1 (reference ital.py:360)."""
+        return bool(self.clip_cov) and 0 < self.clip_cov < 1
 
     def _mark(self, stage=None, t=0, size=0, start=None):
         """HIP event on the launch stream (only when bench.py asked for per-kernel timings).  Events come from
@@ -346,6 +348,7 @@ class ITAL(ActiveRetrievalBase):
                 desc.label_prob, desc.mistake_prob = float(self.label_prob), float(self.mistake_prob)
                 desc.label_mode = _LABEL_MODES[self.label_estimation]
                 desc.noise, desc.eps = float(self.noise), float(self.eps)
+                desc.clip_cov = float(self.clip_cov) if self._clip_active() else 0.0
                 for j in range(6):
                     desc.seed[j] = stream.state[j]
                 desc.jump1, desc.vk = _ptr(jump1), _ptr(vk)
@@ -366,6 +369,23 @@ class ITAL(ActiveRetrievalBase):
                     t_off = torch.from_numpy(np.ascontiguousarray(off[lo:hi])).to(dev)
                     desc.draw_off = _ptr(t_off)
                     total_draws = int(draws_pp.sum())
+                if self._clip_active() and nE + 1 > 5:
+                    # with clip_cov the number of mvndst calls (one per group of correlated variables) and hence the
+                    # stream consumption depends on the data: a counting pass of the same kernel reports it per candidate
+                    counts = torch.zeros(max(n_loc, 1), dtype=torch.int64, device=dev)
+                    desc.draw_count = _ptr(counts)
+                    check(lib.ital_score_generic(ctypes.byref(desc), st))
+                    desc.draw_count = None
+                    local_total = counts.sum().reshape(1)
+                    if gp.collective:
+                        totals = sharding.all_gather_parts(local_total, [1] * gp.world, gp.group)
+                    else:
+                        totals = local_total
+                    totals_h = totals.cpu().tolist()
+                    lower = sum(totals_h[: gp.rank]) if gp.collective else 0
+                    t_off = torch.cumsum(counts, 0) - counts + lower
+                    desc.draw_off = _ptr(t_off)
+                    total_draws = int(sum(totals_h))
                 ev0 = self._mark()
                 check(lib.ital_score_generic(ctypes.byref(desc), st))
                 self._mark("score_generic", t, n_alive, ev0)

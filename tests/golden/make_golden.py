@@ -50,6 +50,8 @@ FIXTURES = {
                          kw=dict(label_prob=0.7, mistake_prob=0.1, monte_carlo_num_fb=2)),
     "synth50_mcboth": dict(data="synth", rows=50, d=5, ls=None, k=4, rounds=1, learner="ITAL",
                            kw=dict(label_prob=1.0, mistake_prob=0.2, monte_carlo_num_rel=2, monte_carlo_num_fb=1)),
+    "synth50_clip": dict(data="synth", rows=50, d=4, ls=None, k=3, rounds=2, learner="ITAL",
+                         kw=dict(change_estimation_subset=4, clip_cov=0.35)),
     "usps500_mcmi": dict(data="usps", rows=500, ls=3.0, k=3, rounds=2, learner="MCMI_min",
                          kw=dict(subsample=150)),
     "synth300_mcmi": dict(data="synth", rows=300, d=16, ls=None, k=3, rounds=2, learner="MCMI_min", kw={}),

@@ -115,7 +115,7 @@ def test_golden_fixture(dev, golden_dir, name):
 
 
 @pytest.mark.parametrize("name", ["synth200_noisy", "synth200_motivated", "iris_ce5", "synth80_mcrel", "synth60_mcfb",
-                                  "synth50_mcboth"])
+                                  "synth50_mcboth", "synth50_clip"])
 def test_golden_fixture_general_scorer(dev, golden_dir, name):
     """Noisy user models (general / motivated), the change-estimation subset and the Monte-Carlo switches
     (patterns / feedback sampled from numpy's global RNG in the reference's order): ital_score_generic."""
@@ -174,6 +174,8 @@ def test_against_oracle(dev, seed, n, d, k, mode):
     (9, 40, 4, 4, dict(change_estimation_subset=3, monte_carlo_num_rel=1)),
     (10, 26, 3, 15, dict(monte_carlo_num_rel=1)),          # orthant dimensions up to 15 (lattice prime 1361)
     (11, 24, 3, 5, dict(change_estimation_subset=12)),     # subset + batch = 17 dimensions
+    (12, 36, 3, 7, dict(clip_cov=0.4)),                    # grouped orthant probabilities from the sixth pick on
+    (13, 30, 3, 3, dict(change_estimation_subset=6, clip_cov=0.25, label_prob=0.7, mistake_prob=0.1)),
 ])
 def test_general_scorer_against_oracle(dev, seed, n, d, k, kw):
     from oracle import mvn as omvn
@@ -290,10 +292,7 @@ def test_api_edge_cases(dev):
         M = ITAL(X, length_scale=0.7, change_estimation_subset=None, device=dev)   # whole candidate set as subset
         M.update({0: 1})
         M.fetch_unlabelled(2)
-    with pytest.raises(NotImplementedError):
-        M = ITAL(X, length_scale=0.7, clip_cov=0.5, change_estimation_subset=4, device=dev)   # grouped orthants
-        M.update({0: 1})
-        M.fetch_unlabelled(3)
+
 
 
 def test_gp_attributes_of_the_reference(dev):
