@@ -85,14 +85,19 @@ class ITAL(ActiveRetrievalBase):
             nfb = num_fb if fb_mc else 3 ** nr - 1
         return rel_mc, npat, fb_mc, nfb
 
-    def _unsupported(self, k):
+    def _unsupported(self, k, n_unseen=0):
         """Reason why the device scorers cannot run this configuration (None if they can)."""
         if self.label_estimation not in _LABEL_MODES:
             return "label_estimation=%r" % (self.label_estimation,)
         if self.change_estimation_subset is None:
-            return "change_estimation_subset=None (the whole candidate set as estimation subset)"
-        sub = self.change_estimation_subset if self.change_estimation_subset > 0 else 0
-        max_dim = sub + k
+            # the whole candidate set is the estimation subset (ital.py:103-104): every orthant spans all candidates
+            if n_unseen > ITAL_GENERIC_MAX_DIM:
+                return ("change_estimation_subset=None with %d candidates: orthants of that dimension (limit %d)"
+                        % (n_unseen, ITAL_GENERIC_MAX_DIM))
+            sub, max_dim = n_unseen, n_unseen
+        else:
+            sub = self.change_estimation_subset if self.change_estimation_subset > 0 else 0
+            max_dim = sub + k
         if self._needs_generic():
             if max_dim > ITAL_GENERIC_MAX_DIM:
                 return "orthant dimension %d (subset + batch) above %d" % (max_dim, ITAL_GENERIC_MAX_DIM)
@@ -142,7 +147,9 @@ class ITAL(ActiveRetrievalBase):
         if candidates is None:
             candidates = self._unseen_array()
         # change-estimation subset: drawn from the unrestricted candidate list on the global numpy RNG (ital.py:103-108)
-        if self.change_estimation_subset is not None and self.change_estimation_subset > 0:
+        if self.change_estimation_subset is None:
+            self._ce_subset = [int(i) for i in candidates]
+        elif self.change_estimation_subset > 0:
             self._ce_subset = sorted(int(i) for i in np.random.choice(
                 candidates, min(len(candidates), self.change_estimation_subset), replace=False))
         else:
@@ -170,7 +177,7 @@ class ITAL(ActiveRetrievalBase):
         k = min(int(k), len(unseen))
         if k <= 0:
             return []
-        why = self._unsupported(k)
+        why = self._unsupported(k, len(unseen))
         if why is not None:
             raise NotImplementedError("ital_amd device scorer: %s is not implemented" % why)
         candidates = self._candidate_list(unseen)

@@ -174,6 +174,7 @@ def test_against_oracle(dev, seed, n, d, k, mode):
     (9, 40, 4, 4, dict(change_estimation_subset=3, monte_carlo_num_rel=1)),
     (10, 26, 3, 15, dict(monte_carlo_num_rel=1)),          # orthant dimensions up to 15 (lattice prime 1361)
     (11, 24, 3, 5, dict(change_estimation_subset=12)),     # subset + batch = 17 dimensions
+    (14, 14, 3, 3, dict(change_estimation_subset=None)),   # the whole (small) candidate set as estimation subset
     (12, 36, 3, 7, dict(clip_cov=0.4)),                    # grouped orthant probabilities from the sixth pick on
     (13, 30, 3, 3, dict(change_estimation_subset=6, clip_cov=0.25, label_prob=0.7, mistake_prob=0.1)),
 ])
@@ -289,7 +290,7 @@ def test_api_edge_cases(dev):
     L.reset()
     assert L.rounds == 0 and L.gp.m == 0 and L.rel_mean is None
     with pytest.raises(NotImplementedError):
-        M = ITAL(X, length_scale=0.7, change_estimation_subset=None, device=dev)   # whole candidate set as subset
+        M = ITAL(rng.random((60, 6)), length_scale=0.7, change_estimation_subset=None, device=dev)   # 59-dimensional orthants
         M.update({0: 1})
         M.fetch_unlabelled(2)
 

@@ -111,7 +111,8 @@ def test_unsupported_option_combinations_are_named():
     assert "larger than 16" in _bare_ital(monte_carlo_num_rel=1)._unsupported(17)
     assert _bare_ital(change_estimation_subset=5)._unsupported(4) is None
     assert "dimension" in _bare_ital(change_estimation_subset=18)._unsupported(4)
-    assert "change_estimation_subset=None" in _bare_ital(change_estimation_subset=None)._unsupported(2)
+    assert "change_estimation_subset=None" in _bare_ital(change_estimation_subset=None)._unsupported(2, 500)
+    assert _bare_ital(change_estimation_subset=None)._unsupported(2, 15) is None
     assert _bare_ital(clip_cov=0.5)._unsupported(6) is None and _bare_ital(clip_cov=0.5)._needs_generic()
     assert not _bare_ital(clip_cov=1.5)._needs_generic()                    # outside (0, 1): no effect (ital.py:360)
     assert "label_estimation" in _bare_ital(label_estimation="median")._unsupported(2)
