@@ -90,6 +90,41 @@ def hbm_stream_probe(device, rows=1_000_000, d=DIM, m=21, reps=10):
             "note": "same kernel as the greedy steps' cross-covariance column, at 1M rows (2.2 GB per launch)"}
 
 
+def other_workloads(X, rel, device):
+    """Secondary timings on the same synthetic data (rank 0, N = 1 only; not part of `value`): the general scorer with a
+    noisy user (reference configs usps-mistakes / mirflickr-mistakes style) and MCMI_min with the reference's subsample."""
+    import torch
+    from ital_amd import ITAL, MCMI_min, mvn_stream
+    out = {}
+
+    def timed(learner, rounds, k):
+        learner.update({0: 1})
+        ret = learner.fetch_unlabelled(k)                 # warm-up round
+        learner.update({int(i): float(rel[i]) for i in ret})
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        scored = 0
+        for _ in range(rounds):
+            n_c = len(learner.get_unseen())
+            ret = learner.fetch_unlabelled(k)
+            learner.update({int(i): float(rel[i]) for i in ret})
+            scored += sum(n_c - t for t in range(k))
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        return {"ms_per_round": dt / rounds * 1e3, "candidates_per_s": scored / dt}
+
+    mvn_stream.GLOBAL.reset()
+    out["ital_general_user_k4"] = dict(timed(ITAL(X, length_scale=LENGTH_SCALE, label_prob=0.5, mistake_prob=0.25,
+                                                  device=device), 2, BATCH),
+                                       config="label_prob 0.5, mistake_prob 0.25: 3^t - 1 feedback configurations per pattern")
+    np.random.seed(0)
+    m = MCMI_min(X, length_scale=LENGTH_SCALE, subsample=1000, device=device)
+    r = timed(m, 5, BATCH)
+    r["candidates_per_s"] = BATCH * 1000 / (r["ms_per_round"] * 1e-3)
+    out["mcmi_min_subsample1000_k4"] = dict(r, config="MCMI_min, subsample 1000 (reference configs/usps.conf)")
+    return out
+
+
 def pmc_traffic(kernel_prefix):
     """HBM bytes per launch of a kernel out of the committed PMC summary (profiles/, collected with tools/profile_gpu.sh
     in separate passes and corrected as MI355X_MICROARCH.md prescribes), or None."""
@@ -246,6 +281,8 @@ def main():
                "roofline": roof, "roofline_hbm": hbm_stream_probe(device) if world == 1 else roof_hbm,
                "roofline_hbm_at_workload_size": roof_hbm,
                "kernel_ms": {"%s_t%d" % k: float(np.mean([d for d, _ in v])) * 1e3 for k, v in sorted(prof.items())}}
+        if world == 1 and not os.environ.get("ITAL_BENCH_NO_EXTRAS"):
+            out["other_workloads"] = other_workloads(X, rel, device)
         out["cpu_baseline"] = cpu_base
         if cpu_base:
             out["speedup_vs_cpu_baseline"] = out["value"] / cpu_base["value"]
