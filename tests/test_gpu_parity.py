@@ -339,6 +339,34 @@ def test_updated_prediction_api(dev):
     assert A.gp.m == 3                                                # the model itself is untouched
 
 
+def test_small_and_degenerate_candidate_sets(dev):
+    """One candidate, k above the number of candidates, every scorer path; nothing left to fetch."""
+    from oracle import mvn as omvn
+    from oracle.ital import OracleITAL
+    ITAL, _, mvn_stream = _learners()
+    rng = np.random.default_rng(17)
+    X = rng.random((7, 3))
+    for kw in (dict(), dict(label_prob=0.7, mistake_prob=0.2), dict(change_estimation_subset=2), dict(monte_carlo_num_rel=1)):
+        mvn_stream.GLOBAL.reset()
+        omvn.rng_reset()
+        A = ITAL(X, length_scale=0.6, device=dev, **kw)
+        B = OracleITAL(X, length_scale=0.6, **kw)
+        lab = {0: 1, 1: -1, 2: 1}
+        A.update(lab)
+        B.update(lab)
+        np.random.seed(5)
+        got = A.fetch_unlabelled(6)                      # 4 candidates only
+        np.random.seed(5)
+        want = [int(i) for i in B.fetch_unlabelled(6)]
+        assert got == want and sorted(got) == [3, 4, 5, 6], kw
+        A.update({i: 1 for i in got[:3]})
+        B.update({i: 1 for i in got[:3]})
+        assert A.fetch_unlabelled(3) == [int(i) for i in B.fetch_unlabelled(3)] == [got[3]]      # a single candidate
+        A.update({got[3]: -1})
+        assert A.fetch_unlabelled(2) == [] and A.get_unseen() == []
+        assert mvn_stream.GLOBAL.draws == omvn.rng_draws()
+
+
 def test_queries_constructor(dev):
     from oracle.ital import OracleITAL
     ITAL, _, _ = _learners()
