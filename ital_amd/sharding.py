@@ -46,7 +46,7 @@ def gather_records(record, out, group=None):
         for w in range(world):
             out[w].copy_(host[w])
         return out
-    dist.all_gather(list(out.unbind(0)), record, group=group)
+    dist.all_gather_into_tensor(out.view(-1), record, group=group)   # one contiguous [world * R] receive buffer
     return out
 
 
