@@ -165,6 +165,20 @@ __device__ void resolve_body(const double* __restrict__ records, int world, int 
     for (int q = threadIdx.x; q < b.ldw; q += blockDim.x) b.VB[(int64_t)slot * b.ldw + q] = r[ITAL_REC_HEADER + b.ldx + q];
 }
 
+// Local arg-extreme and record in one single-workgroup launch (small problems: the two-stage reduction above costs a
+// launch more than it saves).
+__global__ __launch_bounds__(1024) void select_local_small_kernel(const double* __restrict__ mi, const uint8_t* __restrict__ alive,
+                                                                  int64_t n_cand, RecordArgs a) {
+    Best v = {0.0, -1};
+    for (int64_t p = threadIdx.x; p < n_cand; p += blockDim.x) {
+        if (!alive[p]) continue;
+        Best c = {mi[p], a.pos_offset + p};
+        if (better(c, v, a.mode)) v = c;
+    }
+    v = block_best(v, a.mode);
+    record_body(a, v);
+}
+
 __global__ __launch_bounds__(256) void select_resolve_kernel(const double* __restrict__ records, int world, int rec_len,
                                                              int rank, int mode, int slot, ital_batch b,
                                                              uint8_t* __restrict__ alive, int64_t* __restrict__ ret) {
@@ -200,6 +214,12 @@ extern "C" int ital_select_local(const double* mi, const int32_t* cand, const ui
                                  double* work, double* record, hipStream_t stream) {
     if (mode != 0 && mode != 1) return ital_fail(-22, "ital_select_local: mode must be 0 (argmax) or 1 (argmin)");
     if (m > ldw) return ital_fail(-22, "ital_select_local: m exceeds ldw");
+    if (n_cand <= (1 << 18)) {
+        RecordArgs a1 = {cand, pos_offset, row_offset, rank, mode, 0, mu, s2, X, xnorm, ldx, V, ldv, m, ldw,
+                         C, ldc, nprev, kmax, nullptr, record};
+        hipLaunchKernelGGL(select_local_small_kernel, dim3(1), dim3(1024), 0, stream, mi, alive, n_cand, a1);
+        return ital_check_launch("ital_select_local(small)");
+    }
     int nparts = (int)((n_cand + 255) / 256);
     if (nparts > 1024) nparts = 1024;
     if (nparts < 1) nparts = 1;
