@@ -363,6 +363,7 @@ __device__ Prep build_group(int g, const double* mlim, const double* mcor, unsig
 }
 
 // Prepares one call in the lane's slab: cov (packed, n(n+1)/2), lim (n), y (n); scratch fs for the update.
+template <bool CLIP>
 __device__ Prep prepare_call(const ital_gscore_desc& d, const CallInfo& ci, int nU, int nr, int ldS, const double* muU,
                              const double* SigU, const int* usort, const int* ipos, bool clamp_prior, double* slab,
                              double* fs, double* master) {
@@ -493,7 +494,7 @@ __device__ Prep prepare_call(const ital_gscore_desc& d, const CallInfo& ci, int 
         return out;
     }
     for (int a = 0; a < n; a++) lim[a] = -lim[a] / y[a];
-    const bool clip_mode = master != nullptr && n > 5;        // prob_rel -> _grouped_prob_rel (ital.py:360-362)
+    const bool clip_mode = CLIP && master != nullptr && n > 5;        // prob_rel -> _grouped_prob_rel (ital.py:360-362)
     if (ITAL_GEN_EARLY && n >= 3 && !clip_mode) {
         const int e = early_decision(n, lim, out.infi);
         if (e) { out.flags = e; return out; }
@@ -510,7 +511,7 @@ __device__ Prep prepare_call(const ital_gscore_desc& d, const CallInfo& ci, int 
         }
     }
     for (int a = 0; a < n; a++) cov[pidx(a, a)] = 1.0;
-    if (clip_mode) {
+    if (CLIP && clip_mode) {
         double* mlim = master;
         double* mcor = master + n;
         int* adj = reinterpret_cast<int*>(mcor + n * (n + 1) / 2);
@@ -732,7 +733,7 @@ __device__ void make_lattice(const ital_gscore_desc& d, const MrgState& base, un
 #ifndef ITAL_GEN_WAVES
 #define ITAL_GEN_WAVES 3
 #endif
-template <int NMAX, int NH, int TFIX>
+template <int NMAX, int NH, int TFIX, bool CLIP>
 __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(ITAL_GEN_WAVES, ITAL_GEN_WAVES))) void score_generic_kernel(GArgs a) {
     extern __shared__ double lds_all[];
     const ital_gscore_desc& d = a.d;
@@ -814,8 +815,8 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(ITAL_GEN_WA
             const CallInfo ci = decode_call(d, p, chunk0 + lane, cpp, npre, nr, npat);
             double* slab = slabs + (size_t)lane * a.stride;
             if (ci.kind == K_SKIP) { pp.flags = 16; }
-            else pp = prepare_call(d, ci, nU, nr, ldS, muU, SigU, usort, ipos, clamp_prior, slab, slab + a.slab,
-                                       a.master ? slab + a.master : nullptr);
+            else pp = prepare_call<CLIP>(d, ci, nU, nr, ldS, muU, SigU, usort, ipos, clamp_prior, slab, slab + a.slab,
+                                             (CLIP && a.master) ? slab + a.master : nullptr);
         }
         // lattices of the calls that are evaluated, generated lane-parallel: every dimension >= 3 call (evaluated or
         // saturated) takes 8*(2*NDIM-1) uniforms from MVNUNI; lane l jumps ahead by what the calls before it in this chunk
@@ -841,7 +842,7 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(ITAL_GEN_WA
             // clip_cov: calls that fall apart into independent groups (ital.py:413-429) are evaluated group by group --
             // pass g prepares group g of every such call in the call's slab, the wave evaluates the ones that need the
             // lattice rule, and the product of the group probabilities turns the call into a closed-form one
-            if (__any((pp.flags & 32) != 0)) {
+            if (CLIP && __any((pp.flags & 32) != 0)) {
                 int maxg = (pp.flags & 32) ? pp.ng : 0;
 #pragma unroll
                 for (int off = 32; off > 0; off >>= 1) {
@@ -986,26 +987,32 @@ extern "C" int ital_score_generic(const ital_gscore_desc* d, hipStream_t stream)
     const int64_t blocks = (d->n_cand + 1) / 2;
     // plain mode (no subset): every call of dimension >= 3 has dimension n_picks + 1 -> compile-time evaluator
     const int tfix = (!d->subset_mode && nUmax >= 3 && nUmax <= 6) ? nUmax : 0;
-#define ITAL_GEN_LAUNCH(NMAX_, NH_, TFIX_)                                                                             \
+#define ITAL_GEN_LAUNCH(NMAX_, NH_, TFIX_, CLIP_)                                                                             \
     do {                                                                                                               \
         static bool attr_done = false;                                                                                 \
         if (!attr_done) {                                                                                              \
-            if (hipFuncSetAttribute(reinterpret_cast<const void*>(&score_generic_kernel<NMAX_, NH_, TFIX_>),            \
+            if (hipFuncSetAttribute(reinterpret_cast<const void*>(&score_generic_kernel<NMAX_, NH_, TFIX_, CLIP_>),            \
                                     hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)             \
                 return ital_fail(-12, "ital_score_generic: cannot raise the dynamic LDS limit");                        \
             attr_done = true;                                                                                          \
         }                                                                                                              \
-        hipLaunchKernelGGL((score_generic_kernel<NMAX_, NH_, TFIX_>), dim3((unsigned)blocks), dim3(128), lds, stream, a); \
+        hipLaunchKernelGGL((score_generic_kernel<NMAX_, NH_, TFIX_, CLIP_>), dim3((unsigned)blocks), dim3(128), lds, stream, a); \
     } while (0)
-    switch (tfix) {
-        case 3: ITAL_GEN_LAUNCH(6, 2, 3); break;
-        case 4: ITAL_GEN_LAUNCH(6, 2, 4); break;
-        case 5: ITAL_GEN_LAUNCH(6, 2, 5); break;
-        case 6: ITAL_GEN_LAUNCH(6, 2, 6); break;
-        default:
-            if (nUmax <= 6) ITAL_GEN_LAUNCH(6, 2, 0);
-            else if (nUmax <= 12) ITAL_GEN_LAUNCH(12, ITAL_GEN_NH12, 0);
-            else ITAL_GEN_LAUNCH(ITAL_GENERIC_MAX_DIM, 1, 0);
+    if (clip) {     // grouped probabilities: the instantiations that carry the group passes
+        if (nUmax <= 6) ITAL_GEN_LAUNCH(6, 2, 0, true);
+        else if (nUmax <= 12) ITAL_GEN_LAUNCH(12, ITAL_GEN_NH12, 0, true);
+        else ITAL_GEN_LAUNCH(ITAL_GENERIC_MAX_DIM, 1, 0, true);
+    } else {
+        switch (tfix) {
+            case 3: ITAL_GEN_LAUNCH(6, 2, 3, false); break;
+            case 4: ITAL_GEN_LAUNCH(6, 2, 4, false); break;
+            case 5: ITAL_GEN_LAUNCH(6, 2, 5, false); break;
+            case 6: ITAL_GEN_LAUNCH(6, 2, 6, false); break;
+            default:
+                if (nUmax <= 6) ITAL_GEN_LAUNCH(6, 2, 0, false);
+                else if (nUmax <= 12) ITAL_GEN_LAUNCH(12, ITAL_GEN_NH12, 0, false);
+                else ITAL_GEN_LAUNCH(ITAL_GENERIC_MAX_DIM, 1, 0, false);
+        }
     }
 #undef ITAL_GEN_LAUNCH
     return ital_check_launch("ital_score_generic");
