@@ -34,6 +34,9 @@
 #ifndef ITAL_GEN_NH12
 #define ITAL_GEN_NH12 1   // lattice items per lane and round of the runtime-dimension evaluator up to 12 dimensions
 #endif
+#ifndef ITAL_GEN_NOINLINE
+#define ITAL_GEN_NOINLINE __attribute__((noinline))   // keeps the preparation's registers out of the evaluation loop's budget
+#endif
 #ifndef ITAL_GEN_EARLY
 #define ITAL_GEN_EARLY 1   // decide saturated calls from the standardised limits, before COVSRT
 #endif
@@ -328,7 +331,7 @@ __device__ int clip_groups(int n, const double* cor, double clip, int* adj, int*
 }
 
 // Sub-problem of group g of a clip_cov call: singleton -> norm.cdf, pair -> BVU, larger -> standardised slab + COVSRT.
-__device__ Prep build_group(int g, const double* mlim, const double* mcor, unsigned infi_full, const int* gorder,
+__device__ ITAL_GEN_NOINLINE Prep build_group(int g, const double* mlim, const double* mcor, unsigned infi_full, const int* gorder,
                             const int* gstart, double* slab) {
     Prep out;
     out.flags = 0; out.value = 0; out.infi = 0; out.closes = 0; out.ng = 0; out.gdraws = 0;
@@ -364,7 +367,7 @@ __device__ Prep build_group(int g, const double* mlim, const double* mcor, unsig
 
 // Prepares one call in the lane's slab: cov (packed, n(n+1)/2), lim (n), y (n); scratch fs for the update.
 template <bool CLIP>
-__device__ Prep prepare_call(const ital_gscore_desc& d, const CallInfo& ci, int nU, int nr, int ldS, const double* muU,
+__device__ ITAL_GEN_NOINLINE Prep prepare_call(const ital_gscore_desc& d, const CallInfo& ci, int nU, int nr, int ldS, const double* muU,
                              const double* SigU, const int* usort, const int* ipos, bool clamp_prior, double* slab,
                              double* fs, double* master) {
     Prep out;
@@ -708,7 +711,7 @@ __device__ __forceinline__ void wave_sync() {
 
 // The 8 randomly shifted lattices of one call of dimension n, generated by the calling lane from the generator state
 // `base` advanced by `before` uniforms.
-__device__ void make_lattice(const ital_gscore_desc& d, const MrgState& base, unsigned before, int n, double* L) {
+__device__ ITAL_GEN_NOINLINE void make_lattice(const ital_gscore_desc& d, const MrgState& base, unsigned before, int n, double* L) {
     MrgState sti = base;
     for (int bit = 0; before != 0; bit++, before >>= 1)
         if (before & 1u) mrg_apply(sti, d.jump1 + bit * 18);
