@@ -734,10 +734,10 @@ __device__ ITAL_GEN_NOINLINE void make_lattice(const ital_gscore_desc& d, const 
 }
 
 #ifndef ITAL_GEN_WAVES
-#define ITAL_GEN_WAVES 3
+#define ITAL_GEN_WAVES(TFIX) ((TFIX) > 0 ? 3 : 2)   // measured: compile-time-dimension evaluator 3 waves per SIMD, runtime one 2 (spills)
 #endif
 template <int NMAX, int NH, int TFIX, bool CLIP>
-__global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(ITAL_GEN_WAVES, ITAL_GEN_WAVES))) void score_generic_kernel(GArgs a) {
+__global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(ITAL_GEN_WAVES(TFIX), ITAL_GEN_WAVES(TFIX)))) void score_generic_kernel(GArgs a) {
     extern __shared__ double lds_all[];
     const ital_gscore_desc& d = a.d;
     const int lane = threadIdx.x & 63;
