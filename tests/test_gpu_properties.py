@@ -110,3 +110,36 @@ def test_mcmi_is_deterministic_and_permutation_equivariant(dev):
     assert r1 == r2 and all(np.array_equal(a, b, equal_nan=True) for a, b in zip(s1, s2))
     rp, _ = run(X[perm], inv[17])
     assert [int(perm[i]) for i in rp] == r1
+
+
+def test_one_million_candidates(dev):
+    """BASELINE config 5's row count on one GPU (n = 1e6, d = 32, k = 3): 64-bit item / offset arithmetic, determinism,
+    and the closed-form first step against the host formula on the device's own mean and variance."""
+    from scipy.special import ndtr
+    from ital_amd import ITAL, mvn_stream
+    n, d = 1_000_000, 32
+    X = np.random.default_rng(0).random((n, d), dtype=np.float64)
+    picks = []
+    for _ in range(2):
+        mvn_stream.GLOBAL.reset()
+        L = ITAL(X, length_scale=float(np.sqrt(d / 12.0)), device=dev)
+        L.keep_scores = True
+        L.update({7: 1, 500_000: -1, 999_999: 1})
+        picks.append(L.fetch_unlabelled(3))
+    assert picks[0] == picks[1] and len(set(picks[0])) == 3 and not set(picks[0]) & {7, 500_000, 999_999}
+    mu, var = L.gp.predict_stored(cov_mode="diag")
+    s0 = L.last_scores[0].cpu().numpy()                     # list position -> data index: the three labelled rows are cut out
+    cand = np.setdiff1d(np.arange(n), [7, 500_000, 999_999])
+    sub = np.random.default_rng(1).choice(len(cand), 2000, replace=False)
+    m, v = mu[cand[sub]], var[cand[sub]]
+    p_irr = ndtr(-m / np.sqrt(v))
+    su = v                                                   # variance is far from the clamp on this data
+    g = su / (su + 1e-6)
+    mi = np.zeros(len(sub))
+    for f, pr in ((-1.0, p_irr), (1.0, 1.0 - p_irr)):
+        mu_u = m + g * (f - m)
+        q = ndtr(-mu_u / np.sqrt(1e-6 * g))
+        pu = q if f < 0 else 1.0 - q
+        mi += pr * (np.log(pu + 1e-12) - np.log(pr + 1e-12))
+    np.testing.assert_allclose(s0[sub], mi, rtol=1e-9, atol=1e-12)
+    assert cand[int(np.argmax(np.where(np.isnan(s0), -np.inf, s0)))] == picks[0][0]
