@@ -146,3 +146,31 @@ def test_stream_tables_are_consistent():
     assert st == s.peek(37)
     vk = ms.vk_table(6)
     assert np.all(vk[:3] == 0) and np.array_equal(vk[5, :4], ms.korobov_vk(5))
+
+
+def test_ctypes_structs_have_the_layout_of_the_header(tmp_path):
+    """sizeof / offsetof of every descriptor as gcc lays out include/ital_hip.h against the ctypes mirrors."""
+    import ctypes
+    import subprocess
+    from ital_amd import _lib
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    probes = {"ital_batch": (_lib.ItalBatch, ["kmax", "bidx", "VB"]),
+              "ital_score_desc": (_lib.ItalScoreDesc, ["t", "batch", "label_mode", "seed", "jumplane", "status", "seeds"]),
+              "ital_gscore_desc": (_lib.ItalGscoreDesc, ["n_cand", "nE", "ldE", "pick_pos", "label_prob", "clip_cov", "seed",
+                                                         "draws_in", "dead_pos", "fb_samples", "draw_count", "status"]),
+              "ital_mcmi_desc": (_lib.ItalMcmiDesc, ["t", "alive", "ld_cov", "batch", "ce"])}
+    lines = []
+    for name, (_, fields) in probes.items():
+        lines.append('printf("%s %%zu\\n", sizeof(%s));' % (name, name))
+        for f in fields:
+            lines.append('printf("%s.%s %%zu\\n", offsetof(%s, %s));' % (name, f, name, f))
+    src = tmp_path / "layout.c"
+    src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "ital_hip.h"\nint main(void) {\n' + "\n".join(lines)
+                   + "\nreturn 0; }\n")
+    exe = tmp_path / "layout"
+    subprocess.check_call(["gcc", "-I", os.path.join(root, "include"), str(src), "-o", str(exe)])
+    got = dict(line.split() for line in subprocess.check_output([str(exe)], text=True).splitlines())
+    for name, (cls, fields) in probes.items():
+        assert int(got[name]) == ctypes.sizeof(cls), name
+        for f in fields:
+            assert int(got["%s.%s" % (name, f)]) == getattr(cls, f).offset, (name, f)
