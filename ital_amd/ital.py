@@ -181,6 +181,10 @@ class ITAL(ActiveRetrievalBase):
         if why is not None:
             raise NotImplementedError("ital_amd device scorer: %s is not implemented" % why)
         candidates = self._candidate_list(unseen)
+        if len(candidates) < k:
+            # k was clamped to the number of unseen samples BEFORE the top_candidates restriction (ital.py:99-117): the
+            # reference runs out of candidates in its greedy loop and np.argmax([]) raises exactly this (ital.py:130)
+            raise ValueError("attempt to get argmax of an empty sequence")
         if self._needs_generic():
             return self._fetch_generic(k, candidates)
         lib = _lib.lib()

@@ -287,6 +287,11 @@ def test_api_edge_cases(dev):
     rest = L.fetch_unlabelled(8)                    # only 6 unseen samples are left
     assert len(rest) == 6 and sorted(rest + ret + [0, 1, 2]) == list(range(12))
     assert L.top_results(3).tolist() == np.argsort(L.rel_mean)[::-1][:3].tolist()
+    T = ITAL(X, length_scale=0.7, top_candidates=2, device=dev)
+    T.update({0: 1})
+    assert len(T.fetch_unlabelled(2)) == 2
+    with pytest.raises(ValueError, match="empty sequence"):     # more picks than top_candidates allows: np.argmax([])
+        T.fetch_unlabelled(3)
     L.reset()
     assert L.rounds == 0 and L.gp.m == 0 and L.rel_mean is None
     with pytest.raises(NotImplementedError):
