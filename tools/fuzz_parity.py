@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Randomised differential test: device learners against the oracle over random sizes and option combinations
 (every scorer path).  Not part of the pytest suite (run time); prints one line per case and a summary.
-    python tools/fuzz_parity.py [cases] [seed]"""
+    python tools/fuzz_parity.py [cases] [seed] [only-case]      (a third argument reruns one case verbosely)"""
 import os
 import sys
 import time
@@ -16,9 +16,12 @@ from oracle.ital import OracleITAL, OracleMCMI  # noqa: E402
 
 cases = int(sys.argv[1]) if len(sys.argv) > 1 else 20
 seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+only = int(sys.argv[3]) if len(sys.argv) > 3 else None
 bad = 0
 t_start = time.time()
 for case in range(cases):
+    if only is not None and case != only:
+        continue
     rng = np.random.default_rng(seed0 * 1000 + case)
     n = int(rng.integers(12, 90))
     d = int(rng.integers(2, 10))
@@ -66,22 +69,41 @@ for case in range(cases):
     status = "ok"
     try:
         for rnd in range(2):
-            np.random.seed(case * 7 + rnd)
-            got = A.fetch_unlabelled(k)
-            np.random.seed(case * 7 + rnd)
-            want = [int(i) for i in B.fetch_unlabelled(k)]
+            def fetch(learner):
+                np.random.seed(case * 7 + rnd)
+                try:
+                    return [int(i) for i in learner.fetch_unlabelled(k)], None
+                except ValueError as e:            # top_candidates below k: np.argmax([]) in the reference (ital.py:130)
+                    return None, str(e)
+            got, err_a = fetch(A)
+            want, err_b = fetch(B)
+            if err_a or err_b:
+                if not (err_a and err_b and "empty sequence" in err_a and "empty sequence" in err_b):
+                    status = "ERRORS differ: %r vs %r" % (err_a, err_b)
+                break
             cand0 = B.trace[0][0]
             pos = {c: i for i, c in enumerate(cand0)}
             worst = 0.0
             for t, (cand, vals, _) in enumerate(B.trace):
                 mine = A.last_scores[t].cpu().numpy()[[pos[c] for c in cand]]
                 keep = np.array([c not in twin for c in cand])
+                # a twin inside the change-estimation subset or the batch so far puts the same degeneracy into every
+                # candidate's problem (observed: a common 1e-5 shift of all scores): loosen the tolerance for the step
+                fixed = set(int(i) for i in (getattr(B, "_ce_subset", None) or [])) | set(want[:t])
+                tol_t = 1e-3 if (twin & fixed) else 1e-5
                 mine, vals = mine[keep], vals[keep]
                 both = ~(np.isnan(mine) | np.isnan(vals))
                 if not np.array_equal(np.isnan(mine), np.isnan(vals)):
                     status = "NAN-MISMATCH"
+                if only is not None:
+                    print("round", rnd, "step", t, "ce subset", getattr(B, "_ce_subset", None), "twins", sorted(twin))
+                    for c, a_, b_ in zip(np.array(cand)[keep], mine, vals):
+                        print("   cand %3d  device % .12e  oracle % .12e  rel %.2e" % (c, a_, b_, abs(a_ - b_) / max(abs(b_), 1e-9)))
                 if both.any():
-                    worst = max(worst, float(np.max(np.abs(mine[both] - vals[both]) / np.maximum(np.abs(vals[both]), 1e-9))))
+                    worst = max(worst, float(np.max(np.abs(mine[both] - vals[both]) / np.maximum(np.abs(vals[both]), 1e-9))) * 1e-5 / tol_t)
+            if got != want and [int(inv.ravel()[i]) for i in got] == [int(inv.ravel()[i]) for i in want]:
+                status = "ok"                       # a tie between identical rows resolved the other way: same batch
+                break
             if got != want:
                 status = "PICKS %s != %s" % (got, want)
             elif worst > 1e-5:
@@ -93,17 +115,6 @@ for case in range(cases):
             B.update(fb)
         if kind != "mcmi" and status == "ok" and mvn_stream.GLOBAL.draws != omvn.rng_draws():
             status = "STREAM %d != %d" % (mvn_stream.GLOBAL.draws, omvn.rng_draws())
-    except ValueError as e:
-        # top_candidates below k: the reference itself fails with np.argmax([]) (ital.py:130) -- both sides must
-        ok_both = "empty sequence" in str(e)
-        if ok_both:
-            try:
-                np.random.seed(case * 7)
-                (A if "A_raised" not in locals() else B).fetch_unlabelled(k)
-                ok_both = False
-            except ValueError:
-                pass
-        status = "ok" if ok_both else "EXC ValueError: %s" % str(e)[:80]
     except Exception as e:  # noqa: BLE001
         status = "EXC %s: %s" % (type(e).__name__, str(e)[:80])
     bad += status != "ok"
