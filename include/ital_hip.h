@@ -158,6 +158,17 @@ int ital_cov_block(const double* Xa, const double* an, int64_t na, const double*
                    int ldx, const double* Va, int64_t ldva, const double* Vb, int64_t ldvb, int m, double var,
                    double length_scale, double* out, int64_t ldo, hipStream_t stream);
 
+/* out[i] (+)= sum_j |k(a_i, b_j) - Va[:,i].Vb[:,j]| without materialising the block (same FP64 MFMA tiles as
+ * ital_cov_block; partial sums per column split in `work`, at least na doubles, summed in a fixed order).  With
+ * `accumulate` the sums are added to out[] (column blocks of other ranks arriving one at a time).
+ * Replaces the N x N product |alpha_diff . K_all[[T, i], :]|.mean() of EMOC.emoc_scores, reference
+ * ital/baseline_methods.py:361-376: the model output change of candidate i is |(+-1 - mu_i) / (s2_i + noise)| times
+ * the mean absolute posterior covariance of i with all samples. */
+int ital_cov_abs_rowsum(const double* Xa, const double* an, int64_t na, const double* Xb, const double* bn, int64_t nb,
+                        int ldx, const double* Va, int64_t ldva, const double* Vb, int64_t ldvb, int m, double var,
+                        double length_scale, double* work, int64_t work_len, int accumulate, double* out,
+                        hipStream_t stream);
+
 typedef struct ital_mcmi_desc {
     int t;                  /* batch dimension of this greedy step */
     int64_t n_i;            /* candidates scored by this rank: block positions pos_offset .. pos_offset + n_i - 1 */
@@ -200,7 +211,9 @@ typedef struct ital_gscore_desc {
     int n_picks;            /* picks so far (enumerated together with the candidate) */
     const int32_t* pick_pos;/* [n_picks] their positions in E, selection order */
     int subset_mode;        /* 0: MutualInformation._call_iter_all, 1: _call_iter_sub (reference ital/ital.py:183-275) */
-    int fb_mode;            /* 0 perfect user, 1 label_prob >= 1 with mistakes, 2 general (reference ital/ital.py:300-342) */
+    int fb_mode;            /* 0 perfect user, 1 label_prob >= 1 with mistakes, 2 general (reference ital/ital.py:300-342);
+                               3 no simulated feedback: mi[] receives the batch entropy -sum_r p(r) log p(r) of
+                               EntropySampling (reference ital/baseline_methods.py:243-287) */
     double label_prob, mistake_prob;
     int label_mode;         /* 0 mean, 1 optimistic, 2 pessimistic (subset_mode 0 only) */
     double noise, eps;

@@ -69,6 +69,9 @@ SIGNATURES = {
     "ital_score_step": (c_int, [ctypes.POINTER(ItalScoreDesc), c_void_p]),
     "ital_cov_block": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_int, c_void_p, c_int64,
                                c_void_p, c_int64, c_int, c_double, c_double, c_void_p, c_int64, c_void_p]),
+    "ital_cov_abs_rowsum": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_int, c_void_p, c_int64,
+                                    c_void_p, c_int64, c_int, c_double, c_double, c_void_p, c_int64, c_int, c_void_p,
+                                    c_void_p]),
     "ital_mcmi_score_step": (c_int, [ctypes.POINTER(ItalMcmiDesc), c_void_p]),
     "ital_score_generic": (c_int, [ctypes.POINTER(ItalGscoreDesc), c_void_p]),
     "ital_select_local": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int64, c_int, c_int, c_void_p,

@@ -46,13 +46,16 @@ struct CovArgs {
 #endif
 constexpr int COV_MI = ITAL_COV_MI, COV_MJ = ITAL_COV_MJ;
 
+// ROWSUM: instead of storing the block, a workgroup walks the column tiles blockIdx.x, blockIdx.x + gridDim.x, ... and
+// keeps sum_j |Sigma_ij| of its rows; out[blockIdx.x * ldo + i] receives the partial sum of that column split (summed in
+// a fixed order by rowsum_reduce_kernel: no floating-point atomics, the result does not depend on scheduling).
+template <bool ROWSUM>
 __global__ __launch_bounds__(256) void cov_block_kernel(CovArgs a) {
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
     const int col = lane & 15;
     const int kg = lane >> 4;
     const int64_t i0 = (int64_t)blockIdx.y * (64 * COV_MI) + wave * (16 * COV_MI);
-    const int64_t j0 = (int64_t)blockIdx.x * (16 * COV_MJ);
     if (i0 >= a.na) return;
     const double* arow[COV_MI];
     const double* brow[COV_MJ];
@@ -64,6 +67,15 @@ __global__ __launch_bounds__(256) void cov_block_kernel(CovArgs a) {
         a_ok[p] = ia[p] < a.na;
         arow[p] = a.Xa + (a_ok[p] ? ia[p] : 0) * a.ldx;
     }
+    double rs[COV_MI][4];
+#pragma unroll
+    for (int p = 0; p < COV_MI; p++)
+#pragma unroll
+        for (int reg = 0; reg < 4; reg++) rs[p][reg] = 0.0;
+    const int64_t ntile = (a.nb + 16 * COV_MJ - 1) / (16 * COV_MJ);
+    int64_t jt = blockIdx.x;
+    do {
+    const int64_t j0 = jt * (16 * COV_MJ);
 #pragma unroll
     for (int q = 0; q < COV_MJ; q++) {
         jb[q] = j0 + 16 * q + col;
@@ -139,8 +151,33 @@ __global__ __launch_bounds__(256) void cov_block_kernel(CovArgs a) {
 #pragma unroll
             for (int reg = 0; reg < 4; reg++) {
                 const int64_t i = i0 + 16 * p + kg + 4 * reg;
-                if (i < a.na && b_ok[q]) a.out[i * a.ldo + jb[q]] = acc[p][q][reg];
+                if (ROWSUM) rs[p][reg] += b_ok[q] ? fabs(acc[p][q][reg]) : 0.0;
+                else if (i < a.na && b_ok[q]) a.out[i * a.ldo + jb[q]] = acc[p][q][reg];
             }
+    jt += gridDim.x;
+    } while (ROWSUM && jt < ntile);
+    if (ROWSUM) {
+#pragma unroll
+        for (int p = 0; p < COV_MI; p++)
+#pragma unroll
+            for (int reg = 0; reg < 4; reg++) {
+                double v = rs[p][reg];
+#pragma unroll
+                for (int off = 1; off < 16; off <<= 1) v += __shfl_xor(v, off, 64);
+                const int64_t i = i0 + 16 * p + kg + 4 * reg;
+                if (col == 0 && i < a.na) a.out[(int64_t)blockIdx.x * a.ldo + i] = v;
+            }
+    }
+}
+
+// out[i] = (accumulate ? out[i] : 0) + sum_s part[s][i], s ascending
+__global__ __launch_bounds__(256) void rowsum_reduce_kernel(const double* part, int64_t ld, int nsplit, int64_t n, int accumulate,
+                                                            double* out) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    double v = accumulate ? out[i] : 0.0;
+    for (int s = 0; s < nsplit; s++) v += part[(int64_t)s * ld + i];
+    out[i] = v;
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -311,8 +348,35 @@ extern "C" int ital_cov_block(const double* Xa, const double* an, int64_t na, co
     const int64_t gx = (nb + 16 * COV_MJ - 1) / (16 * COV_MJ), gy = (na + 64 * COV_MI - 1) / (64 * COV_MI);
     if (gy > 65535) return ital_fail(-22, "ital_cov_block: too many rows per call");
     CovArgs a = {Xa, an, na, Xb, bn, nb, ldx, Va, ldva, Vb, ldvb, m, var, -2.0 * length_scale * length_scale, out, ldo};
-    hipLaunchKernelGGL(cov_block_kernel, dim3((unsigned)gx, (unsigned)gy), dim3(256), 0, stream, a);
+    hipLaunchKernelGGL(cov_block_kernel<false>, dim3((unsigned)gx, (unsigned)gy), dim3(256), 0, stream, a);
     return ital_check_launch("ital_cov_block");
+}
+
+extern "C" int ital_cov_abs_rowsum(const double* Xa, const double* an, int64_t na, const double* Xb, const double* bn,
+                                   int64_t nb, int ldx, const double* Va, int64_t ldva, const double* Vb, int64_t ldvb,
+                                   int m, double var, double length_scale, double* work, int64_t work_len, int accumulate,
+                                   double* out, hipStream_t stream) {
+    if (na <= 0) return 0;
+    if (nb <= 0) {
+        if (!accumulate && hipMemsetAsync(out, 0, (size_t)na * sizeof(double), stream) != hipSuccess)
+            return ital_fail(-5, "ital_cov_abs_rowsum: memset failed");
+        return 0;
+    }
+    if (ldx % 16 != 0) return ital_fail(-22, "ital_cov_abs_rowsum: ldx must be a multiple of 16");
+    if (m < 0 || (m > 0 && (!Va || !Vb))) return ital_fail(-22, "ital_cov_abs_rowsum: whitened blocks missing");
+    if (!work || work_len < na) return ital_fail(-22, "ital_cov_abs_rowsum: work area smaller than na doubles");
+    const int64_t ntile = (nb + 16 * COV_MJ - 1) / (16 * COV_MJ), gy = (na + 64 * COV_MI - 1) / (64 * COV_MI);
+    if (gy > 65535) return ital_fail(-22, "ital_cov_abs_rowsum: too many rows per call");
+    // column splits: enough workgroups to fill the 256 CUs several times over, as many as the work area holds
+    int64_t nsplit = (4096 + gy - 1) / gy;
+    if (nsplit > ntile) nsplit = ntile;
+    if (nsplit > work_len / na) nsplit = work_len / na;
+    if (nsplit > 65535) nsplit = 65535;
+    CovArgs a = {Xa, an, na, Xb, bn, nb, ldx, Va, ldva, Vb, ldvb, m, var, -2.0 * length_scale * length_scale, work, na};
+    hipLaunchKernelGGL(cov_block_kernel<true>, dim3((unsigned)nsplit, (unsigned)gy), dim3(256), 0, stream, a);
+    hipLaunchKernelGGL(rowsum_reduce_kernel, dim3((unsigned)((na + 255) / 256)), dim3(256), 0, stream, work, na, (int)nsplit, na,
+                       accumulate, out);
+    return ital_check_launch("ital_cov_abs_rowsum");
 }
 
 extern "C" int ital_mcmi_score_step(const ital_mcmi_desc* d, hipStream_t stream) {

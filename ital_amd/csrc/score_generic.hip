@@ -803,7 +803,8 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(ITAL_GEN_WA
 
     const int npat = d.mc_rel > 0 ? d.mc_rel : (1 << nr);
     const int npre = subset ? 2 : 1;
-    const int nfb = d.fb_mode == 0 ? 1 : (d.mc_fb > 0 ? d.mc_fb : (d.fb_mode == 1 ? (1 << nr) : pow3(nr) - 1));
+    const bool entropy = d.fb_mode == 3;   // batch entropy: prior probabilities only (baseline_methods.py:270-287)
+    const int nfb = entropy ? 0 : (d.fb_mode == 0 ? 1 : (d.mc_fb > 0 ? d.mc_fb : (d.fb_mode == 1 ? (1 << nr) : pow3(nr) - 1)));
     const int cpp = npre + nfb;
     const int total = npat * cpp;
     const bool clamp_prior = !subset && nr == 1;   // first greedy step: predict_stored(cov_mode='diag') (ital.py:558)
@@ -913,7 +914,17 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(ITAL_GEN_WA
                     value = qmc_eval<NMAX, NH>(n_c, slab_c, infi_c, closes_c, slab_c + a.lat, lane, tailq);
             }
             const CallInfo ci = decode_call(d, p, chunk0 + cl, cpp, npre, nr, npat);
-            if (ci.kind == K_PRIOR) {
+            if (entropy) {
+                if (nr == 1) {
+                    // single_entropy (baseline_methods.py:263-267): P(irrelevant) clamped to [1e-8, 1 - 1e-8]
+                    if (ci.pat == 0) {
+                        const double q = fmax(1e-8, fmin(1.0 - 1e-8, value));
+                        mi = q * log(q) + (1.0 - q) * log(1.0 - q);
+                    }
+                } else if (value > 1e-12) {
+                    mi += value * log(value);
+                }
+            } else if (ci.kind == K_PRIOR) {
                 pr_cur = value;
                 logpr_cur = log(value + d.eps);
             } else if (ci.kind == K_PRIOR_SUB) {
@@ -938,6 +949,7 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(ITAL_GEN_WA
         return;
     }
     if (d.mc_rel > 0) mi /= d.mc_rel;   // ital.py:221-222
+    if (entropy) mi = -mi;
     if (lane == 0) d.mi[p] = mi;
 }
 
@@ -958,12 +970,14 @@ extern "C" int ital_score_generic(const ital_gscore_desc* d, hipStream_t stream)
         return ital_fail(-22, "ital_score_generic: more enumerated variables than ITAL_GENERIC_MAX_REL");
     if (!d->subset_mode && d->nE != d->n_picks)
         return ital_fail(-22, "ital_score_generic: without a change-estimation subset the base set is the batch");
-    if (d->fb_mode < 0 || d->fb_mode > 2) return ital_fail(-22, "ital_score_generic: fb_mode must be 0, 1 or 2");
+    if (d->fb_mode < 0 || d->fb_mode > 3) return ital_fail(-22, "ital_score_generic: fb_mode must be 0, 1, 2 or 3");
+    if (d->fb_mode == 3 && (d->subset_mode || d->mc_rel > 0 || d->mc_fb > 0))
+        return ital_fail(-22, "ital_score_generic: the entropy objective enumerates the batch patterns (no subset, no sampling)");
     if ((d->mc_rel > 0 && !d->rel_samples) || (d->mc_fb > 0 && !d->fb_samples))
         return ital_fail(-22, "ital_score_generic: sample lists missing");
     {
         double npat = d->mc_rel > 0 ? (double)d->mc_rel : pow(2.0, nr);
-        double nfb = d->fb_mode == 0 ? 1.0 : (d->mc_fb > 0 ? (double)d->mc_fb : (d->fb_mode == 1 ? pow(2.0, nr) : pow(3.0, nr) - 1));
+        double nfb = d->fb_mode == 3 ? 0.0 : d->fb_mode == 0 ? 1.0 : (d->mc_fb > 0 ? (double)d->mc_fb : (d->fb_mode == 1 ? pow(2.0, nr) : pow(3.0, nr) - 1));
         if (npat * (2 + nfb) > (double)ITAL_GENERIC_MAX_CALLS)
             return ital_fail(-22, "ital_score_generic: more calls per candidate than ITAL_GENERIC_MAX_CALLS (use the monte-carlo switches)");
     }

@@ -63,7 +63,7 @@ def _learners():
     return table
 
 
-BASELINES = ("border_div", "entropy", "EMOC", "SUD", "RBMAL", "TCAL", "USDM", "AdaptAL")
+BASELINES = ("SUD", "RBMAL", "TCAL", "USDM", "AdaptAL")
 
 
 def make_learner(method, data, learner_config, **placement):
@@ -71,8 +71,8 @@ def make_learner(method, data, learner_config, **placement):
     if method not in table:
         if method in BASELINES:
             raise NotImplementedError("learner %r is one of the reference's comparison baselines that are not part of the "
-                                      "MI355X path (ITAL, MCMI and the ranking baselines random / topscoring / border / "
-                                      "var / unc are)" % method)
+                                      "MI355X path (ITAL, MCMI and the GP-sharing baselines random / topscoring / border / "
+                                      "border_div / var / unc / entropy / EMOC are)" % method)
         raise KeyError("unknown learner %r" % method)
     return table[method](data, **learner_config, **placement)
 

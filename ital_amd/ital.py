@@ -30,10 +30,11 @@ _FUSED_SELECT_MAX = 1 << 18   # one rank, up to this many candidates: arg-max + 
 class ITAL(ActiveRetrievalBase):
     """Information-theoretic Active Learning for information retrieval (reference ital/ital.py:12-134).
 
-    Constructor arguments are the reference's (ital.py:15-81).  Options that this round's device scorer does not
-    cover raise NotImplementedError at fetch time instead of silently taking another path: a non-perfect user
-    model (label_prob < 1 or mistake_prob > 0), change_estimation_subset != 0, clip_cov and the Monte-Carlo
-    switches.  `parallelized` is accepted and ignored (the GPU is the parallelism).
+    Constructor arguments are the reference's (ital.py:15-81).  The perfect-user default runs on the specialised
+    scorer (`ital_score_step`); every other option (user models, change-estimation subset, clip_cov, label_estimation,
+    the Monte-Carlo switches) on the general one (`ital_score_generic`).  Configurations beyond the device limits
+    (`_unsupported`) raise NotImplementedError at fetch time instead of silently taking another path.  `parallelized`
+    is accepted and ignored (the GPU is the parallelism).
     """
 
     def __init__(self, data=None, queries=[], length_scale=0.1, var=1.0, noise=1e-6, label_prob=1.0,
@@ -65,6 +66,10 @@ class ITAL(ActiveRetrievalBase):
     def _perfect_user(self):
         return self.label_prob >= 1 and self.mistake_prob <= 0
 
+    def _fb_mode(self):
+        """fb_mode of ital_gscore_desc: which simulated feedback the scorer enumerates (reference ital.py:300-342)."""
+        return 0 if self._perfect_user() else (1 if self.label_prob >= 1 else 2)
+
     def _subset_mode(self):
         return self.change_estimation_subset is None or self.change_estimation_subset > 0
 
@@ -75,7 +80,9 @@ class ITAL(ActiveRetrievalBase):
         rel_mc = num_rel is not None and not (2 ** (nr - 1) < num_rel)
         npat = num_rel if rel_mc else 2 ** nr
         num_fb = nr * self.monte_carlo_num_fb if self.monte_carlo_num_fb is not None else None
-        if fb_mode == 0:
+        if fb_mode == 3:                 # entropy objective: no simulated feedback at all
+            fb_mc, nfb = False, 0
+        elif fb_mode == 0:
             fb_mc, nfb = False, 1
         elif fb_mode == 1:
             fb_mc = num_fb is not None and not (2 ** (nr - 1) < num_fb)
@@ -103,7 +110,7 @@ class ITAL(ActiveRetrievalBase):
                 return "orthant dimension %d (subset + batch) above %d" % (max_dim, ITAL_GENERIC_MAX_DIM)
             if k > ITAL_GENERIC_MAX_REL:
                 return "batches larger than %d with the general scorer" % ITAL_GENERIC_MAX_REL
-            fb_mode = 0 if self._perfect_user() else (1 if self.label_prob >= 1 else 2)
+            fb_mode = self._fb_mode()
             for nr in range(1, k + 1):
                 _, npat, _, nfb = self._mc_plan(nr, fb_mode)
                 if npat * (2 + nfb) > ITAL_GENERIC_MAX_CALLS:
@@ -280,7 +287,7 @@ class ITAL(ActiveRetrievalBase):
         gp = self.gp
         dev = gp.device
         subset_mode = self._ce_subset is not None
-        fb_mode = 0 if self._perfect_user() else (1 if self.label_prob >= 1 else 2)
+        fb_mode = self._fb_mode()
         E = list(self._ce_subset) if subset_mode else []
         kmax_e = len(E) + k
         GN = ITAL_GENERIC_MAX_DIM

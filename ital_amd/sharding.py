@@ -67,6 +67,19 @@ def all_reduce_sum(t, group=None):
     return t
 
 
+def broadcast(t, src, group=None):
+    """In-place broadcast of rank `src`'s tensor (group rank)."""
+    import torch.distributed as dist
+    src_global = dist.get_global_rank(group, src) if group is not None else src
+    if _host_staged(t, group):
+        h = t.cpu()
+        dist.broadcast(h, src=src_global, group=group)
+        t.copy_(h)
+        return t
+    dist.broadcast(t, src=src_global, group=group)
+    return t
+
+
 def all_gather_parts(loc, sizes, group=None):
     """Concatenation over ranks of 1-D shards of the given sizes."""
     import torch

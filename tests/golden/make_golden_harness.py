@@ -18,7 +18,7 @@ sys.path.insert(0, HERE)
 import make_golden  # noqa: E402
 
 NAMES = ["harness_iris", "harness_noisy", "harness_mcmi", "harness_topscoring", "harness_border", "harness_unc", "harness_random",
-         "harness_var"]
+         "harness_var", "harness_emoc", "harness_entropy", "harness_border_div"]
 
 
 def run(name):

@@ -17,6 +17,9 @@ import torch.multiprocessing as mp  # noqa: E402
 HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.join(HERE, "golden"))
 import make_golden  # noqa: E402  (fixture table only)
+import make_golden_baselines  # noqa: E402  (fixture table only)
+
+FIXTURES = dict(make_golden.FIXTURES, **make_golden_baselines.FIXTURES)
 
 
 def _free_port():
@@ -34,9 +37,10 @@ def _worker(rank, world, port, name, out):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         from ital_amd import ITAL, MCMI_min, mvn_stream
+        from ital_amd.baselines import EMOC, EntropySampling
         z = np.load(os.path.join(HERE, "golden", name + ".npz"))
-        spec = make_golden.FIXTURES[name]
-        cls = ITAL if spec["learner"] == "ITAL" else MCMI_min
+        spec = FIXTURES[name]
+        cls = {"ITAL": ITAL, "MCMI_min": MCMI_min, "EMOC": EMOC, "EntropySampling": EntropySampling}[spec["learner"]]
         np.random.seed(0)
         mvn_stream.GLOBAL.reset()
         L = cls(z["X"], length_scale=float(z["length_scale"]), device="cuda:0", rank=rank, world=world,
@@ -53,7 +57,8 @@ def _worker(rank, world, port, name, out):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("name", ["usps500", "synth96_k6", "synth300_mcmi", "usps500_mcmi"])
+@pytest.mark.parametrize("name", ["usps500", "synth96_k6", "synth300_mcmi", "usps500_mcmi", "emoc_synth150",
+                                  "entropy_synth80"])
 def test_two_ranks_match_golden(name):
     if not torch.cuda.is_available():
         pytest.skip("no GPU")
@@ -79,9 +84,10 @@ def _nccl_worker(rank, world, port, name, out):
     dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", 0))
     try:
         from ital_amd import ITAL, MCMI_min, mvn_stream
+        from ital_amd.baselines import EMOC, EntropySampling
         z = np.load(os.path.join(HERE, "golden", name + ".npz"))
-        spec = make_golden.FIXTURES[name]
-        cls = ITAL if spec["learner"] == "ITAL" else MCMI_min
+        spec = FIXTURES[name]
+        cls = {"ITAL": ITAL, "MCMI_min": MCMI_min, "EMOC": EMOC, "EntropySampling": EntropySampling}[spec["learner"]]
         np.random.seed(0)
         mvn_stream.GLOBAL.reset()
         L = cls(z["X"], length_scale=float(z["length_scale"]), device="cuda:0", rank=rank, world=world,

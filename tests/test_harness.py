@@ -66,7 +66,7 @@ def test_simulated_user_consumes_rng_like_the_reference():
 
 def test_baselines_are_rejected_explicitly(tmp_path):
     conf = tmp_path / "b.conf"
-    conf.write_text("[EXPERIMENT]\ndataset = Iris\nmethod = EMOC\nbatch_size = 2\n[Iris]\n")
+    conf.write_text("[EXPERIMENT]\ndataset = Iris\nmethod = SUD\nbatch_size = 2\n[Iris]\n")
     with pytest.raises(NotImplementedError, match="baseline"):
         harness.load_config(str(conf))
 
@@ -94,17 +94,20 @@ def _run(name, learners, ordered=True):
     return learner
 
 
-@pytest.mark.parametrize("name", ["harness_noisy", "harness_mcmi"])
+@pytest.mark.parametrize("name", ["harness_noisy", "harness_mcmi", "harness_emoc", "harness_entropy", "harness_border_div"])
 def test_loop_with_oracle_learners_reproduces_reference_tables(name):
     from oracle import mvn
+    from oracle.baselines import OracleBorderDiv, OracleEMOC, OracleEntropy
     from oracle.ital import OracleITAL, OracleMCMI
     mvn.rng_reset()
-    _run(name, {"ITAL": OracleITAL, "MCMI": OracleMCMI})
+    _run(name, {"ITAL": OracleITAL, "MCMI": OracleMCMI, "EMOC": OracleEMOC, "entropy": OracleEntropy,
+                "border_div": OracleBorderDiv})
 
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("name", ["harness_iris", "harness_noisy", "harness_mcmi", "harness_topscoring", "harness_border",
-                                  "harness_unc", "harness_random", "harness_var"])
+                                  "harness_unc", "harness_random", "harness_var", "harness_emoc", "harness_entropy",
+                                  "harness_border_div"])
 def test_loop_with_device_learners_reproduces_reference_tables(name):
     torch = pytest.importorskip("torch")
     if not torch.cuda.is_available():
