@@ -125,22 +125,38 @@ def other_workloads(X, rel, device):
     return out
 
 
-def pmc_traffic(kernel_prefix):
-    """HBM bytes per launch of a kernel out of the committed PMC summary (profiles/, collected with tools/profile_gpu.sh
-    in separate passes and corrected as MI355X_MICROARCH.md prescribes), or None."""
+def pmc_row(kernel_prefix):
+    """Row of a kernel in the committed PMC summary (profiles/, collected with tools/profile_gpu.sh in separate passes and
+    corrected as MI355X_MICROARCH.md prescribes), or None."""
     import csv
     import glob
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc_summary*.csv")))
+    files = sorted(f for f in glob.glob(os.path.join(ROOT, "profiles", "*pmc_summary*.csv")) if "mcmi" not in f)
     if not files:
         return None
     with open(files[-1], newline="") as f:
         for row in csv.DictReader(f):
             if row["kernel"].startswith(kernel_prefix):
-                try:
-                    return float(row["fetch_bytes_corrected_avg"]) + float(row["write_bytes_avg"])
-                except (KeyError, ValueError):
-                    return None
+                return row
     return None
+
+
+def pmc_traffic(kernel_prefix):
+    """HBM bytes per launch of a kernel (fetch + write), or None."""
+    row = pmc_row(kernel_prefix)
+    try:
+        return float(row["fetch_bytes_corrected_avg"]) + float(row["write_bytes_avg"])
+    except (TypeError, KeyError, ValueError):
+        return None
+
+
+def pmc_valu_issue_frac(kernel_prefix, launch_s):
+    """Share of the chip's vector-issue cycles the kernel's VALU instructions fill: a wave64 instruction holds its SIMD's
+    16 lanes for 4 cycles; 256 CUs x 4 SIMDs at 2.4 GHz.  Instruction count from the committed PMC pass, launch time live."""
+    row = pmc_row(kernel_prefix)
+    try:
+        return float(row["SQ_INSTS_VALU_avg"]) * 4.0 / (1024 * 2.4e9 * launch_s)
+    except (TypeError, KeyError, ValueError):
+        return None
 
 
 def cpu_baseline(X, cores):
@@ -168,6 +184,8 @@ def main():
     ap.add_argument("--batch", type=int, default=4, help="batch size k (experiments)")
     ap.add_argument("--label-prob", type=float, default=1.0, help="user model (experiments; != 1 selects the general scorer)")
     ap.add_argument("--mistake-prob", type=float, default=0.0)
+    ap.add_argument("--force-collectives", action="store_true",
+                    help="one rank, but through the exchange path of N > 1 (1-rank RCCL group): prices the per-step collective")
     args = ap.parse_args()
     globals().update(ROWS_PER_GPU=args.rows, BATCH=args.batch)
 
@@ -185,9 +203,12 @@ def main():
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     group = None
-    if world > 1:
+    if world > 1 or args.force_collectives:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        if args.force_collectives:
+            os.environ["ITAL_FORCE_COLLECTIVES"] = "1"
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
         group = dist.group.WORLD
 
@@ -256,6 +277,7 @@ def main():
                     "traffic": pmc_traffic("void ital::score_qmc_kernel<%d>" % BATCH), "avg_launch_ms": avg_s * 1e3,
                     "pairs_per_s": qmc_pairs(BATCH, avg_c) / avg_s,
                     "flop_per_pair": FLOP_PER_PAIR,
+                    "valu_issue_frac": pmc_valu_issue_frac("void ital::score_qmc_kernel<%d>" % BATCH, avg_s),
                     "note": "transcendental FP64 chains (Phi, Phi^-1): neither HBM nor MFMA bounds this kernel "
                             "(SURVEY.md 8d S-qmc), so the peak is the FP64 vector rate; achieved = algorithmic pairs x "
                             "flops of the isolated chain / launch time; HBM-bound streaming kernel in roofline_hbm"}
