@@ -12,6 +12,8 @@ kernel enqueued on one stream, with no host round trip inside a round:
 Candidates are sharded by rows across ranks; the per-step exchange is ONE fixed-size record per rank.
 """
 import ctypes
+import os
+from concurrent.futures import ThreadPoolExecutor
 
 import numpy as np
 import torch
@@ -24,6 +26,7 @@ from .gp import _pad16, _ptr, _stream
 from .retrieval_base import ActiveRetrievalBase
 
 _LABEL_MODES = {"mean": 0, "optimistic": 1, "pessimistic": 2}
+_HOST_THREADS = max(1, min(16, os.cpu_count() or 1))   # host share of one GPU (Monte-Carlo pattern sampling)
 _FUSED_SELECT_MAX = 1 << 18   # one rank, up to this many candidates: arg-max + record + resolve in a single launch
 
 
@@ -328,6 +331,7 @@ class ITAL(ActiveRetrievalBase):
             picks, pick_pos = [], []
             self.last_scores = []
             n_alive = len(candidates)
+            z_next = None
             for t in range(1, k + 1):
                 nE = len(E)
                 nr = t
@@ -344,7 +348,8 @@ class ITAL(ActiveRetrievalBase):
                 mc = None
                 if rel_mc or fb_mc:
                     mc = self._mc_samples(nr, npat, rel_mc, fb_mc, nfb, fb_mode, cand, picks, pos_of, E, pick_pos, e_mu,
-                                          e_sig, C, subset_mode)
+                                          e_sig, C, subset_mode, z_next, (pos_offset, pos_offset + n_loc))
+                z_next = None
                 dead_pos = [pos_of[q] for q in picks]
                 desc = ItalGscoreDesc()
                 desc.n_cand = n_loc
@@ -414,6 +419,12 @@ class ITAL(ActiveRetrievalBase):
                                             gp.ldv, gp.m, gp.cap, _ptr(C), gp.ldv, nE, b["kmax"], _ptr(b["work"]),
                                             _ptr(b["rec"]), st))
                 recs = sharding.gather_records(b["rec"], b["rec_all"], gp.group) if gp.collective else b["rec"].unsqueeze(0)
+                if t < k:
+                    # the standard normals of the next step's pattern sampling depend on nothing but their count: drawn
+                    # now, while the scorer runs, they are off the critical path (same order on numpy's global generator)
+                    rel_nx, npat_nx, fb_nx, _ = self._mc_plan(nr + 1, fb_mode)
+                    if rel_nx and not fb_nx:
+                        z_next = np.random.standard_normal((n_alive - 1, npat_nx, nr + 1))
                 recs_h = recs.cpu().numpy()          # host synchronisation of this greedy step
                 w = sharding.winner(recs_h, 0)
                 rec = recs_h[w]
@@ -448,10 +459,12 @@ class ITAL(ActiveRetrievalBase):
         gp.check_status()
         return [int(i) for i in picks]
 
-    def _mc_samples(self, nr, npat, rel_mc, fb_mc, nfb, fb_mode, cand, picks, pos_of, E, pick_pos, e_mu, e_sig, C, subset_mode):
+    def _mc_samples(self, nr, npat, rel_mc, fb_mc, nfb, fb_mode, cand, picks, pos_of, E, pick_pos, e_mu, e_sig, C, subset_mode,
+                    z_rel=None, local=None):
         """Sign patterns / feedback configurations of the Monte-Carlo switches, drawn from numpy's global RNG in the
         reference's serial order (per live candidate: one multivariate_normal.rvs, ital.py:297; per pattern one
-        np.random.choice, ital.py:323-337).  Returns per list position: patterns [P, npat] uint32 (or None), feedback
+        np.random.choice, ital.py:323-337).  `z_rel`: the standard normals of this step when the caller drew them ahead
+        (pattern sampling only); `local`: list positions [lo, hi) whose patterns this rank reads.  Returns per list position: patterns [P, npat] uint32 (or None), feedback
         [P, npat, nfb] uint32 (or None), uniforms of mvndst's stream consumed [P] int64."""
         gp = self.gp
         P = len(cand)
@@ -470,16 +483,19 @@ class ITAL(ActiveRetrievalBase):
         d_full = np.array([dpc(int(v)) for v in range(nE + 2)], dtype=np.int64)[n_full]
         npre_draws = (dpc(nr) + d_full) if subset_mode else d_full
         rel_arr = fb_arr = None
-        # ---- mean / covariance of the enumerated variables of every live candidate (ital.py:247-248, :529)
+        # ---- mean / covariance of the enumerated variables of the live candidates (ital.py:247-248, :529); with pattern
+        # sampling alone only of the ones this rank scores (live[jl0:jl1]): nobody reads the other patterns
+        jl0, jl1 = 0, len(live)
+        if rel_mc and not fb_mc and local is not None:
+            jl0, jl1 = int(np.searchsorted(live, local[0])), int(np.searchsorted(live, local[1]))
         if rel_mc:
             mu_all = np.asarray(self.rel_mean, dtype=np.float64)
             s2_all = gp._full(gp.s2)
             pp = list(pick_pos)
             cpick = np.stack([gp._full(C[b]) for b in pp]) if pp else np.zeros((0, gp.n_total))
-            rows = cand[live]
-            L = len(live)
-            mean = np.empty((L, nr))
-            cov = np.empty((L, nr, nr))
+            rows = cand[live[jl0:jl1]]
+            mean = np.empty((len(rows), nr))
+            cov = np.empty((len(rows), nr, nr))
             mean[:, : nr - 1] = e_mu[pp][None, :] if pp else 0
             cov[:, : nr - 1, : nr - 1] = e_sig[np.ix_(pp, pp)][None] if pp else 0
             mean[:, nr - 1] = mu_all[rows]
@@ -488,8 +504,8 @@ class ITAL(ActiveRetrievalBase):
                 cov[:, : nr - 1, nr - 1] = cpick[:, rows].T
                 cov[:, nr - 1, : nr - 1] = cpick[:, rows].T
             if subset_mode:
-                for j in np.flatnonzero(in_e[live] >= 0):          # members of the base set: covariances from E itself
-                    idx = pp + [int(in_e[live[j]])]
+                for j in np.flatnonzero(in_e[live[jl0:jl1]] >= 0):  # members of the base set: covariances from E itself
+                    idx = pp + [int(in_e[live[jl0 + j]])]
                     mean[j] = e_mu[idx]
                     cov[j] = e_sig[np.ix_(idx, idx)]
             elif nr == 1:
@@ -506,13 +522,27 @@ class ITAL(ActiveRetrievalBase):
             cdf = pr.cumsum()
             cdf /= cdf[-1]
 
-        def draw_rel(j0, j1):
-            """multivariate_normal.rvs for live candidates j0..j1-1: numpy's legacy generator = standard normals in
-            order, then x = z . (sqrt(s) v) + mean with (u, s, v) = svd(cov)."""
-            z = np.random.standard_normal((j1 - j0, npat, nr))
-            _, sv, vt = np.linalg.svd(cov[j0:j1])
-            x = z @ (np.sqrt(sv)[:, :, None] * vt) + mean[j0:j1, None, :]
+        def transform(z, j0, j1):
+            _, sv, vt = np.linalg.svd(cov[j0 - jl0:j1 - jl0])
+            x = z @ (np.sqrt(sv)[:, :, None] * vt) + mean[j0 - jl0:j1 - jl0, None, :]
             return ((x > 0) * weights).sum(axis=2).astype(np.uint32)
+
+        def draw_rel(j0, j1, z=None):
+            """multivariate_normal.rvs for live candidates j0..j1-1: numpy's legacy generator = standard normals in
+            order, then x = z . (sqrt(s) v) + mean with (u, s, v) = svd(cov).  The per-candidate LAPACK calls are
+            independent of each other: large stacks are cut into slices for a thread pool (numpy's gufuncs release the
+            GIL; the result is the same bits as one call)."""
+            if z is None:
+                z = np.random.standard_normal((j1 - j0, npat, nr))
+            n = j1 - j0
+            workers = min(_HOST_THREADS, n * nr * nr // 65536)
+            if workers < 2:
+                return transform(z, j0, j1)
+            cuts = np.linspace(0, n, 4 * workers + 1).astype(np.int64)
+            with ThreadPoolExecutor(workers) as pool:
+                parts = list(pool.map(lambda ab: transform(z[ab[0]:ab[1]], j0 + ab[0], j0 + ab[1]),
+                                      zip(cuts[:-1], cuts[1:])))
+            return np.concatenate(parts)
 
         def draw_fb(pats):
             """np.random.choice(vals, (nfb, nr), p) for every pattern of `pats` [..., npat]: uniforms in order."""
@@ -528,7 +558,13 @@ class ITAL(ActiveRetrievalBase):
         L = len(live)
         enum_pats = np.arange(npat, dtype=np.uint32)
         if rel_mc and not fb_mc:
-            rel_live = draw_rel(0, L)
+            # every rank walks the whole stream of normals (the legacy generator cannot jump), but only its own
+            # candidates' patterns are ever read: the decompositions are done for those alone
+            if z_rel is None:
+                z_rel = np.random.standard_normal((L, npat, nr))
+            rel_live = np.zeros((L, npat), dtype=np.uint32)
+            if jl1 > jl0:
+                rel_live[jl0:jl1] = draw_rel(jl0, jl1, z_rel[jl0:jl1])
         elif fb_mc and not rel_mc:
             fb_live = draw_fb(np.broadcast_to(enum_pats, (L, npat)))
         else:

@@ -58,7 +58,7 @@ def _worker(rank, world, port, name, out):
 
 
 @pytest.mark.parametrize("name", ["usps500", "synth96_k6", "synth300_mcmi", "usps500_mcmi", "emoc_synth150",
-                                  "entropy_synth80"])
+                                  "entropy_synth80", "synth80_mcrel", "synth50_mcboth"])
 def test_two_ranks_match_golden(name):
     if not torch.cuda.is_available():
         pytest.skip("no GPU")
