@@ -20,8 +20,12 @@ __device__ __forceinline__ double fma_k(double acc, double x, double K) { return
 // n / d for well-scaled d (polynomial denominators, no zero / inf / subnormal): hardware reciprocal seed, two
 // Newton steps and one residual correction -- ~1 ulp, about half the instructions of the IEEE division expansion.
 __device__ __forceinline__ double fast_div(double n, double d) {
+    // v_rcp_f64 is good to ~2^-23; one Newton step on the reciprocal (2^-46), then the residual correction of the quotient
+    // squares the error once more: <= 1 ulp without a second step on the reciprocal
     double r = __builtin_amdgcn_rcp(d);
+#ifdef ITAL_DIV_TWO_STEPS
     r = fma(fma(-d, r, 1.0), r, r);
+#endif
     r = fma(fma(-d, r, 1.0), r, r);
     double q = n * r;
     return fma(fma(-d, q, n), r, q);
@@ -34,6 +38,7 @@ __device__ __forceinline__ double exp_neg(double x) {
     const double n = rint(x * LOG2E);
     double r = fma(-n, LN2_HI, x);
     r = fma(-n, LN2_LO, r);
+#ifdef ITAL_EXP_TAYLOR13
     double p = 1.0 / 6227020800.0;
     p = fma_k(p, r, 1.0 / 479001600.0);
     p = fma_k(p, r, 1.0 / 39916800.0);
@@ -46,6 +51,19 @@ __device__ __forceinline__ double exp_neg(double x) {
     p = fma_k(p, r, 1.0 / 24.0);
     p = fma_k(p, r, 1.0 / 6.0);
     p = fma(p, r, 0.5);
+#else
+    // exp(r) = 1 + r + r^2 q(r), q of degree 9 fitted on |r| <= ln2/2 (Chebyshev fit, error 1.8e-17 relative to exp)
+    double p = 2.5100375832561321544e-8;
+    p = fma_k(p, r, 2.7620075879983480862e-7);
+    p = fma_k(p, r, 2.7557268480310025341e-6);
+    p = fma_k(p, r, 0.000024801521322368693026);
+    p = fma_k(p, r, 0.00019841269863040545271);
+    p = fma_k(p, r, 0.0013888888917196719077);
+    p = fma_k(p, r, 0.0083333333333300644495);
+    p = fma_k(p, r, 0.041666666666624161903);
+    p = fma_k(p, r, 0.16666666666666667452);
+    p = fma_k(p, r, 0.50000000000000010211);
+#endif
     p = fma(p, r, 1.0);
     p = fma(p, r, 1.0);
     return ldexp(p, (int)n);
@@ -77,17 +95,19 @@ __device__ __forceinline__ double log_pos(double x) {
     return fma(de, LN2_HI, fma(de, LN2_LO, lm));
 }
 
-// sqrt(a) for a in a normal, well-scaled range (here [1e-3, 1e3]): reciprocal-square-root seed, two Goldschmidt steps and a
-// final residual correction (~1 ulp).
+// sqrt(a) for a in a normal, well-scaled range (here [1e-3, 1e3]): reciprocal-square-root seed (~2^-23), one Goldschmidt step (2^-46)
+// and a final residual correction that squares the error again (~1 ulp).
 __device__ __forceinline__ double sqrt_pos(double a) {
     double y = __builtin_amdgcn_rsq(a);
     double g = a * y, h = 0.5 * y;
     double r = fma(-h, g, 0.5);
     g = fma(g, r, g);
     h = fma(h, r, h);
+#ifdef ITAL_SQRT_TWO_STEPS
     r = fma(-h, g, 0.5);
     g = fma(g, r, g);
     h = fma(h, r, h);
+#endif
     const double d = fma(-g, g, a);
     return fma(d, h, g);
 }
