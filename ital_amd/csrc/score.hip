@@ -26,6 +26,10 @@
 #ifndef ITAL_QMC_NH
 #define ITAL_QMC_NH 2      // lattice items per lane and round (each with its antithetic partner)
 #endif
+#ifndef ITAL_QMC_CHUNK_LOG2
+#define ITAL_QMC_CHUNK_LOG2(T) 3   // calls per pass of a wave: 8, one lane per (call, shift) when the lattices are drawn (measured: 4 calls
+                                   // per pass -- twice the work items -- is 14 % slower at t = 3 and 7 % at t = 4: the per-pass preparation costs more than the finer grid gains)
+#endif
 #ifndef ITAL_QMC_WAVES
 #define ITAL_QMC_WAVES(T) ((T) <= 4 ? 3 : 2)   // waves per SIMD the register allocation aims at (measured)
 #endif
@@ -152,8 +156,8 @@ struct Qmc {
     static constexpr int SLAB_RAW = NCOV + 2 * T;            // packed factor, limits, expected values
     static constexpr int SLAB = SLAB_RAW | 1;                 // odd stride: conflict-free per-lane slabs
     static constexpr int NCALLS = 2 << T;                     // 2 * 2^T
-    static constexpr int CHUNK = 8;                           // calls prepared per pass (LDS: slab + lattice per call)
-    static constexpr int CHUNK_LOG2 = 3;
+    static constexpr int CHUNK_LOG2 = ITAL_QMC_CHUNK_LOG2(T);
+    static constexpr int CHUNK = 1 << CHUNK_LOG2;             // calls prepared per pass (LDS: slab + lattice per call), <= 8
     static constexpr int NCHUNK = NCALLS / CHUNK;             // work items a candidate can be split into
     static constexpr int NCOR = T * (T - 1) / 2;
     // wave-shared candidate area (doubles): pivot, correl, mu0', G, sd', then ints perm
@@ -609,7 +613,7 @@ extern "C" int ital_score_step(const ital_score_desc* d, hipStream_t stream) {
     a.nsplit = 1;
     a.part = nullptr;
     if (d->split > 1 && d->partial && d->label_mode == 0) {
-        const int max_split = (2 << d->t) / 8;   // NCALLS / CHUNK
+        const int max_split = (2 << d->t) >> ITAL_QMC_CHUNK_LOG2(d->t);   // NCALLS / CHUNK
         int ns = 1;
         while (ns * 2 <= d->split && ns * 2 <= max_split) ns *= 2;
         a.nsplit = ns;
