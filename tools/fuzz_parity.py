@@ -13,6 +13,8 @@ import torch  # noqa: E402
 from ital_amd import ITAL, MCMI_min, mvn_stream  # noqa: E402
 from oracle import mvn as omvn  # noqa: E402
 from oracle.ital import OracleITAL, OracleMCMI  # noqa: E402
+from oracle.baselines import OracleBorderDiv, OracleEMOC, OracleEntropy  # noqa: E402
+from ital_amd.baselines import EMOC, BorderlineDiversitySampling, EntropySampling  # noqa: E402
 
 cases = int(sys.argv[1]) if len(sys.argv) > 1 else 20
 seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 0
@@ -31,7 +33,7 @@ for case in range(cases):
         X[int(rng.integers(0, n))] = X[int(rng.integers(0, n))]
     ls = float(np.sqrt(d / 12.0) * rng.uniform(0.5, 1.5))
     kw = {}
-    kind = rng.choice(["perfect", "noisy", "motivated", "subset", "mc", "clip", "mcmi", "optimistic", "topcand", "mix"])
+    kind = rng.choice(["perfect", "noisy", "motivated", "subset", "mc", "clip", "mcmi", "optimistic", "topcand", "mix", "emoc", "entropy", "borderdiv"])
     if kind == "noisy":
         kw = dict(label_prob=float(rng.uniform(0.3, 0.9)), mistake_prob=float(rng.uniform(0.0, 0.4)))
     elif kind == "motivated":
@@ -57,7 +59,14 @@ for case in range(cases):
     twin = set(np.flatnonzero(cnt[inv.ravel()] > 1).tolist())
     mvn_stream.GLOBAL.reset()
     omvn.rng_reset()
-    if kind == "mcmi":
+    if kind in ("emoc", "entropy", "borderdiv"):
+        dcls, ocls = {"emoc": (EMOC, OracleEMOC), "entropy": (EntropySampling, OracleEntropy),
+                      "borderdiv": (BorderlineDiversitySampling, OracleBorderDiv)}[kind]
+        if kind == "borderdiv":
+            kw = dict(alpha=float(rng.uniform(0.1, 0.9)))
+        A = dcls(X, length_scale=ls, device="cuda:0", **kw)
+        B = ocls(X, length_scale=ls, **kw)
+    elif kind == "mcmi":
         A = MCMI_min(X, length_scale=ls, subsample=int(rng.integers(8, n)) if rng.random() < 0.5 else None, device="cuda:0")
         B = OracleMCMI(X, length_scale=ls, subsample=A.subsample)
     else:
@@ -81,10 +90,14 @@ for case in range(cases):
                 if not (err_a and err_b and "empty sequence" in err_a and "empty sequence" in err_b):
                     status = "ERRORS differ: %r vs %r" % (err_a, err_b)
                 break
-            cand0 = B.trace[0][0]
-            pos = {c: i for i, c in enumerate(cand0)}
             worst = 0.0
-            for t, (cand, vals, _) in enumerate(B.trace):
+            if kind == "emoc":
+                keep = np.array([c not in twin for c in B.last_candidates])
+                worst = float(np.max(np.abs(A.last_scores[keep] - B.last_scores[keep]) / np.abs(B.last_scores[keep]))) if keep.any() else 0.0
+                worst *= 1e-5 / 1e-7                 # EMOC scores agree to 1e-7
+            traced = [] if kind in ("emoc", "borderdiv") else [(tr[0], tr[1]) for tr in B.trace]
+            pos = {c: i for i, c in enumerate(traced[0][0])} if traced else {}
+            for t, (cand, vals) in enumerate(traced):
                 mine = A.last_scores[t].cpu().numpy()[[pos[c] for c in cand]]
                 keep = np.array([c not in twin for c in cand])
                 # a twin inside the change-estimation subset or the batch so far puts the same degeneracy into every
@@ -113,7 +126,7 @@ for case in range(cases):
             fb = {i: (1 if X[i, 0] > 0.5 else -1) for i in got}
             A.update(fb)
             B.update(fb)
-        if kind != "mcmi" and status == "ok" and mvn_stream.GLOBAL.draws != omvn.rng_draws():
+        if kind not in ("mcmi", "emoc", "entropy", "borderdiv") and status == "ok" and mvn_stream.GLOBAL.draws != omvn.rng_draws():
             status = "STREAM %d != %d" % (mvn_stream.GLOBAL.draws, omvn.rng_draws())
     except Exception as e:  # noqa: BLE001
         status = "EXC %s: %s" % (type(e).__name__, str(e)[:80])
