@@ -50,7 +50,7 @@ def test_gp_update_predict_vs_oracle(dev):
     ref = OracleGP(X, ls)
     perm = rng.permutation(700)
     at = 0
-    for c in (1, 4, 17, 3, 40):  # crosses the 16-row chunking and the capacity growth
+    for c in (1, 4, 17, 3, 40, 70):  # crosses the 16-row chunking, the capacity growth and two 64-column blocks of the factor
         idx = perm[at:at + c].tolist()
         y = np.where(rng.random(c) > 0.5, 1.0, -1.0)
         at += c
