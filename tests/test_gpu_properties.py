@@ -34,18 +34,21 @@ def test_ties_resolve_to_lowest_list_position(dev):
         assert ret[0] < int(best[1]) + 2
 
 
-def test_scores_do_not_depend_on_the_work_item_split(dev):
+@pytest.mark.parametrize("n,k", [(700, 5), (100, 5), (3300, 4)])
+def test_scores_do_not_depend_on_the_work_item_split(dev, n, k):
+    """One wave per candidate against work items of one preparation pass, at sizes below, around and above one
+    scheduling round of the grid."""
     from ital_amd import ITAL, mvn_stream
     rng = np.random.default_rng(2)
-    X = rng.random((700, 12))
+    X = rng.random((n, 12))
     out = []
-    for split in (1, 2, 8):
+    for split in (1, 2, 8, 16):
         mvn_stream.GLOBAL.reset()
         L = ITAL(X, length_scale=1.0, device=dev)
         L.qmc_split = split
         L.keep_scores = True
         L.update({3: 1, 4: -1, 5: 1})
-        ret = L.fetch_unlabelled(5)
+        ret = L.fetch_unlabelled(k)
         out.append((ret, [s.cpu().numpy() for s in L.last_scores], mvn_stream.GLOBAL.draws))
     for ret, scores, draws in out[1:]:
         assert ret == out[0][0] and draws == out[0][2]
