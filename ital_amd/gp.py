@@ -196,28 +196,36 @@ class GaussianProcess(object):
         self.y = y.copy() if self.y is None else np.concatenate((self.y, y))
         return self
 
+    def _owned(self, ind):
+        """Host-side ownership of global indices: (mask as a float64 device column, clamped local indices on the device).
+        Worked out with numpy -- a device-side mask would cost a nonzero() and a host synchronisation per use."""
+        idx = np.asarray([int(i) for i in ind], dtype=np.int64)
+        own = (idx >= self.row0) & (idx < self.row1)
+        loc = np.where(own, idx - self.row0, 0)
+        return (torch.from_numpy(own.astype(np.float64)).to(self.device),
+                torch.from_numpy(loc).to(self.device), bool(own.any()))
+
     def _gather_rows(self, ind):
         """Feature rows of global indices, replicated on every rank (owners contribute, the rest adds zeros)."""
-        idx = torch.as_tensor(ind, dtype=torch.int64, device=self.device)
         if not self.collective:
+            idx = torch.as_tensor(ind, dtype=torch.int64, device=self.device)
             return self.Xd.index_select(0, idx)       # every row is local: no ownership test, no host synchronisation
-        rows = torch.zeros((len(ind), self.ldx), dtype=torch.float64, device=self.device)
-        own = (idx >= self.row0) & (idx < self.row1)
-        if bool(own.any()):
-            rows[own] = self.Xd.index_select(0, idx[own] - self.row0)
-        if self.collective:
-            sharding.all_reduce_sum(rows, self.group)
+        mask, loc, any_own = self._owned(ind)
+        if any_own:
+            rows = self.Xd.index_select(0, loc) * mask[:, None]
+        else:
+            rows = torch.zeros((len(ind), self.ldx), dtype=torch.float64, device=self.device)
+        sharding.all_reduce_sum(rows, self.group)
         return rows
 
     def gather_columns(self, mat, ind):
         """mat[:, local column of each global index] replicated on every rank ([rows, len(ind)]); `mat` holds one column
         per local data row (V, or covariance columns)."""
-        idx = torch.as_tensor([int(i) for i in ind], dtype=torch.int64, device=self.device)
-        out = torch.zeros((mat.shape[0], len(idx)), dtype=torch.float64, device=self.device)
-        own = (idx >= self.row0) & (idx < self.row1)
-        if bool(own.any()):
-            sel = torch.nonzero(own).squeeze(1)
-            out[:, sel] = mat.index_select(1, idx[own] - self.row0)
+        mask, loc, any_own = self._owned(ind)
+        if any_own:
+            out = mat.index_select(1, loc) * mask[None, :]
+        else:
+            out = torch.zeros((mat.shape[0], len(loc)), dtype=torch.float64, device=self.device)
         if self.collective:
             sharding.all_reduce_sum(out, self.group)
         return out

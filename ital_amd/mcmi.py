@@ -58,21 +58,24 @@ class MCMI_min(ActiveRetrievalBase):
         dev = gp.device
         nc = len(cand)
         ldc = _pad16(nc)
-        idx = torch.as_tensor(cand, dtype=torch.int64, device=dev)
-        own = (idx >= gp.row0) & (idx < gp.row1)
-        loc = idx[own] - gp.row0
         Xc = torch.zeros((nc, gp.ldx), dtype=torch.float64, device=dev)
         Vc = torch.zeros((max(gp.m, 1), ldc), dtype=torch.float64, device=dev)
         vec = torch.zeros((3, nc), dtype=torch.float64, device=dev)  # |x|^2, mean, variance
         if not gp.collective:
+            loc = torch.as_tensor(np.asarray(cand, dtype=np.int64) - gp.row0, dtype=torch.int64, device=dev)
             Xc.copy_(gp.Xd.index_select(0, loc))
             Vc[: gp.m, :nc] = gp.V[: gp.m].index_select(1, loc)
             vec[0], vec[1], vec[2] = gp.xnorm[loc], gp.mu[loc], gp.s2[loc]
         else:
-            Xc[own] = gp.Xd.index_select(0, loc)
-            sel = torch.nonzero(own).squeeze(1)
-            Vc[: gp.m, sel] = gp.V[: gp.m].index_select(1, loc)
-            vec[0, sel], vec[1, sel], vec[2, sel] = gp.xnorm[loc], gp.mu[loc], gp.s2[loc]
+            # ownership worked out on the host (a device-side mask costs a nonzero() and a synchronisation per use)
+            cand_h = np.asarray(cand, dtype=np.int64)
+            sel_h = np.flatnonzero((cand_h >= gp.row0) & (cand_h < gp.row1))
+            if len(sel_h):
+                sel = torch.from_numpy(sel_h).to(dev)
+                loc = torch.from_numpy(cand_h[sel_h] - gp.row0).to(dev)
+                Xc[sel] = gp.Xd.index_select(0, loc)
+                Vc[: gp.m, sel] = gp.V[: gp.m].index_select(1, loc)
+                vec[0, sel], vec[1, sel], vec[2, sel] = gp.xnorm[loc], gp.mu[loc], gp.s2[loc]
             for buf in (Xc, Vc, vec):
                 sharding.all_reduce_sum(buf, gp.group)
         return Xc, Vc, ldc, vec[0].contiguous(), vec[1].contiguous(), vec[2].contiguous()
