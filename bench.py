@@ -29,11 +29,12 @@ LENGTH_SCALE = 3.0
 FP64_VALU_PEAK_TFLOPS = 78.6   # MI355X vector FP64 (= half the 157.3 TF FP32 vector rate of MI355X_MICROARCH.md)
 HBM_PEAK_GBS = 8000.0
 PRIMES = (31, 47, 73, 113, 173, 263, 397, 593, 907, 1361)
-# Algorithmic FP64 work of one (Phi, Phi^-1) pair of the lattice integrand, in flops (FMA = 2): Hart's Phi = 46
-# instruction slots (exp 19, two polynomials 13, division 7, rest 7), AS241's central Phi^-1 = 26, its log/sqrt tail
-# branch 70 for the 15 % of the arguments that need it -- the instruction counts of the isolated chain
-# (tools/ubench/phi_ubench.hip), not of the kernel, so bookkeeping the kernel adds does not count as achieved work.
-FLOP_PER_PAIR = 2.0 * (46 + 26 + 0.15 * 70)
+# FP64 work of one (Phi, Phi^-1) pair of the lattice integrand in flops (FMA = 2, multiply / add = 1), counted in the ISA
+# of the isolated chain (tools/ubench/phi_ubench.hip): Hart's Phi 53 flops (22 FMA + 9 mul/add among 47 vector
+# instructions), AS241's central Phi^-1 48 (21 + 6 among 45), its log/sqrt tail branch 126 (56 + 14 among 121) for the
+# 15 % of the arguments that need it.  The chain, not the kernel: bookkeeping the kernel adds is not achieved work.
+FLOP_PER_PAIR = 53 + 0.85 * 48 + 0.15 * 126
+VALU_PER_PAIR_CHAIN = 47 + 0.85 * 45 + 0.15 * 121      # vector instructions of the isolated chain per pair
 
 
 def make_data(n, d, seed):
@@ -276,11 +277,13 @@ def main():
                     "peak": FP64_VALU_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach / FP64_VALU_PEAK_TFLOPS,
                     "traffic": pmc_traffic("void ital::score_qmc_kernel<%d>" % BATCH), "avg_launch_ms": avg_s * 1e3,
                     "pairs_per_s": qmc_pairs(BATCH, avg_c) / avg_s,
-                    "flop_per_pair": FLOP_PER_PAIR,
+                    "flop_per_pair": FLOP_PER_PAIR, "valu_per_pair_isolated_chain": VALU_PER_PAIR_CHAIN,
                     "valu_issue_frac": pmc_valu_issue_frac("void ital::score_qmc_kernel<%d>" % BATCH, avg_s),
                     "note": "transcendental FP64 chains (Phi, Phi^-1): neither HBM nor MFMA bounds this kernel "
                             "(SURVEY.md 8d S-qmc), so the peak is the FP64 vector rate; achieved = algorithmic pairs x "
-                            "flops of the isolated chain / launch time; HBM-bound streaming kernel in roofline_hbm"}
+                            "flops of the isolated chain / launch time.  Only ~55 % of the chain's instructions are "
+                            "FMAs, so the flop fraction understates how busy the vector unit is: valu_issue_frac is "
+                            "the share of its issue slots the kernel fills.  HBM-bound streaming kernel in roofline_hbm"}
         cc = prof.get(("cross_cov", 1), []) + prof.get(("cross_cov", 2), []) + prof.get(("cross_cov", 3), [])
         roof_hbm = None
         if cc:
