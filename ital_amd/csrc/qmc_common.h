@@ -6,6 +6,13 @@
 
 #include "device_math.h"
 
+#ifndef ITAL_QMC_NH
+#define ITAL_QMC_NH 2      // lattice items per lane and round (each with its antithetic partner)
+#endif
+#ifndef ITAL_QMC_TRIM_LAST
+#define ITAL_QMC_TRIM_LAST 1   // last round of a call's lattice points with only as many chains per lane as it needs
+#endif
+
 namespace ital {
 
 constexpr int P_TAB[10] = {31, 47, 73, 113, 173, 263, 397, 593, 907, 1361};
@@ -55,6 +62,125 @@ __device__ __forceinline__ void phinv_wave(const double (&p)[NC], double (&out)[
 
 __device__ __forceinline__ void phinv_wave4(const double (&p)[4], double (&out)[4], double* __restrict__ q, int lane) {
     phinv_wave<4>(p, out, q, lane);
+}
+
+// The integrand of NCB lattice points per lane (MVNDFN for one-sided limits): sequential conditioning over the T
+// variables, every chain independent of the others; returns the lane's sum of the integrand values.  cf: packed strict
+// lower triangle of the row-scaled factor, lm: scaled limits (wave-uniform), bit i of infi: variable i is bounded below.
+template <int T, int NCB>
+__device__ __forceinline__ double eval_chains(const double (&xx)[NCB][(T - 1 > 0 ? T - 1 : 1)], bool (&dead)[NCB],
+                                              const double (&cf)[(T * (T - 1) / 2 > 0 ? T * (T - 1) / 2 : 1)],
+                                              const double (&lm)[T], unsigned infi_c, double* tailq, int lane) {
+    double yy[NCB][(T - 1 > 0 ? T - 1 : 1)], ff[NCB];
+#pragma unroll
+    for (int c = 0; c < NCB; c++) ff[c] = 1.0;
+#pragma unroll
+    for (int i = 0; i < T; i++) {
+        const bool lower = (infi_c >> i) & 1u;
+        double pin[NCB];
+#pragma unroll
+        for (int c = 0; c < NCB; c++) {
+            double sc = 0;
+#pragma unroll
+            for (int j = 0; j < i; j++) sc = fma(cf[i * (i - 1) / 2 + j], yy[c][j], sc);
+            const double ph = mvn_phi(lm[i] - sc);
+            const double d = lower ? ph : 0.0;
+            const double w = lower ? 1.0 - ph : ph;
+            dead[c] = dead[c] || !(w > 0);
+            ff[c] *= w;
+            if (i < T - 1) pin[c] = fma(xx[c][i], w, d);   // a dead chain (w == 0) just inverts d: finite, discarded
+        }
+        if (i < T - 1) {
+            double out[NCB];
+            phinv_wave<NCB>(pin, out, tailq, lane);
+#pragma unroll
+            for (int c = 0; c < NCB; c++) yy[c][i] = out[c];
+        }
+    }
+    double acc = 0.0;
+#pragma unroll
+    for (int c = 0; c < NCB; c++) acc += dead[c] ? 0.0 : ff[c];
+    return acc;
+}
+
+// Sum over this lane's share of the 16 P lattice points of one orthant call of compile-time dimension T (8 randomly
+// shifted Korobov lattices of P points, each point with its antithetic partner).  lat: [8][NDIM] permuted generators, then
+// [8][NDIM] shifts; cf / lm / infi as eval_chains.  The caller adds the lanes up and divides by 16 P.
+template <int T>
+__device__ __forceinline__ double qmc_lane_sum(const double* __restrict__ lat,
+                                               const double (&cf)[(T * (T - 1) / 2 > 0 ? T * (T - 1) / 2 : 1)],
+                                               const double (&lm)[T], unsigned infi_c, double* __restrict__ tailq, int lane) {
+    constexpr int NDIM = T - 1, PRIME = P_TAB[(NDIM < 10 ? NDIM : 10) - 1];
+    double acc = 0.0;
+    // NC = 2*NH independent chains per lane: NH lattice items, each with its antithetic partner.  The 16 P
+    // chains of a call rarely fill whole rounds of 64 NC chains (t = 4: 1168 = 4.56 x 256): the last round runs
+    // with just the chains it needs (3 per lane instead of 4 at t = 4: 19 chain slots per lane instead of 20),
+    // whole items first, the two chains of the left-over items on neighbouring lanes.
+    constexpr int NH = ITAL_QMC_NH, NC = 2 * NH;
+    constexpr int NITEM = 8 * PRIME, FULL = (2 * NITEM) / (64 * NC), REST = 2 * NITEM - FULL * 64 * NC;
+    constexpr int NCL = ITAL_QMC_TRIM_LAST ? (REST + 63) / 64 : (REST > 0 ? NC : 0);
+    // (a last round that needs all NC chains anyway is simply one more trip of this loop: one copy of the code)
+    constexpr int LOOP_END = (NCL == NC ? FULL + 1 : FULL) * 64 * NH;
+    for (int base = 0; base < LOOP_END; base += 64 * NH) {
+        double xx[NC][NDIM];
+        bool dead[NC];
+#pragma unroll
+        for (int h = 0; h < NH; h++) {
+            const int item = base + 64 * h + lane;
+            const bool ok = NCL != NC || item < NITEM;
+            const int it = ok ? item : 0;
+            const int sft = it / PRIME;
+            const int k = it - sft * PRIME + 1;
+#pragma unroll
+            for (int j = 0; j < NDIM; j++) {
+                const double v = k * lat[sft * NDIM + j] + lat[8 * NDIM + sft * NDIM + j];
+                const double fr = v - floor(v);
+                xx[2 * h][j] = fabs(2 * fr - 1);
+                xx[2 * h + 1][j] = 1 - xx[2 * h][j];
+            }
+            dead[2 * h] = dead[2 * h + 1] = !ok;
+        }
+        acc += eval_chains<T, NC>(xx, dead, cf, lm, infi_c, tailq, lane);
+    }
+    if (NCL > 0 && NCL != NC) {
+        constexpr int NCLA = NCL > 0 ? NCL : 1;
+        double xx[NCLA][NDIM];
+        bool dead[NCLA];
+        constexpr int base = FULL * 64 * NH;
+#pragma unroll
+        for (int h = 0; h < NCL / 2; h++) {              // whole items: both antithetic chains on this lane
+            const int item = base + 64 * h + lane;
+            const bool ok = item < NITEM;
+            const int it = ok ? item : 0;
+            const int sft = it / PRIME;
+            const int k = it - sft * PRIME + 1;
+#pragma unroll
+            for (int j = 0; j < NDIM; j++) {
+                const double v = k * lat[sft * NDIM + j] + lat[8 * NDIM + sft * NDIM + j];
+                const double fr = v - floor(v);
+                xx[2 * h][j] = fabs(2 * fr - 1);
+                xx[2 * h + 1][j] = 1 - xx[2 * h][j];
+            }
+            dead[2 * h] = dead[2 * h + 1] = !ok;
+        }
+        if (NCL & 1) {                                    // left-over items: one chain each on lanes 2i, 2i + 1
+            const int item = base + 64 * (NCL / 2) + (lane >> 1);
+            const bool ok = item < NITEM;
+            const int it = ok ? item : 0;
+            const int sft = it / PRIME;
+            const int k = it - sft * PRIME + 1;
+#pragma unroll
+            for (int j = 0; j < NDIM; j++) {
+                const double v = k * lat[sft * NDIM + j] + lat[8 * NDIM + sft * NDIM + j];
+                const double fr = v - floor(v);
+                const double x = fabs(2 * fr - 1);
+                xx[NCLA - 1][j] = (lane & 1) ? 1 - x : x;
+            }
+            dead[NCLA - 1] = !ok;
+        }
+        acc += eval_chains<T, NCLA>(xx, dead, cf, lm, infi_c, tailq, lane);
+    }
+    return acc;
 }
 
 }  // namespace ital

@@ -23,15 +23,9 @@
 #include "ital_internal.h"
 #include "qmc_common.h"
 
-#ifndef ITAL_QMC_NH
-#define ITAL_QMC_NH 2      // lattice items per lane and round (each with its antithetic partner)
-#endif
 #ifndef ITAL_QMC_CHUNK_LOG2
 #define ITAL_QMC_CHUNK_LOG2(T) 3   // calls per pass of a wave: 8, one lane per (call, shift) when the lattices are drawn (measured: 4 calls
                                    // per pass -- twice the work items -- is 14 % slower at t = 3 and 7 % at t = 4: the per-pass preparation costs more than the finer grid gains)
-#endif
-#ifndef ITAL_QMC_TRIM_LAST
-#define ITAL_QMC_TRIM_LAST 1   // last round of a call's lattice points with only as many chains per lane as it needs
 #endif
 #ifndef ITAL_QMC_WAVES
 #define ITAL_QMC_WAVES(T) ((T) <= 4 ? 3 : 2)   // waves per SIMD the register allocation aims at (measured)
@@ -231,45 +225,6 @@ __device__ bool covsrt(double* cov, double* lim, double* y, unsigned& infi) {
         }
     }
     return ok;
-}
-
-// The integrand of NCB lattice points per lane (MVNDFN for one-sided limits): sequential conditioning over the T
-// variables, every chain independent of the others; returns the lane's sum of the integrand values.  cf: packed strict
-// lower triangle of the row-scaled factor, lm: scaled limits (wave-uniform), bit i of infi: variable i is bounded below.
-template <int T, int NCB>
-__device__ __forceinline__ double eval_chains(const double (&xx)[NCB][(T - 1 > 0 ? T - 1 : 1)], bool (&dead)[NCB],
-                                              const double (&cf)[(T * (T - 1) / 2 > 0 ? T * (T - 1) / 2 : 1)],
-                                              const double (&lm)[T], unsigned infi_c, double* tailq, int lane) {
-    double yy[NCB][(T - 1 > 0 ? T - 1 : 1)], ff[NCB];
-#pragma unroll
-    for (int c = 0; c < NCB; c++) ff[c] = 1.0;
-#pragma unroll
-    for (int i = 0; i < T; i++) {
-        const bool lower = (infi_c >> i) & 1u;
-        double pin[NCB];
-#pragma unroll
-        for (int c = 0; c < NCB; c++) {
-            double sc = 0;
-#pragma unroll
-            for (int j = 0; j < i; j++) sc = fma(cf[i * (i - 1) / 2 + j], yy[c][j], sc);
-            const double ph = mvn_phi(lm[i] - sc);
-            const double d = lower ? ph : 0.0;
-            const double w = lower ? 1.0 - ph : ph;
-            dead[c] = dead[c] || !(w > 0);
-            ff[c] *= w;
-            if (i < T - 1) pin[c] = fma(xx[c][i], w, d);   // a dead chain (w == 0) just inverts d: finite, discarded
-        }
-        if (i < T - 1) {
-            double out[NCB];
-            phinv_wave<NCB>(pin, out, tailq, lane);
-#pragma unroll
-            for (int c = 0; c < NCB; c++) yy[c][i] = out[c];
-        }
-    }
-    double acc = 0.0;
-#pragma unroll
-    for (int c = 0; c < NCB; c++) acc += dead[c] ? 0.0 : ff[c];
-    return acc;
 }
 
 // MVNUNI state at the first call of every work item (candidate position p, part): the step's seed advanced by
@@ -526,71 +481,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(ITAL_QMC_WA
 #pragma unroll
                     for (int j = 0; j < i; j++) cf[i * (i - 1) / 2 + j] = uniform_f64(cov[pidx(i, j)]);
                 }
-                double acc = 0.0;
-                // NC = 2*NH independent chains per lane: NH lattice items, each with its antithetic partner.  The 16 P
-                // chains of a call rarely fill whole rounds of 64 NC chains (t = 4: 1168 = 4.56 x 256): the last round runs
-                // with just the chains it needs (3 per lane instead of 4 at t = 4: 19 chain slots per lane instead of 20),
-                // whole items first, the two chains of the left-over items on neighbouring lanes.
-                constexpr int NH = ITAL_QMC_NH, NC = 2 * NH;
-                constexpr int NITEM = 8 * Q::PRIME, FULL = (2 * NITEM) / (64 * NC), REST = 2 * NITEM - FULL * 64 * NC;
-                constexpr int NCL = ITAL_QMC_TRIM_LAST ? (REST + 63) / 64 : (REST > 0 ? NC : 0);
-                for (int base = 0; base < FULL * 64 * NH; base += 64 * NH) {
-                    double xx[NC][Q::NDIM];
-                    bool dead[NC];
-#pragma unroll
-                    for (int h = 0; h < NH; h++) {
-                        const int it = base + 64 * h + lane;
-                        const int sft = it / Q::PRIME;
-                        const int k = it - sft * Q::PRIME + 1;
-#pragma unroll
-                        for (int j = 0; j < Q::NDIM; j++) {
-                            const double v = k * lat[sft * Q::NDIM + j] + lat[8 * Q::NDIM + sft * Q::NDIM + j];
-                            const double fr = v - floor(v);
-                            xx[2 * h][j] = fabs(2 * fr - 1);
-                            xx[2 * h + 1][j] = 1 - xx[2 * h][j];
-                        }
-                        dead[2 * h] = dead[2 * h + 1] = false;
-                    }
-                    acc += eval_chains<T, NC>(xx, dead, cf, lm, infi_c, tailq, lane);
-                }
-                if (NCL > 0) {
-                    constexpr int NCLA = NCL > 0 ? NCL : 1;
-                    double xx[NCLA][Q::NDIM];
-                    bool dead[NCLA];
-                    constexpr int base = FULL * 64 * NH;
-#pragma unroll
-                    for (int h = 0; h < NCL / 2; h++) {              // whole items: both antithetic chains on this lane
-                        const int item = base + 64 * h + lane;
-                        const bool ok = item < NITEM;
-                        const int it = ok ? item : 0;
-                        const int sft = it / Q::PRIME;
-                        const int k = it - sft * Q::PRIME + 1;
-#pragma unroll
-                        for (int j = 0; j < Q::NDIM; j++) {
-                            const double v = k * lat[sft * Q::NDIM + j] + lat[8 * Q::NDIM + sft * Q::NDIM + j];
-                            const double fr = v - floor(v);
-                            xx[2 * h][j] = fabs(2 * fr - 1);
-                            xx[2 * h + 1][j] = 1 - xx[2 * h][j];
-                        }
-                        dead[2 * h] = dead[2 * h + 1] = !ok;
-                    }
-                    if (NCL & 1) {                                    // left-over items: one chain each on lanes 2i, 2i + 1
-                        const int item = base + 64 * (NCL / 2) + (lane >> 1);
-                        const bool ok = item < NITEM;
-                        const int it = ok ? item : 0;
-                        const int sft = it / Q::PRIME;
-                        const int k = it - sft * Q::PRIME + 1;
-#pragma unroll
-                        for (int j = 0; j < Q::NDIM; j++) {
-                            const double v = k * lat[sft * Q::NDIM + j] + lat[8 * Q::NDIM + sft * Q::NDIM + j];
-                            const double fr = v - floor(v);
-                            const double x = fabs(2 * fr - 1);
-                            xx[NCLA - 1][j] = (lane & 1) ? 1 - x : x;
-                        }
-                        dead[NCLA - 1] = !ok;
-                    }
-                    acc += eval_chains<T, NCLA>(xx, dead, cf, lm, infi_c, tailq, lane);
-                }
+                const double acc = qmc_lane_sum<T>(lat, cf, lm, infi_c, tailq, lane);
                 value = wave_sum(acc) / (16.0 * Q::PRIME);
             }
             if ((call & 1) == 0) {

@@ -645,7 +645,6 @@ __device__ double qmc_eval_fixed(const double* __restrict__ slab, unsigned infi,
                                  double* __restrict__ tailq) {
     constexpr int NDIM = T - 1, NCOV = T * (T + 1) / 2, NCOR = T * (T - 1) / 2;
     constexpr int PRIME = P_TAB[(NDIM < 10 ? NDIM : 10) - 1];
-    constexpr int NH = 2, NC = 4;
     double cf[NCOR > 0 ? NCOR : 1], lm[T];
 #pragma unroll
     for (int i = 0; i < T; i++) {
@@ -653,53 +652,7 @@ __device__ double qmc_eval_fixed(const double* __restrict__ slab, unsigned infi,
 #pragma unroll
         for (int j = 0; j < i; j++) cf[i * (i - 1) / 2 + j] = uniform_f64(slab[pidx(i, j)]);
     }
-    double acc = 0.0;
-    for (int base = 0; base < 8 * PRIME; base += 64 * NH) {
-        double xx[NC][NDIM], yy[NC][NDIM], ff[NC];
-        bool dead[NC];
-#pragma unroll
-        for (int h = 0; h < NH; h++) {
-            const int item = base + 64 * h + lane;
-            const bool ok = item < 8 * PRIME;
-            const int it = ok ? item : 0;
-            const int sft = it / PRIME;
-            const int k = it - sft * PRIME + 1;
-#pragma unroll
-            for (int j = 0; j < NDIM; j++) {
-                const double v = k * lat[sft * NDIM + j] + lat[8 * NDIM + sft * NDIM + j];
-                const double fr = v - floor(v);
-                xx[2 * h][j] = fabs(2 * fr - 1);
-                xx[2 * h + 1][j] = 1 - xx[2 * h][j];
-            }
-            ff[2 * h] = ff[2 * h + 1] = 1.0;
-            dead[2 * h] = dead[2 * h + 1] = !ok;
-        }
-#pragma unroll
-        for (int i = 0; i < T; i++) {
-            const bool lower = (infi >> i) & 1u;
-            double pin[NC];
-#pragma unroll
-            for (int c = 0; c < NC; c++) {
-                double sc = 0;
-#pragma unroll
-                for (int j = 0; j < i; j++) sc = fma(cf[i * (i - 1) / 2 + j], yy[c][j], sc);
-                const double ph = mvn_phi(lm[i] - sc);
-                const double dd = lower ? ph : 0.0;
-                const double w = lower ? 1.0 - ph : ph;
-                dead[c] = dead[c] || !(w > 0);
-                ff[c] *= w;
-                if (i < T - 1) pin[c] = fma(xx[c][i], w, dd);
-            }
-            if (i < T - 1) {
-                double outv[NC];
-                phinv_wave<NC>(pin, outv, tailq, lane);
-#pragma unroll
-                for (int c = 0; c < NC; c++) yy[c][i] = outv[c];
-            }
-        }
-#pragma unroll
-        for (int c = 0; c < NC; c++) acc += dead[c] ? 0.0 : ff[c];
-    }
+    const double acc = qmc_lane_sum<T>(lat, cf, lm, infi, tailq, lane);
     return wave_sum(acc) / (16.0 * PRIME);
 }
 
