@@ -193,8 +193,16 @@ class ITAL(ActiveRetrievalBase):
         candidates = self._candidate_list(unseen)
         if len(candidates) < k:
             # k was clamped to the number of unseen samples BEFORE the top_candidates restriction (ital.py:99-117): the
-            # reference runs out of candidates in its greedy loop and np.argmax([]) raises exactly this (ital.py:130)
+            # reference picks until the list is empty and np.argmax([]) then raises exactly this (ital.py:130) -- with
+            # the random streams advanced by the steps it did run, so those are run here too
+            if len(candidates) > 0:
+                self._select(len(candidates), candidates)
             raise ValueError("attempt to get argmax of an empty sequence")
+        return self._select(k, candidates)
+
+    def _select(self, k, candidates):
+        """Greedy construction of a batch of k out of `candidates` (k <= len(candidates))."""
+        gp = self.gp
         if self._needs_generic():
             return self._fetch_generic(k, candidates)
         lib = _lib.lib()
