@@ -292,6 +292,13 @@ def test_api_edge_cases(dev):
     assert len(T.fetch_unlabelled(2)) == 2
     with pytest.raises(ValueError, match="empty sequence"):     # more picks than top_candidates allows: np.argmax([])
         T.fetch_unlabelled(3)
+    T3 = ITAL(X, length_scale=0.7, top_candidates=3, device=dev)
+    T3.update({0: 1})
+    mvn_stream.GLOBAL.reset()
+    with pytest.raises(ValueError, match="empty sequence"):
+        T3.fetch_unlabelled(4)
+    # the reference gets through three greedy steps first: one candidate is left at t = 3, 2 * 2^3 calls of 24 uniforms
+    assert mvn_stream.GLOBAL.draws == 16 * mvn_stream.draws_per_call(3)
     L.reset()
     assert L.rounds == 0 and L.gp.m == 0 and L.rel_mean is None
     with pytest.raises(NotImplementedError):
