@@ -163,7 +163,7 @@ struct Qmc {
     static constexpr int LAT = 8 * NDIM * 2;                  // per call: permuted generators + shifts, 8 shifts
     static constexpr int TAILQ = 128 * ITAL_QMC_NH;           // compaction queue of the Phi^-1 tail branch (in place)
     static constexpr int SWAPS = (CHUNK * 8 * NDIM + 1) / 2;  // ints: transposition targets of every (call, shift)
-    static constexpr int WAVE_DOUBLES = CHUNK * (SLAB + LAT) + A_SIZE + T + TAILQ + SWAPS;  // + perm
+    static constexpr int WAVE_DOUBLES = CHUNK * (SLAB + LAT) + A_SIZE + T + TAILQ + SWAPS + CHUNK;  // + perm, per-call sums
 };
 
 // Swap rows/columns p < q of the packed lower-triangular matrix, the limits and the limit-type bits (RCSWP).
@@ -269,6 +269,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(ITAL_QMC_WA
     int* perm = reinterpret_cast<int*>(lats + Q::CHUNK * Q::LAT);  // T ints: natural index held at each sorted slot
     double* tailq = lats + Q::CHUNK * Q::LAT + T;
     int* swaps = reinterpret_cast<int*>(tailq + Q::TAILQ);
+    double* vals = tailq + Q::TAILQ + Q::SWAPS;   // lattice sums of the calls of a pass
 
     const int row = a.cand[p];
     const int64_t gi = a.row_offset + row;
@@ -463,14 +464,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(ITAL_QMC_WA
 
         // ---------------- Phase C: the wave evaluates the calls of this chunk one after the other
         for (int cl = 0; cl < Q::CHUNK; cl++) {
-            const int call = chunk + cl;
             // wave-uniform copies (SGPR) of the preparing lane's flags: keeps the generator arithmetic on the scalar unit
             const bool sat_c = __builtin_amdgcn_readlane((int)sat, cl) != 0;
             const unsigned infi_c = (unsigned)__builtin_amdgcn_readlane((int)infi, cl);
-            double value;
-            if (sat_c) {
-                value = 1.0;
-            } else {
+            if (!sat_c) {
                 const double* lat = lats + cl * Q::LAT;
                 // per-call constants out of the preparing lane's slab, as wave-uniform (scalar) values
                 const double* cov = slabs + cl * Q::SLAB;
@@ -482,8 +479,18 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(ITAL_QMC_WA
                     for (int j = 0; j < i; j++) cf[i * (i - 1) / 2 + j] = uniform_f64(cov[pidx(i, j)]);
                 }
                 const double acc = qmc_lane_sum<T>(lat, cf, lm, infi_c, tailq, lane);
-                value = wave_sum(acc) / (16.0 * Q::PRIME);
+                const double tot = wave_sum(acc);
+                if (lane == 0) vals[cl] = tot;
             }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        // the calls' values enter the sum in call order (prior probability, then the one after the simulated update)
+        for (int cl = 0; cl < Q::CHUNK; cl++) {
+            const int call = chunk + cl;
+            const bool sat_c = __builtin_amdgcn_readlane((int)sat, cl) != 0;
+            const double value = sat_c ? 1.0 : vals[cl] / (16.0 * Q::PRIME);
             if ((call & 1) == 0) {
                 pr_cur = value;
             } else {
