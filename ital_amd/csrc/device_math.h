@@ -359,6 +359,23 @@ __device__ __forceinline__ void mrg_apply(MrgState& s, const long long* __restri
     unsigned long long r[3], q[3];
 #pragma unroll
     for (int i = 0; i < 3; i++) {
+        // entries and state are below 2^31: three products sum to less than 3 * 2^62 < 2^64 -- one reduction per row
+        r[i] = ((unsigned long long)J[3 * i] * a0 + (unsigned long long)J[3 * i + 1] * a1 +
+                (unsigned long long)J[3 * i + 2] * a2) % MRG_M1;
+        q[i] = ((unsigned long long)J[9 + 3 * i] * b0 + (unsigned long long)J[9 + 3 * i + 1] * b1 +
+                (unsigned long long)J[9 + 3 * i + 2] * b2) % MRG_M2;
+    }
+    s.x10 = (int)r[0]; s.x11 = (int)r[1]; s.x12 = (int)r[2];
+    s.x20 = (int)q[0]; s.x21 = (int)q[1]; s.x22 = (int)q[2];
+}
+
+// the same with every product reduced on its own (what the general scorer uses, see score_generic.hip)
+__device__ __forceinline__ void mrg_apply_each(MrgState& s, const long long* __restrict__ J) {
+    unsigned long long a0 = s.x10, a1 = s.x11, a2 = s.x12;
+    unsigned long long b0 = s.x20, b1 = s.x21, b2 = s.x22;
+    unsigned long long r[3], q[3];
+#pragma unroll
+    for (int i = 0; i < 3; i++) {
         r[i] = ((unsigned long long)J[3 * i] * a0 % MRG_M1 + (unsigned long long)J[3 * i + 1] * a1 % MRG_M1 +
                 (unsigned long long)J[3 * i + 2] * a2 % MRG_M1) % MRG_M1;
         q[i] = ((unsigned long long)J[9 + 3 * i] * b0 % MRG_M2 + (unsigned long long)J[9 + 3 * i + 1] * b1 % MRG_M2 +

@@ -29,6 +29,12 @@
 #include "device_math.h"
 #include "ital_hip.h"
 #include "ital_internal.h"
+#ifndef ITAL_GEN_SHORT_JUMP
+// measured in this kernel: the jump with one reduction per matrix row (device_math.h) makes the t = 3 instantiation 5 %
+// faster and the t = 4 one 3 % slower (register allocation around the out-of-line lattice routine); the noisy-user round
+// as a whole is 2 % faster with a reduction per product
+#define mrg_apply mrg_apply_each
+#endif
 #include "qmc_common.h"
 
 #ifndef ITAL_GEN_NH12
