@@ -72,6 +72,10 @@ struct KcolsArgs {
 };
 
 enum { MODE_RAW = 0, MODE_WHITEN = 1 };
+#ifndef ITAL_KCOLS_KU
+#define ITAL_KCOLS_KU 4
+#endif
+constexpr int KU = ITAL_KCOLS_KU;   // feature steps per trip of the dot-product loop
 
 __global__ __launch_bounds__(256) void kcols_kernel(KcolsArgs a) {
     __shared__ double tile[4][16][17];  // per wave: R[j][i] transpose buffer for the whitening epilogue
@@ -89,32 +93,47 @@ __global__ __launch_bounds__(256) void kcols_kernel(KcolsArgs a) {
 
     d4 acc_dot = {0, 0, 0, 0};
     // ---- dot products over the feature dimension: 16 k-values per step, 32 B per lane per operand
-    for (int k0 = 0; k0 < a.ldx; k0 += 16) {
-        const int kk = k0 + 4 * kg;
-        double2 b01 = {0, 0}, b23 = {0, 0}, a01 = {0, 0}, a23 = {0, 0};
-        if (row_ok) {
-            b01 = *reinterpret_cast<const double2*>(xrow + kk);
-            b23 = *reinterpret_cast<const double2*>(xrow + kk + 2);
+    // KU steps of 16 features per trip, all their loads issued before the first MFMA: at the sizes where the kernel is
+    // latency bound (a few hundred waves) the operand fetches of a trip overlap instead of queueing behind each other.
+    for (int k0 = 0; k0 < a.ldx; k0 += 16 * KU) {
+        double2 b01[KU], b23[KU], a01[KU], a23[KU];
+#pragma unroll
+        for (int u = 0; u < KU; u++) {
+            const int kk = k0 + 16 * u + 4 * kg;
+            const bool in = k0 + 16 * u < a.ldx;           // ldx is a multiple of 16
+            b01[u] = b23[u] = a01[u] = a23[u] = double2{0, 0};
+            if (in && row_ok) {
+                b01[u] = *reinterpret_cast<const double2*>(xrow + kk);
+                b23[u] = *reinterpret_cast<const double2*>(xrow + kk + 2);
+            }
+            if (in && sel_ok) {
+                a01[u] = *reinterpret_cast<const double2*>(srow + kk);
+                a23[u] = *reinterpret_cast<const double2*>(srow + kk + 2);
+            }
         }
-        if (sel_ok) {
-            a01 = *reinterpret_cast<const double2*>(srow + kk);
-            a23 = *reinterpret_cast<const double2*>(srow + kk + 2);
+#pragma unroll
+        for (int u = 0; u < KU; u++) {
+            acc_dot = __builtin_amdgcn_mfma_f64_16x16x4f64(a01[u].x, b01[u].x, acc_dot, 0, 0, 0);
+            acc_dot = __builtin_amdgcn_mfma_f64_16x16x4f64(a01[u].y, b01[u].y, acc_dot, 0, 0, 0);
+            acc_dot = __builtin_amdgcn_mfma_f64_16x16x4f64(a23[u].x, b23[u].x, acc_dot, 0, 0, 0);
+            acc_dot = __builtin_amdgcn_mfma_f64_16x16x4f64(a23[u].y, b23[u].y, acc_dot, 0, 0, 0);
         }
-        acc_dot = __builtin_amdgcn_mfma_f64_16x16x4f64(a01.x, b01.x, acc_dot, 0, 0, 0);
-        acc_dot = __builtin_amdgcn_mfma_f64_16x16x4f64(a01.y, b01.y, acc_dot, 0, 0, 0);
-        acc_dot = __builtin_amdgcn_mfma_f64_16x16x4f64(a23.x, b23.x, acc_dot, 0, 0, 0);
-        acc_dot = __builtin_amdgcn_mfma_f64_16x16x4f64(a23.y, b23.y, acc_dot, 0, 0, 0);
     }
     // ---- S = W V over the labelled dimension: A[j][r] = W[j][r], B[r][i] = V[r][i]
     d4 acc_s = {0, 0, 0, 0};
-    for (int r0 = 0; r0 < a.m; r0 += 4) {
-        const int r = r0 + kg;
-        double av = 0, bv = 0;
-        if (r < a.m) {
-            if (sel_ok) av = a.W[(int64_t)col * a.ldw + r];
-            if (row_ok) bv = a.V[(int64_t)r * a.ldv + irow];
+    for (int r0 = 0; r0 < a.m; r0 += 16) {
+        double av[4], bv[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const int r = r0 + 4 * u + kg;
+            av[u] = bv[u] = 0;
+            if (r < a.m) {
+                if (sel_ok) av[u] = a.W[(int64_t)col * a.ldw + r];
+                if (row_ok) bv[u] = a.V[(int64_t)r * a.ldv + irow];
+            }
         }
-        acc_s = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc_s, 0, 0, 0);
+#pragma unroll
+        for (int u = 0; u < 4; u++) acc_s = __builtin_amdgcn_mfma_f64_16x16x4f64(av[u], bv[u], acc_s, 0, 0, 0);
     }
     // ---- epilogue.  D layout (f64 16x16x4): element reg -> row j = kg + 4*reg, column i = col.
     const double xn = row_ok ? a.xnorm[irow] : 0.0;
