@@ -99,48 +99,56 @@ __global__ __launch_bounds__(256) void score_t1_kernel(ScoreArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------------ t = 2
+// A block scores 32 candidates: 128 (candidate, pattern) pairs, pattern r = 0..3 in itertools.product order (bit 1 = batch
+// member, bit 0 = candidate).  Waves 0-1 evaluate the pairs' prior probabilities, waves 2-3 the probabilities after the
+// simulated update -- one bivariate closed form per thread, the same branch for a whole wave (the step is a few hundred waves
+// of one long dependent chain each: this way twice as many, half as long); 32 threads then add the terms up in order.
 __global__ __launch_bounds__(256) void score_t2_kernel(ScoreArgs a) {
-    const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const int64_t p = gid >> 2;
-    const int r = (int)(gid & 3);  // pattern index in itertools.product order: bit1 = batch member, bit0 = candidate
+    __shared__ double vals[2][128];
+    const int pair = threadIdx.x & 127;
+    const bool updated = threadIdx.x >= 128;
+    const int64_t p = (int64_t)blockIdx.x * 32 + (pair >> 2);
+    const int r = pair & 3;
     const bool valid = p < a.n_cand && a.alive[p];
-    double pr = 0, pu = 1;
+    double val = updated ? 1.0 : 0.0;
     if (valid) {
         const int row = a.cand[p];
         const double m0 = a.b.bmu[0], m1 = a.mu[row];
         const double s00 = a.b.sig[0], s11 = a.s2[row], s01 = a.C[row];
         const bool rel0 = (r >> 1) & 1, rel1 = r & 1;
-        // prior
-        const double sd0 = sqrt(s00), sd1 = sqrt(s11);
-        pr = bvn_orthant(-m0 / sd0, -m1 / sd1, rel0, rel1, s01 / (sd0 * sd1));
-        // simulated update, closed form
-        const double a00 = s00 + a.noise, a11 = s11 + a.noise, a01 = s01;
-        const double det = a00 * a11 - a01 * a01;
-        const double w00 = a11 / det, w11 = a00 / det, w01 = -a01 / det;
-        const double g00 = 1.0 - a.noise * w00, g11 = 1.0 - a.noise * w11, g01 = -a.noise * w01;
-        const double f0 = rel0 ? 1.0 : -1.0, f1 = rel1 ? 1.0 : -1.0;
-        const double u0 = m0 + g00 * (f0 - m0) + g01 * (f1 - m1);
-        const double u1 = m1 + g01 * (f0 - m0) + g11 * (f1 - m1);
-        const double c00 = a.noise * g00, c11 = a.noise * g11, c01 = a.noise * g01;
-        const double t0 = sqrt(c00), t1 = sqrt(c11);
-        double h = -u0 / t0, k = -u1 / t1;
-        const double rho = c01 / (t0 * t1);
-        // variables sorted by data index (ital.py:448): symmetric for the closed form, kept for the bookkeeping
-        const int64_t gi = a.row_offset + row;
-        if (gi < a.b.bidx[0]) pu = bvn_orthant(k, h, rel1, rel0, rho);
-        else pu = bvn_orthant(h, k, rel0, rel1, rho);
+        if (!updated) {
+            const double sd0 = sqrt(s00), sd1 = sqrt(s11);
+            val = bvn_orthant(-m0 / sd0, -m1 / sd1, rel0, rel1, s01 / (sd0 * sd1));
+        } else {
+            // simulated update, closed form
+            const double a00 = s00 + a.noise, a11 = s11 + a.noise, a01 = s01;
+            const double det = a00 * a11 - a01 * a01;
+            const double w00 = a11 / det, w11 = a00 / det, w01 = -a01 / det;
+            const double g00 = 1.0 - a.noise * w00, g11 = 1.0 - a.noise * w11, g01 = -a.noise * w01;
+            const double f0 = rel0 ? 1.0 : -1.0, f1 = rel1 ? 1.0 : -1.0;
+            const double u0 = m0 + g00 * (f0 - m0) + g01 * (f1 - m1);
+            const double u1 = m1 + g01 * (f0 - m0) + g11 * (f1 - m1);
+            const double c00 = a.noise * g00, c11 = a.noise * g11, c01 = a.noise * g01;
+            const double t0 = sqrt(c00), t1 = sqrt(c11);
+            double h = -u0 / t0, k = -u1 / t1;
+            const double rho = c01 / (t0 * t1);
+            // variables sorted by data index (ital.py:448): symmetric for the closed form, kept for the bookkeeping
+            const int64_t gi = a.row_offset + row;
+            if (gi < a.b.bidx[0]) val = bvn_orthant(k, h, rel1, rel0, rho);
+            else val = bvn_orthant(h, k, rel0, rel1, rho);
+        }
     }
-    // combine the four patterns in product order on the first lane of each quad
-    const int lane = threadIdx.x & 63;
-    const int base = lane & ~3;
-    double mi = 0.0;
+    vals[updated ? 1 : 0][pair] = val;
+    __syncthreads();
+    if (threadIdx.x < 32) {
+        const int64_t pc = (int64_t)blockIdx.x * 32 + threadIdx.x;
+        if (pc < a.n_cand && a.alive[pc]) {
+            double mi = 0.0;
 #pragma unroll
-    for (int q = 0; q < 4; q++) {
-        const double prq = __shfl(pr, base + q, 64);
-        const double puq = __shfl(pu, base + q, 64);
-        mi_accumulate(mi, prq, puq, a.eps, a.label_mode);
+            for (int q = 0; q < 4; q++) mi_accumulate(mi, vals[0][4 * threadIdx.x + q], vals[1][4 * threadIdx.x + q], a.eps, a.label_mode);
+            a.mi[pc] = mi;
+        }
     }
-    if (valid && r == 0) a.mi[p] = mi;
 }
 
 // ------------------------------------------------------------------------------------------------ t >= 3
@@ -560,7 +568,7 @@ extern "C" int ital_score_step(const ital_score_desc* d, hipStream_t stream) {
         return ital_check_launch("ital_score_step(t=1)");
     }
     if (d->t == 2) {
-        hipLaunchKernelGGL(score_t2_kernel, dim3((unsigned)((d->n_cand * 4 + 255) / 256)), dim3(256), 0, stream, a);
+        hipLaunchKernelGGL(score_t2_kernel, dim3((unsigned)((d->n_cand + 31) / 32)), dim3(256), 0, stream, a);
         return ital_check_launch("ital_score_step(t=2)");
     }
     if (!d->jump || !d->jumplane || !d->vk) return ital_fail(-22, "ital_score_step: jump tables / generators missing for t >= 3");
