@@ -57,15 +57,36 @@ __device__ Best block_best(Best v, int mode) {
     return r;  // valid in wave 0
 }
 
+// Best live position of the strided range first, first + step, ...: four positions per trip, their flags and values
+// loaded before any is compared (the single-workgroup selections are a chain of memory round trips otherwise).
+__device__ __forceinline__ Best scan_best(const double* __restrict__ mi, const uint8_t* __restrict__ alive, int64_t n_cand,
+                                          int64_t first, int64_t step, int64_t pos_offset, int mode) {
+    Best v = {0.0, -1};
+    for (int64_t p = first; p < n_cand; p += 4 * step) {
+        bool live[4];
+        double val[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const int64_t q = p + u * step;
+            const bool in = q < n_cand;
+            live[u] = in && alive[in ? q : 0] != 0;
+            val[u] = mi[in ? q : 0];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            if (!live[u]) continue;
+            Best c = {val[u], pos_offset + p + u * step};
+            if (better(c, v, mode)) v = c;
+        }
+    }
+    return v;
+}
+
 __global__ __launch_bounds__(256) void select_partial_kernel(const double* __restrict__ mi, const uint8_t* __restrict__ alive,
                                                              int64_t n_cand, int64_t pos_offset, int mode,
                                                              double* __restrict__ work) {
-    Best v = {0.0, -1};
-    for (int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < n_cand; p += (int64_t)gridDim.x * blockDim.x) {
-        if (!alive[p]) continue;
-        Best c = {mi[p], pos_offset + p};
-        if (better(c, v, mode)) v = c;
-    }
+    Best v = scan_best(mi, alive, n_cand, (int64_t)blockIdx.x * blockDim.x + threadIdx.x, (int64_t)gridDim.x * blockDim.x,
+                       pos_offset, mode);
     v = block_best(v, mode);
     if (threadIdx.x == 0) {
         work[2 * blockIdx.x] = v.val;
@@ -169,12 +190,7 @@ __device__ void resolve_body(const double* __restrict__ records, int world, int 
 // launch more than it saves).
 __global__ __launch_bounds__(1024) void select_local_small_kernel(const double* __restrict__ mi, const uint8_t* __restrict__ alive,
                                                                   int64_t n_cand, RecordArgs a) {
-    Best v = {0.0, -1};
-    for (int64_t p = threadIdx.x; p < n_cand; p += blockDim.x) {
-        if (!alive[p]) continue;
-        Best c = {mi[p], a.pos_offset + p};
-        if (better(c, v, a.mode)) v = c;
-    }
+    Best v = scan_best(mi, alive, n_cand, threadIdx.x, blockDim.x, a.pos_offset, a.mode);
     v = block_best(v, a.mode);
     record_body(a, v);
 }
@@ -189,12 +205,7 @@ __global__ __launch_bounds__(256) void select_resolve_kernel(const double* __res
 // the greedy steps of small problems are launch-latency bound).
 __global__ __launch_bounds__(1024) void select_fused_kernel(const double* __restrict__ mi, int64_t n_cand, RecordArgs a,
                                                             int slot, ital_batch b, uint8_t* alive, int64_t* __restrict__ ret) {
-    Best v = {0.0, -1};
-    for (int64_t p = threadIdx.x; p < n_cand; p += blockDim.x) {
-        if (!alive[p]) continue;
-        Best c = {mi[p], a.pos_offset + p};
-        if (better(c, v, a.mode)) v = c;
-    }
+    Best v = scan_best(mi, alive, n_cand, threadIdx.x, blockDim.x, a.pos_offset, a.mode);
     v = block_best(v, a.mode);
     record_body(a, v);
     __threadfence_block();
