@@ -87,34 +87,57 @@ __global__ __launch_bounds__(256) void cov_block_kernel(CovArgs a) {
     for (int p = 0; p < COV_MI; p++)
 #pragma unroll
         for (int q = 0; q < COV_MJ; q++) acc[p][q] = (d4){0, 0, 0, 0};
-    for (int k0 = 0; k0 < a.ldx; k0 += 16) {
+    // Register double buffer over the feature steps: the operands of step k + 1 are requested before the 32 MFMAs of step k
+    // are issued, so that their fetch (L2 / MALL) overlaps the matrix work instead of preceding it.
+    struct Operands { double2 a01[COV_MI], a23[COV_MI], b01[COV_MJ], b23[COV_MJ]; };
+    auto fetch = [&](Operands& o, int k0) {
         const int kk = k0 + 4 * kg;
-        double2 a01[COV_MI], a23[COV_MI], b01[COV_MJ], b23[COV_MJ];
+        const bool in = k0 < a.ldx;
 #pragma unroll
         for (int p = 0; p < COV_MI; p++) {
-            a01[p] = a23[p] = (double2){0, 0};
-            if (a_ok[p]) {
-                a01[p] = *reinterpret_cast<const double2*>(arow[p] + kk);
-                a23[p] = *reinterpret_cast<const double2*>(arow[p] + kk + 2);
+            o.a01[p] = o.a23[p] = (double2){0, 0};
+            if (in && a_ok[p]) {
+                o.a01[p] = *reinterpret_cast<const double2*>(arow[p] + kk);
+                o.a23[p] = *reinterpret_cast<const double2*>(arow[p] + kk + 2);
             }
         }
 #pragma unroll
         for (int q = 0; q < COV_MJ; q++) {
-            b01[q] = b23[q] = (double2){0, 0};
-            if (b_ok[q]) {
-                b01[q] = *reinterpret_cast<const double2*>(brow[q] + kk);
-                b23[q] = *reinterpret_cast<const double2*>(brow[q] + kk + 2);
+            o.b01[q] = o.b23[q] = (double2){0, 0};
+            if (in && b_ok[q]) {
+                o.b01[q] = *reinterpret_cast<const double2*>(brow[q] + kk);
+                o.b23[q] = *reinterpret_cast<const double2*>(brow[q] + kk + 2);
             }
         }
+    };
+    auto multiply = [&](const Operands& o) {
+        // one feature quadruple at a time over all eight accumulators: consecutive MFMAs never depend on each other
 #pragma unroll
         for (int p = 0; p < COV_MI; p++)
 #pragma unroll
-            for (int q = 0; q < COV_MJ; q++) {
-                acc[p][q] = __builtin_amdgcn_mfma_f64_16x16x4f64(a01[p].x, b01[q].x, acc[p][q], 0, 0, 0);
-                acc[p][q] = __builtin_amdgcn_mfma_f64_16x16x4f64(a01[p].y, b01[q].y, acc[p][q], 0, 0, 0);
-                acc[p][q] = __builtin_amdgcn_mfma_f64_16x16x4f64(a23[p].x, b23[q].x, acc[p][q], 0, 0, 0);
-                acc[p][q] = __builtin_amdgcn_mfma_f64_16x16x4f64(a23[p].y, b23[q].y, acc[p][q], 0, 0, 0);
-            }
+            for (int q = 0; q < COV_MJ; q++) acc[p][q] = __builtin_amdgcn_mfma_f64_16x16x4f64(o.a01[p].x, o.b01[q].x, acc[p][q], 0, 0, 0);
+#pragma unroll
+        for (int p = 0; p < COV_MI; p++)
+#pragma unroll
+            for (int q = 0; q < COV_MJ; q++) acc[p][q] = __builtin_amdgcn_mfma_f64_16x16x4f64(o.a01[p].y, o.b01[q].y, acc[p][q], 0, 0, 0);
+#pragma unroll
+        for (int p = 0; p < COV_MI; p++)
+#pragma unroll
+            for (int q = 0; q < COV_MJ; q++) acc[p][q] = __builtin_amdgcn_mfma_f64_16x16x4f64(o.a23[p].x, o.b23[q].x, acc[p][q], 0, 0, 0);
+#pragma unroll
+        for (int p = 0; p < COV_MI; p++)
+#pragma unroll
+            for (int q = 0; q < COV_MJ; q++) acc[p][q] = __builtin_amdgcn_mfma_f64_16x16x4f64(o.a23[p].y, o.b23[q].y, acc[p][q], 0, 0, 0);
+    };
+    {
+        Operands even, odd;
+        fetch(even, 0);
+        for (int k0 = 0; k0 < a.ldx; k0 += 32) {
+            fetch(odd, k0 + 16);          // zeros past the end: the extra MFMAs of an odd step count add nothing
+            multiply(even);
+            fetch(even, k0 + 32);
+            multiply(odd);
+        }
     }
     // dot products -> kernel values in place (D layout: reg -> row (i) = kg + 4*reg, column (j) = col) ...
 #pragma unroll
