@@ -33,13 +33,17 @@ for case in range(cases):
         X[int(rng.integers(0, n))] = X[int(rng.integers(0, n))]
     ls = float(np.sqrt(d / 12.0) * rng.uniform(0.5, 1.5))
     kw = {}
-    kind = rng.choice(["perfect", "noisy", "motivated", "subset", "mc", "clip", "mcmi", "optimistic", "topcand", "mix", "emoc", "entropy", "borderdiv"])
+    kind = rng.choice(["perfect", "noisy", "motivated", "subset", "mc", "clip", "mcmi", "optimistic", "topcand", "mix", "emoc", "entropy", "borderdiv", "bigk"])
     if kind == "noisy":
         kw = dict(label_prob=float(rng.uniform(0.3, 0.9)), mistake_prob=float(rng.uniform(0.0, 0.4)))
     elif kind == "motivated":
         kw = dict(mistake_prob=float(rng.uniform(0.05, 0.4)))
     elif kind == "subset":
         kw = dict(change_estimation_subset=int(rng.integers(1, 6)))
+    elif kind == "bigk":                          # full enumeration of larger batches on a small candidate set
+        k = int(rng.integers(5, 7))
+        n = int(rng.integers(12, 26))
+        X = X[:n] if n <= len(X) else rng.random((n, d))
     elif kind == "mc":
         kw = dict(monte_carlo_num_rel=int(rng.integers(1, 3)))
         k = int(rng.integers(3, 7))
