@@ -22,7 +22,7 @@ extern "C" {
 typedef struct ihipStream_t* hipStream_t; /* same declaration as hip_runtime_api.h */
 
 #define ITAL_MAX_T 8        /* largest batch dimension with full sign-pattern enumeration on the device */
-#define ITAL_REC_HEADER 8   /* doubles in front of the feature row inside a selection record */
+#define ITAL_REC_HEADER 10  /* doubles in front of the feature row inside a selection record */
 #define ITAL_JUMP_BITS 48
 #define ITAL_GENERIC_MAX_DIM 20  /* largest orthant dimension of the general scorer (subset + picks + candidate) */
 #define ITAL_GENERIC_MAX_REL 16  /* largest number of enumerated / sampled variables of the general scorer */
@@ -100,7 +100,9 @@ typedef struct ital_score_desc {
     const double* C;        /* [t-1][ldc] cross-covariance of member b with every row */
     int64_t ldc;
     int64_t row_offset;     /* data index of local row 0 */
-    int64_t pos_offset;     /* list position of local position 0 */
+    int64_t pos_offset;     /* list position of local position 0 (used when gpos == NULL) */
+    const int64_t* gpos;    /* [n_cand] list position of every local position when this rank's positions are not one
+                               contiguous run of the list (top_candidates on several ranks, reference ital/ital.py:111-117) */
     ital_batch batch;
     double noise, eps;
     int label_mode;         /* 0 'mean', 1 'optimistic', 2 'pessimistic' (reference ital/ital.py:210-219) */
@@ -108,15 +110,17 @@ typedef struct ital_score_desc {
     /* t >= 3: replay of SciPy mvndst's MVNUNI stream (serial evaluation order of the reference) */
     int seed[6];            /* generator state before the first call of this greedy step */
     const long long* jump;  /* [ITAL_JUMP_BITS][18] transition matrices for 2^b calls of dimension t */
-    const long long* jumplane; /* [64][18] transition matrices for 0..63 lattice shifts (2(t-1)-1 uniforms each; 8 = one call) */
+    const long long* jumppat; /* [2^t][18] transition matrices for 2r calls, r = 0..2^t-1 (the prior-probability call of
+                               sign pattern r is call 2r of a candidate, the one after the simulated update call 2r+1) */
     const double* vk;       /* [t-1] Korobov generator vector of this dimension */
-    int* status;            /* |= 2: singular conditional covariance met */
-    /* t >= 3, label_mode 0: a candidate's 2*2^t calls may be split over up to `split` waves (rounded down to a power of
-     * two, at least 8 calls per wave) to even out the grid's last scheduling round; partial sums go through `partial`
-     * ([n_cand][split] doubles) and are added in a fixed order.  split <= 1 or partial == NULL: one wave per candidate. */
-    int split;
-    double* partial;
-    int* seeds;             /* t >= 3: scratch of n_cand * max(split, 1) * 6 ints (generator state per work item) */
+    int* status;            /* |= 2: singular conditional covariance met; |= 4: a probability after the simulated update is
+                               not decided by its limits alone (noise > ~3e-4).  Either way mi[] is not valid and the step
+                               belongs to ital_score_generic */
+    /* t >= 3: workspace of `work_doubles` doubles in device memory, at least ital_score_workspace(t, 1); the candidates
+     * are processed in slabs of work_doubles / ital_score_workspace(t, 1) (prepared calls: factor, limits, the 8 shifted
+     * lattices of every evaluated call -- 0.5 to 1 KB per call) */
+    double* work;
+    int64_t work_doubles;
 } ital_score_desc;
 
 /* Scores every live candidate position: mi[p] = MI(batch + candidate p).
@@ -125,29 +129,35 @@ typedef struct ital_score_desc {
  * updated_prob_rel (:432-450, gp.updated_prediction / extend_inv). */
 int ital_score_step(const ital_score_desc* d, hipStream_t stream);
 
+/* Doubles of workspace that let ital_score_step(t >= 3) handle n_cand candidates in one slab (0 for t < 3). */
+int64_t ital_score_workspace(int t, int64_t n_cand);
+
 /* Local arg-extreme over the live positions + selection record for the exchange between ranks.
  * mode 0: first maximum, NaN wins (np.argmax, reference ital/ital.py:130); mode 1: first minimum (np.argmin,
- * ital/mcmi.py:77).  record = [value, list position, data index, mu, s2, |x|^2, rank, local position,
- * x[ldx], V column[ldw], cross-covariances with the members[kmax]]; value = NaN-free sentinel when the rank has
- * no live candidate (record[1] < 0).  work: >= 2*1024 doubles. */
+ * ital/mcmi.py:77).  record = [value, list position, data index, mu, s2, |x|^2, rank, local position, the rank's
+ * status word (*status, or 0 when status == NULL), reserved, x[ldx], V column[ldw], cross-covariances with the
+ * members[kmax]]; record[1] < 0 when the rank has no live candidate.  List position of local position q:
+ * gpos[q], or pos_offset + q when gpos == NULL.  work: >= 3*1024 doubles. */
 int ital_select_local(const double* mi, const int32_t* cand, const uint8_t* alive, int64_t n_cand, int64_t pos_offset,
-                      int64_t row_offset, int rank, int mode, const double* mu, const double* s2, const double* X,
-                      const double* xnorm, int ldx, const double* V, int64_t ldv, int m, int ldw, const double* C,
-                      int64_t ldc, int nprev, int kmax, double* work, double* record, hipStream_t stream);
+                      const int64_t* gpos, int64_t row_offset, int rank, int mode, const double* mu, const double* s2,
+                      const double* X, const double* xnorm, int ldx, const double* V, int64_t ldv, int m, int ldw,
+                      const double* C, int64_t ldc, int nprev, int kmax, const int* status, double* work, double* record,
+                      hipStream_t stream);
 
 /* Picks the winner among `world` records (same rule, lowest list position on ties), appends it to the batch
- * state as member `slot`, clears its alive flag on the owning rank and stores its data index in ret[slot].
+ * state as member `slot`, clears its alive flag on the owning rank and stores its data index in ret[slot];
+ * ret[kmax] |= the OR of the status words of all records, so that every rank reads the same verdict (ret: kmax + 1).
  * Replaces mutual_information.append + del candidates[max_ind], reference ital/ital.py:131-132, :561-586. */
 int ital_select_resolve(const double* records, int world, int rec_len, int rank, int mode, int slot,
                         ital_batch batch, uint8_t* alive, int64_t* ret, hipStream_t stream);
 
 /* ital_select_local + ital_select_resolve for ONE rank in a single launch (small problems are launch-latency bound).
- * Same semantics; `record` is scratch of 8 + ldx + ldw + kmax doubles. */
+ * Same semantics; `record` is scratch of ITAL_REC_HEADER + ldx + ldw + kmax doubles. */
 int ital_select_fused(const double* mi, const int32_t* cand, uint8_t* alive, int64_t n_cand, int64_t pos_offset,
-                      int64_t row_offset, int rank, int mode, const double* mu, const double* s2, const double* X,
-                      const double* xnorm, int ldx, const double* V, int64_t ldv, int m, int ldw, const double* C,
-                      int64_t ldc, int nprev, int slot, ital_batch batch, double* record, int64_t* ret,
-                      hipStream_t stream);
+                      const int64_t* gpos, int64_t row_offset, int rank, int mode, const double* mu, const double* s2,
+                      const double* X, const double* xnorm, int ldx, const double* V, int64_t ldv, int m, int ldw,
+                      const double* C, int64_t ldc, int nprev, int slot, ital_batch batch, const int* status,
+                      double* record, int64_t* ret, hipStream_t stream);
 
 /* ---- MCMI[min] (pairwise objective) ---------------------------------------------------------------------- */
 
@@ -201,6 +211,7 @@ typedef struct ital_gscore_desc {
     const double* C;        /* [nE][ldc] posterior covariance of base member e with every row */
     int64_t ldc;
     int64_t row_offset, pos_offset;
+    const int64_t* gpos;    /* [n_cand] list position of every local position, or NULL: pos_offset + local position */
     /* base set E: the change-estimation subset followed by the picks outside it (subset_mode 1), or the picks */
     int nE;
     const int64_t* E_idx;   /* [nE] data indices */

@@ -25,13 +25,13 @@ def make_batch_buffers(device, kmax, ldx, cap, ldc, world):
     b["VB"] = torch.zeros((kmax, cap), dtype=f64, device=device)
     b["C"] = torch.zeros((kmax, ldc), dtype=f64, device=device)
     b["ret"] = torch.zeros(kmax + 1, dtype=i64, device=device)   # last slot: copy of the status word (one download)
-    b["work"] = torch.zeros(2 * 1024, dtype=f64, device=device)
+    b["work"] = torch.zeros(3 * 1024, dtype=f64, device=device)
     rec_len = ITAL_REC_HEADER + ldx + cap + kmax
     b["rec_len"] = rec_len
     b["rec"] = torch.zeros(rec_len, dtype=f64, device=device)
     b["rec_all"] = torch.zeros((world, rec_len), dtype=f64, device=device)
     b["jump"] = {}
-    b["jumplane"] = {}
+    b["jumppat"] = {}
     b["vk"] = {}
     b["batch"] = ItalBatch(kmax, ldx, cap, _ptr(b["bidx"]), _ptr(b["bgpos"]), _ptr(b["bsort"]), _ptr(b["bmu"]),
                            _ptr(b["sig"]), _ptr(b["XB"]), _ptr(b["XBn"]), _ptr(b["VB"]))

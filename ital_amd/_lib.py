@@ -11,7 +11,7 @@ LIB_PATH = os.environ.get("ITAL_HIP_LIB", os.path.join(HERE, "libital_hip.so")) 
 c_void_p, c_int, c_int64, c_double = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_double
 
 ITAL_MAX_T = 8
-ITAL_REC_HEADER = 8
+ITAL_REC_HEADER = 10
 ITAL_JUMP_BITS = 48
 ITAL_GENERIC_MAX_DIM = 20
 ITAL_GENERIC_MAX_REL = 16
@@ -27,14 +27,14 @@ class ItalBatch(ctypes.Structure):
 class ItalScoreDesc(ctypes.Structure):
     _fields_ = [("t", c_int), ("n_cand", c_int64), ("cand", c_void_p), ("alive", c_void_p), ("mu", c_void_p),
                 ("s2", c_void_p), ("C", c_void_p), ("ldc", c_int64), ("row_offset", c_int64),
-                ("pos_offset", c_int64), ("batch", ItalBatch), ("noise", c_double), ("eps", c_double),
-                ("label_mode", c_int), ("mi", c_void_p), ("seed", c_int * 6), ("jump", c_void_p), ("jumplane", c_void_p),
-                ("vk", c_void_p), ("status", c_void_p), ("split", c_int), ("partial", c_void_p), ("seeds", c_void_p)]
+                ("pos_offset", c_int64), ("gpos", c_void_p), ("batch", ItalBatch), ("noise", c_double), ("eps", c_double),
+                ("label_mode", c_int), ("mi", c_void_p), ("seed", c_int * 6), ("jump", c_void_p), ("jumppat", c_void_p),
+                ("vk", c_void_p), ("status", c_void_p), ("work", c_void_p), ("work_doubles", c_int64)]
 
 
 class ItalGscoreDesc(ctypes.Structure):
     _fields_ = [("n_cand", c_int64), ("cand", c_void_p), ("alive", c_void_p), ("mu", c_void_p), ("s2", c_void_p),
-                ("C", c_void_p), ("ldc", c_int64), ("row_offset", c_int64), ("pos_offset", c_int64),
+                ("C", c_void_p), ("ldc", c_int64), ("row_offset", c_int64), ("pos_offset", c_int64), ("gpos", c_void_p),
                 ("nE", c_int), ("E_idx", c_void_p), ("E_sort", c_void_p), ("E_mu", c_void_p), ("E_sig", c_void_p),
                 ("ldE", c_int), ("n_picks", c_int), ("pick_pos", c_void_p), ("subset_mode", c_int), ("fb_mode", c_int),
                 ("label_prob", c_double), ("mistake_prob", c_double), ("label_mode", c_int), ("noise", c_double),
@@ -67,6 +67,7 @@ SIGNATURES = {
     "ital_predict": (c_int, [c_void_p, c_int64, c_int, c_void_p, c_void_p, c_int, c_void_p, c_int, c_void_p,
                              c_double, c_double, c_void_p, c_void_p, c_void_p]),
     "ital_score_step": (c_int, [ctypes.POINTER(ItalScoreDesc), c_void_p]),
+    "ital_score_workspace": (c_int64, [c_int, c_int64]),
     "ital_cov_block": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_int, c_void_p, c_int64,
                                c_void_p, c_int64, c_int, c_double, c_double, c_void_p, c_int64, c_void_p]),
     "ital_cov_abs_rowsum": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_int, c_void_p, c_int64,
@@ -74,12 +75,12 @@ SIGNATURES = {
                                     c_void_p]),
     "ital_mcmi_score_step": (c_int, [ctypes.POINTER(ItalMcmiDesc), c_void_p]),
     "ital_score_generic": (c_int, [ctypes.POINTER(ItalGscoreDesc), c_void_p]),
-    "ital_select_local": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int64, c_int, c_int, c_void_p,
+    "ital_select_local": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_void_p, c_int64, c_int, c_int, c_void_p,
                                   c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int64, c_int, c_int, c_void_p,
-                                  c_int64, c_int, c_int, c_void_p, c_void_p, c_void_p]),
-    "ital_select_fused": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int64, c_int, c_int, c_void_p,
+                                  c_int64, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "ital_select_fused": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_void_p, c_int64, c_int, c_int, c_void_p,
                                   c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int64, c_int, c_int, c_void_p,
-                                  c_int64, c_int, c_int, ItalBatch, c_void_p, c_void_p, c_void_p]),
+                                  c_int64, c_int, c_int, ItalBatch, c_void_p, c_void_p, c_void_p, c_void_p]),
     "ital_select_resolve": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, ItalBatch, c_void_p, c_void_p,
                                     c_void_p]),
 }

@@ -23,10 +23,6 @@
 #include "ital_internal.h"
 #include "qmc_common.h"
 
-#ifndef ITAL_QMC_CHUNK_LOG2
-#define ITAL_QMC_CHUNK_LOG2(T) 3   // calls per pass of a wave: 8, one lane per (call, shift) when the lattices are drawn (measured: 4 calls
-                                   // per pass -- twice the work items -- is 14 % slower at t = 3 and 7 % at t = 4: the per-pass preparation costs more than the finer grid gains)
-#endif
 #ifndef ITAL_QMC_WAVES
 #define ITAL_QMC_WAVES(T) ((T) <= 4 ? 3 : 2)   // waves per SIMD the register allocation aims at (measured)
 #endif
@@ -43,7 +39,8 @@ struct ScoreArgs {
     const double* C;        // [t-1][ldc] cross-covariance columns of the batch members
     int64_t ldc;
     int64_t row_offset;     // global data index of local row 0
-    int64_t pos_offset;     // global list position of local position 0
+    int64_t pos_offset;     // global list position of local position 0 (when gpos == nullptr)
+    const int64_t* gpos;    // [n_cand] global list position of every local position, or nullptr
     ital_batch b;
     double noise, eps;
     int label_mode;         // 0 mean, 1 optimistic, 2 pessimistic
@@ -51,10 +48,7 @@ struct ScoreArgs {
     // MVNUNI replay
     int seed[6];            // generator state at the first call of this greedy step
     const long long* jump;  // [48][18]: transition matrices for 2^b calls (of this step's dimension)
-    const long long* jumplane;  // [64][18]: transition matrices for 0..63 shifts (8 shifts = one call)
-    int* seeds;             // [n_cand * nsplit][6] generator state at the first call of every work item
-    int nsplit;             // work items per candidate (label_mode 0 only; power of two <= NCALLS / CHUNK)
-    double* part;           // [n_cand][nsplit] partial sums when nsplit > 1
+    const long long* jumplane;  // [2^t][18]: transition matrices for 2r calls (the prior call of sign pattern r)
     const double* vk;       // [t-1] Korobov generators
     int* status;
 };
@@ -152,27 +146,35 @@ __global__ __launch_bounds__(256) void score_t2_kernel(ScoreArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------------ t >= 3
+// Four kernels per greedy step, every one with all 64 lanes of its waves at work:
+//   qmc_seed_kernel    thread per candidate         MVNUNI state at the candidate's first call (jump-ahead)
+//   qmc_prep_kernel<T> thread per (candidate, r)    candidate-level algebra, the standardised prior problem of sign pattern r,
+//                                                   COVSRT, saturation verdicts, the call's 8 shifted lattices -> one record
+//   qmc_main_kernel<T> wave per (candidate, r)      the lattice sum of the prior call (the FP64-VALU bound part), MI term of r
+//   qmc_combine_kernel thread per candidate         terms of the 2^T patterns in itertools.product order -> mi
+// The records travel through a workspace in HBM (472 B per call at T = 4); the candidates are processed in slabs that fit it.
 template <int T>
 struct Qmc {
     static constexpr int NDIM = T - 1;
     static constexpr int NP = NDIM < 10 ? NDIM : 10;
     static constexpr int PRIME = P_TAB[NP - 1];
     static constexpr int NCOV = T * (T + 1) / 2;
-    static constexpr int SLAB_RAW = NCOV + 2 * T;            // packed factor, limits, expected values
-    static constexpr int SLAB = SLAB_RAW | 1;                 // odd stride: conflict-free per-lane slabs
-    static constexpr int NCALLS = 2 << T;                     // 2 * 2^T
-    static constexpr int CHUNK_LOG2 = ITAL_QMC_CHUNK_LOG2(T);
-    static constexpr int CHUNK = 1 << CHUNK_LOG2;             // calls prepared per pass (LDS: slab + lattice per call), <= 8
-    static constexpr int NCHUNK = NCALLS / CHUNK;             // work items a candidate can be split into
     static constexpr int NCOR = T * (T - 1) / 2;
-    // wave-shared candidate area (doubles): pivot, correl, mu0', G, sd', then ints perm
-    static constexpr int A_PIVOT = 0, A_COR = A_PIVOT + T, A_MU0 = A_COR + NCOR, A_G = A_MU0 + T, A_SD = A_G + T * T,
-                         A_SIZE = A_SD + T;
+    static constexpr int NPAT = 1 << T;                       // sign patterns = prior calls per candidate
+    static constexpr int NCALLS = 2 << T;                     // calls the reference makes per candidate (prior + updated)
     static constexpr int LAT = 8 * NDIM * 2;                  // per call: permuted generators + shifts, 8 shifts
+    static constexpr int R_LIM = NCOR, R_META = NCOR + T, R_LAT = NCOR + T + 1;
+    static constexpr int REC = R_LAT + LAT;                   // doubles per prepared call
+    static constexpr int SLAB_RAW = NCOV + 2 * T + NDIM;      // prep scratch per thread: packed factor, limits, expected values, generators
+    static constexpr int SLAB = SLAB_RAW | 1;                 // odd stride: conflict-free per-thread slabs
+    static constexpr int PREP_THREADS = T <= 6 ? 256 : 128;
     static constexpr int TAILQ = 128 * ITAL_QMC_NH;           // compaction queue of the Phi^-1 tail branch (in place)
-    static constexpr int SWAPS = (CHUNK * 8 * NDIM + 1) / 2;  // ints: transposition targets of every (call, shift)
-    static constexpr int WAVE_DOUBLES = CHUNK * (SLAB + LAT) + A_SIZE + T + TAILQ + SWAPS + CHUNK;  // + perm, per-call sums
+    static constexpr int WAVE_DOUBLES = LAT + TAILQ;
+    static constexpr int64_t CAND_DOUBLES = (int64_t)NPAT * (REC + 1) + 3;   // records, terms, 6 ints of generator state
 };
+// meta word of a record: bit 0 evaluate the lattice sum; bit 1 prior probability == 1 (else 0) when not evaluated;
+// bit 2 probability after the simulated update == 1 (else 0); bits 8.. limit types after COVSRT
+constexpr long long META_EVAL = 1, META_PRIOR_ONE = 2, META_POST_ONE = 4;
 
 // Swap rows/columns p < q of the packed lower-triangular matrix, the limits and the limit-type bits (RCSWP).
 template <int T>
@@ -235,323 +237,305 @@ __device__ bool covsrt(double* cov, double* lim, double* y, unsigned& infi) {
     return ok;
 }
 
-// MVNUNI state at the first call of every work item (candidate position p, part): the step's seed advanced by
-// (rank of p among the live positions) * ncalls + part * ncalls / nsplit calls.  One thread per item: the jump-ahead
-// (a 3x3 matrix product mod m per set bit of the offset) costs ~5000 scalar instructions when a wave does it for itself,
-// which at 12 waves per CU on one scalar unit was ~10 % of the scorer's time.
-__global__ __launch_bounds__(256) void qmc_seed_kernel(ScoreArgs a, int ncalls, int* __restrict__ seeds) {
-    const int64_t item = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const int64_t p = item / a.nsplit;
-    if (p >= a.n_cand || !a.alive[p]) return;
-    const int part = (int)(item - p * a.nsplit);
-    const int64_t gpos = a.pos_offset + p;
+// Verdict on an orthant problem from its standardised limits alone (no COVSRT): whatever order COVSRT picks, the
+// conditional limit of variable a is (lim_a - sum_j c_aj y_j) / c_aa with sum_j c_aj^2 + c_aa^2 = 1 and |y_j| <= 9, so it
+// stays beyond +-37 (where MVNPHI is exactly 0 or 1) once |lim_a| > 37 + 9 sqrt(T - 1).  l[a]: the limit in the variable's
+// own direction (interval [l, inf)).  Returns 2 (probability exactly 1), 4 (exactly 0) or 0 (undecided).
+template <int T>
+__device__ __forceinline__ int early_verdict(const double (&l)[T]) {
+    const double thr = 37.0 + 9.0 * sqrt((double)(T - 1));
+    bool all_full = true, any_empty = false;
+#pragma unroll
+    for (int a = 0; a < T; a++) {
+        if (l[a] > thr) any_empty = true;
+        if (!(l[a] < -thr)) all_full = false;
+    }
+    return any_empty ? 4 : (all_full ? 2 : 0);
+}
+
+__device__ __forceinline__ int64_t list_position(const ScoreArgs& a, int64_t p) { return a.gpos ? a.gpos[p] : a.pos_offset + p; }
+
+// MVNUNI state at the first call of every candidate of the slab: the step's seed advanced by
+// (rank of the candidate among the live list positions) * ncalls calls -- one 3x3 matrix product mod m per set bit.
+__global__ __launch_bounds__(256) void qmc_seed_kernel(ScoreArgs a, int ncalls, int64_t slab_lo, int64_t slab_n,
+                                                       int* __restrict__ seeds) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= slab_n) return;
+    const int64_t p = slab_lo + i;
+    if (!a.alive[p]) return;
+    const int64_t gpos = list_position(a, p);
     int64_t before = gpos;
-    for (int i = 0; i < a.t - 1; i++) before -= (a.b.bgpos[i] < gpos) ? 1 : 0;
-    uint64_t calls_before = (uint64_t)before * (uint64_t)ncalls + (uint64_t)(part * (ncalls / a.nsplit));
+    for (int q = 0; q < a.t - 1; q++) before -= (a.b.bgpos[q] < gpos) ? 1 : 0;
+    uint64_t calls_before = (uint64_t)before * (uint64_t)ncalls;
     MrgState rng = {a.seed[0], a.seed[1], a.seed[2], a.seed[3], a.seed[4], a.seed[5]};
     for (int bit = 0; calls_before != 0; bit++, calls_before >>= 1)
         if (calls_before & 1) mrg_apply(rng, a.jump + bit * 18);
-    int* sp = seeds + item * 6;
+    int* sp = seeds + i * 6;
     sp[0] = rng.x10; sp[1] = rng.x11; sp[2] = rng.x12; sp[3] = rng.x20; sp[4] = rng.x21; sp[5] = rng.x22;
 }
 
 template <int T>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(ITAL_QMC_WAVES(T), ITAL_QMC_WAVES(T)))) void score_qmc_kernel(ScoreArgs a) {
+__global__ __launch_bounds__(Qmc<T>::PREP_THREADS) void qmc_prep_kernel(ScoreArgs a, int64_t slab_lo, int64_t slab_n,
+                                                                         const int* __restrict__ seeds,
+                                                                         double* __restrict__ recs) {
     using Q = Qmc<T>;
     extern __shared__ double lds_all[];
-    const int lane = threadIdx.x & 63;
-    const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    // work item of this wave: candidate position p, chunks [part * cpi, (part + 1) * cpi) of its calls.  Splitting the
-    // candidates evens out the last scheduling round of the grid (9298 one-candidate waves on 3072 wave slots take as
-    // long as 12288 would); the partial sums are combined in a fixed order by score_combine_kernel.
-    const int64_t item = (int64_t)blockIdx.x * 4 + wid;
-    const int64_t p = item / a.nsplit;
-    const int part = (int)(item - p * a.nsplit);
-    const int chunk_lo = part * (Q::NCALLS / a.nsplit), chunk_hi = chunk_lo + Q::NCALLS / a.nsplit;
-    if (p >= a.n_cand) return;
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= slab_n) return;
+    const int64_t p = slab_lo + i;
     if (!a.alive[p]) return;
-    double* W = lds_all + (size_t)wid * Q::WAVE_DOUBLES;
-    double* slabs = W;
-    double* area = W + Q::CHUNK * Q::SLAB;
-    double* lats = area + Q::A_SIZE;         // per prepared call: [8][NDIM] generators, then [8][NDIM] shifts
-    int* perm = reinterpret_cast<int*>(lats + Q::CHUNK * Q::LAT);  // T ints: natural index held at each sorted slot
-    double* tailq = lats + Q::CHUNK * Q::LAT + T;
-    int* swaps = reinterpret_cast<int*>(tailq + Q::TAILQ);
-    double* vals = tailq + Q::TAILQ + Q::SWAPS;   // lattice sums of the calls of a pass
-
+    const int r = blockIdx.y;                   // sign pattern: bit T-1-v = variable v relevant (itertools.product order)
     const int row = a.cand[p];
-    const int64_t gi = a.row_offset + row;
+    double* rec = recs + ((int64_t)i * Q::NPAT + r) * Q::REC;
 
-    // ---------------- Phase A: candidate-level quantities (identical in every lane)
+    // ---------------- candidate-level quantities
+    double mean[T], Sg[T][T];
+#pragma unroll
+    for (int v = 0; v < T - 1; v++) {
+        mean[v] = a.b.bmu[v];
+#pragma unroll
+        for (int j = 0; j < T - 1; j++) Sg[v][j] = a.b.sig[v * a.b.kmax + j];
+        const double c = a.C[(int64_t)v * a.ldc + row];
+        Sg[v][T - 1] = c;
+        Sg[T - 1][v] = c;
+    }
+    mean[T - 1] = a.mu[row];
+    Sg[T - 1][T - 1] = a.s2[row];  // not clamped (gp.py:254)
+    double sd[T], own[T];
+    long long meta = 0;
+    // ---------------- the probability after the simulated update with the labels r: closed form on the t x t block,
+    // W = (Sigma + noise I)^-1 through its Cholesky factor, G = I - noise W, mu' = mu + G (f - mu), Sigma' = noise G.
+    // With the perfect user every variable lands ~1/sqrt(noise) standard deviations on its own side: decided here.
     {
-        double mean[T], Sg[T][T];
-#pragma unroll
-        for (int i = 0; i < T - 1; i++) {
-            mean[i] = a.b.bmu[i];
-#pragma unroll
-            for (int j = 0; j < T - 1; j++) Sg[i][j] = a.b.sig[i * a.b.kmax + j];
-            const double c = a.C[(int64_t)i * a.ldc + row];
-            Sg[i][T - 1] = c;
-            Sg[T - 1][i] = c;
-        }
-        mean[T - 1] = a.mu[row];
-        Sg[T - 1][T - 1] = a.s2[row];  // not clamped (gp.py:254)
-        double sd[T];
-#pragma unroll
-        for (int i = 0; i < T; i++) {
-            sd[i] = sqrt(Sg[i][i]);
-            area[Q::A_PIVOT + i] = -mean[i] / sd[i];
-        }
-#pragma unroll
-        for (int i = 1; i < T; i++)
-#pragma unroll
-            for (int j = 0; j < i; j++) area[Q::A_COR + i * (i - 1) / 2 + j] = Sg[i][j] / (sd[i] * sd[j]);
-        // W = (Sigma + noise I)^-1 through its Cholesky factor, G = I - noise W
         double Lc[T][T];
 #pragma unroll
-        for (int i = 0; i < T; i++)
+        for (int v = 0; v < T; v++)
 #pragma unroll
-            for (int j = 0; j <= i; j++) {
-                double v = Sg[i][j] + (i == j ? a.noise : 0.0);
+            for (int j = 0; j <= v; j++) {
+                double x = Sg[v][j] + (v == j ? a.noise : 0.0);
 #pragma unroll
-                for (int q = 0; q < j; q++) v -= Lc[i][q] * Lc[j][q];
-                Lc[i][j] = (i == j) ? sqrt(v) : v / Lc[j][j];
+                for (int q = 0; q < j; q++) x -= Lc[v][q] * Lc[j][q];
+                Lc[v][j] = (v == j) ? sqrt(x) : x / Lc[j][j];
             }
         double Li[T][T];  // inverse of the factor (lower)
 #pragma unroll
         for (int j = 0; j < T; j++) {
 #pragma unroll
-            for (int i = 0; i < T; i++) {
-                if (i < j) { Li[i][j] = 0; continue; }
-                double v = (i == j) ? 1.0 : 0.0;
+            for (int v = 0; v < T; v++) {
+                if (v < j) { Li[v][j] = 0; continue; }
+                double x = (v == j) ? 1.0 : 0.0;
 #pragma unroll
-                for (int q = j; q < i; q++) v -= Lc[i][q] * Li[q][j];
-                Li[i][j] = v / Lc[i][i];
+                for (int q = j; q < v; q++) x -= Lc[v][q] * Li[q][j];
+                Li[v][j] = x / Lc[v][v];
             }
         }
-        double G[T][T];
 #pragma unroll
-        for (int i = 0; i < T; i++)
-#pragma unroll
-            for (int j = 0; j <= i; j++) {
-                double w = 0;
-#pragma unroll
-                for (int q = i; q < T; q++) w += Li[q][i] * Li[q][j];
-                const double gij = (i == j ? 1.0 : 0.0) - a.noise * w;
-                G[i][j] = gij;
-                G[j][i] = gij;
-            }
-#pragma unroll
-        for (int i = 0; i < T; i++) {
-            double gm = 0;
+        for (int v = 0; v < T; v++) {
+            double mu_u = mean[v], gvv = 0;
 #pragma unroll
             for (int j = 0; j < T; j++) {
-                gm += G[i][j] * mean[j];
-                area[Q::A_G + i * T + j] = G[i][j];
-            }
-            area[Q::A_MU0 + i] = mean[i] - gm;
-            area[Q::A_SD + i] = sqrt(a.noise * G[i][i]);
-        }
-        // sorted-by-data-index order of (batch members, candidate)
-        int rank = 0;
+                double w = 0;
 #pragma unroll
-        for (int i = 0; i < T - 1; i++) rank += (a.b.bidx[i] < gi) ? 1 : 0;
-#pragma unroll
-        for (int s = 0; s < T; s++) {
-            int src;
-            if (s < rank) src = a.b.bsort[s];
-            else if (s == rank) src = T - 1;
-            else src = a.b.bsort[s - 1];
-            perm[s] = src;
-        }
-    }
-    // ---------------- stream position of this work item (prepared by qmc_seed_kernel, one thread per item)
-    MrgState rng;
-    {
-        const int* sp = a.seeds + item * 6;
-        rng.x10 = __builtin_amdgcn_readfirstlane(sp[0]); rng.x11 = __builtin_amdgcn_readfirstlane(sp[1]);
-        rng.x12 = __builtin_amdgcn_readfirstlane(sp[2]); rng.x20 = __builtin_amdgcn_readfirstlane(sp[3]);
-        rng.x21 = __builtin_amdgcn_readfirstlane(sp[4]); rng.x22 = __builtin_amdgcn_readfirstlane(sp[5]);
-    }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-
-    double mi = 0.0;
-    double pr_cur = 0.0;
-    for (int chunk = chunk_lo; chunk < chunk_hi; chunk += Q::CHUNK) {
-        // ---------------- Phase B: lane l prepares call chunk + l (limits, pattern bits, COVSRT) in its LDS slab
-        bool sat = false, okc = true;
-        unsigned infi = 0;
-        if (lane < Q::CHUNK) {
-            const int call = chunk + lane;
-            const int r = call >> 1;
-            double* cov = slabs + lane * Q::SLAB;
-            double* lim = cov + Q::NCOV;
-            double* y = lim + T;
-            if ((call & 1) == 0) {
-                for (int i = 0; i < T; i++) {
-                    lim[i] = area[Q::A_PIVOT + i];
-                    infi |= (unsigned)((r >> (T - 1 - i)) & 1) << i;
-                    for (int j = 0; j < i; j++) cov[pidx(i, j)] = area[Q::A_COR + i * (i - 1) / 2 + j];
-                    cov[pidx(i, i)] = 1.0;
-                }
-            } else {
-                for (int s = 0; s < T; s++) {
-                    const int nat = perm[s];
-                    double mu_u = area[Q::A_MU0 + nat];
-                    for (int j = 0; j < T; j++) {
-                        const double f = ((r >> (T - 1 - j)) & 1) ? 1.0 : -1.0;
-                        mu_u += area[Q::A_G + nat * T + j] * f;
-                    }
-                    const double sds = area[Q::A_SD + nat];
-                    lim[s] = -mu_u / sds;
-                    infi |= (unsigned)((r >> (T - 1 - nat)) & 1) << s;
-                    for (int s2 = 0; s2 < s; s2++) {
-                        const int nat2 = perm[s2];
-                        cov[pidx(s, s2)] = (a.noise * area[Q::A_G + nat * T + nat2]) / (sds * area[Q::A_SD + nat2]);
-                    }
-                    cov[pidx(s, s)] = 1.0;
-                }
+                for (int q = (v > j ? v : j); q < T; q++) w += Li[q][v] * Li[q][j];
+                const double gvj = (v == j ? 1.0 : 0.0) - a.noise * w;
+                const double f = ((r >> (T - 1 - j)) & 1) ? 1.0 : -1.0;
+                mu_u += gvj * (f - mean[j]);
+                if (j == v) gvv = gvj;
             }
-            okc = covsrt<T>(cov, lim, y, infi);
-            // integrand identically 1?  every conditional limit stays beyond +-37 for any |y| <= 9
-            sat = okc;
-            for (int i = 0; i < T; i++) {
+            const double lim_u = -mu_u / sqrt(a.noise * gvv);
+            own[v] = ((r >> (T - 1 - v)) & 1) ? lim_u : -lim_u;
+        }
+        const int e = early_verdict<T>(own);
+        if (e == 2) meta |= META_POST_ONE;
+        else if (e == 0) atomicOr(a.status, 4);   // an updated probability that needs the integrator: the general scorer's job
+    }
+    // ---------------- the prior probability of pattern r: standardised problem in natural order (ital.py:373-383)
+    double* cov = lds_all + (size_t)threadIdx.x * Q::SLAB;
+    double* lim = cov + Q::NCOV;
+    double* y = lim + T;
+    double* gen = y + T;
+    unsigned infi = 0;
+#pragma unroll
+    for (int v = 0; v < T; v++) {
+        sd[v] = sqrt(Sg[v][v]);
+        const double piv = -mean[v] / sd[v];
+        const unsigned bit = (r >> (T - 1 - v)) & 1;
+        lim[v] = piv;
+        own[v] = bit ? piv : -piv;
+        infi |= bit << v;
+    }
+    int verdict = early_verdict<T>(own);
+    bool evaluate = false;
+    if (verdict == 0) {
+#pragma unroll
+        for (int v = 0; v < T; v++) {
+#pragma unroll
+            for (int j = 0; j < v; j++) cov[pidx(v, j)] = Sg[v][j] / (sd[v] * sd[j]);
+            cov[pidx(v, v)] = 1.0;
+        }
+        const bool okc = covsrt<T>(cov, lim, y, infi);
+        if (!okc) {
+            atomicOr(a.status, 2);  // singular conditional covariance: not supported by this kernel (general scorer)
+        } else {
+            // integrand identically 1 / 0?  every conditional limit stays beyond +-37 for any |y| <= 9
+            bool sat1 = true, sat0 = false;
+            for (int v = 0; v < T; v++) {
                 double bound = 0;
-                for (int j = 0; j < i; j++) bound += fabs(cov[pidx(i, j)]) * 9.0;
-                const bool lower = (infi >> i) & 1u;
-                if (lower) { if (!(lim[i] + bound < -37.0)) sat = false; }
-                else { if (!(lim[i] - bound > 37.0)) sat = false; }
-            }
-        }
-        // The 8 randomly shifted lattices of every call that is evaluated.  A call draws 8*(2*NDIM-1) uniforms from MVNUNI
-        // whether it is evaluated or not: per shift NDIM-1 for DKSMRC's random transposition of the generator vector, then
-        // NDIM shifts.  Lane 8c + s jumps to shift s of call c (one matrix product) and replays only that shift's draws;
-        // the transpositions, which accumulate from shift to shift, are then applied by the call's own lane.
-        {
-            const int c = lane >> 3, sft = lane & 7;
-            const bool sat_c = __shfl((int)sat, c, 64) != 0;
-            if (c < Q::CHUNK && !sat_c) {
-                MrgState sti = rng;
-                mrg_apply(sti, a.jumplane + lane * 18);
-                MrgStateF st = mrg_to_f(sti);
-                int* sw = swaps + (c * 8 + sft) * Q::NDIM;
-                for (int j = 1; j <= Q::NDIM - 1; j++) {
-                    const double u = mrg_next_f(st);
-                    sw[j - 1] = (int)(j + u * (Q::NDIM + 1 - j));
-                }
-                double* L = lats + c * Q::LAT;
-                for (int j = 0; j < Q::NDIM; j++) L[8 * Q::NDIM + sft * Q::NDIM + j] = mrg_next_f(st);
-            }
-        }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        if (lane < Q::CHUNK && !sat) {
-            double* L = lats + lane * Q::LAT;
-            for (int j = 0; j < Q::NDIM; j++) L[j] = a.vk[j];
-            for (int sft = 0; sft < 8; sft++) {
-                double* row = L + sft * Q::NDIM;
-                if (sft > 0)
-                    for (int j = 0; j < Q::NDIM; j++) row[j] = row[j - Q::NDIM];
-                const int* sw = swaps + (lane * 8 + sft) * Q::NDIM;
-                for (int j = 1; j <= Q::NDIM - 1; j++) {
-                    const int jp = sw[j - 1];
-                    const double xt = row[j - 1];
-                    row[j - 1] = row[jp - 1];
-                    row[jp - 1] = xt;
+                for (int j = 0; j < v; j++) bound += fabs(cov[pidx(v, j)]) * 9.0;
+                const bool lower = (infi >> v) & 1u;
+                if (lower) {
+                    if (!(lim[v] + bound < -37.0)) sat1 = false;
+                    if (lim[v] - bound > 37.0) sat0 = true;
+                } else {
+                    if (!(lim[v] - bound > 37.0)) sat1 = false;
+                    if (lim[v] + bound < -37.0) sat0 = true;
                 }
             }
+            if (sat0) verdict = 4;
+            else if (sat1) verdict = 2;
+            else evaluate = true;
         }
-        mrg_apply(rng, a.jump + Q::CHUNK_LOG2 * 18);   // the wave's base state moves on by CHUNK calls
-        if (!okc) atomicOr(a.status, 2);  // singular conditional covariance: not supported by this kernel
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-
-        // ---------------- Phase C: the wave evaluates the calls of this chunk one after the other
-        for (int cl = 0; cl < Q::CHUNK; cl++) {
-            // wave-uniform copies (SGPR) of the preparing lane's flags: keeps the generator arithmetic on the scalar unit
-            const bool sat_c = __builtin_amdgcn_readlane((int)sat, cl) != 0;
-            const unsigned infi_c = (unsigned)__builtin_amdgcn_readlane((int)infi, cl);
-            if (!sat_c) {
-                const double* lat = lats + cl * Q::LAT;
-                // per-call constants out of the preparing lane's slab, as wave-uniform (scalar) values
-                const double* cov = slabs + cl * Q::SLAB;
-                double cf[Q::NCOR > 0 ? Q::NCOR : 1], lm[T];
-#pragma unroll
-                for (int i = 0; i < T; i++) {
-                    lm[i] = uniform_f64(cov[Q::NCOV + i]);
-#pragma unroll
-                    for (int j = 0; j < i; j++) cf[i * (i - 1) / 2 + j] = uniform_f64(cov[pidx(i, j)]);
-                }
-                const double acc = qmc_lane_sum<T>(lat, cf, lm, infi_c, tailq, lane);
-                const double tot = wave_sum(acc);
-                if (lane == 0) vals[cl] = tot;
-            }
-        }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        // the calls' values enter the sum in call order (prior probability, then the one after the simulated update)
-        for (int cl = 0; cl < Q::CHUNK; cl++) {
-            const int call = chunk + cl;
-            const bool sat_c = __builtin_amdgcn_readlane((int)sat, cl) != 0;
-            const double value = sat_c ? 1.0 : vals[cl] / (16.0 * Q::PRIME);
-            if ((call & 1) == 0) {
-                pr_cur = value;
-            } else {
-                mi_accumulate(mi, pr_cur, value, a.eps, a.label_mode);
-            }
-        }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     }
-    if (lane == 0) {
-        if (a.nsplit == 1) a.mi[p] = mi;
-        else a.part[p * a.nsplit + part] = mi;
+    if (verdict == 2) meta |= META_PRIOR_ONE;
+    if (evaluate) {
+        meta |= META_EVAL | ((long long)infi << 8);
+        for (int v = 1; v < T; v++)
+            for (int j = 0; j < v; j++) rec[v * (v - 1) / 2 + j] = cov[pidx(v, j)];
+        for (int v = 0; v < T; v++) rec[Q::R_LIM + v] = lim[v];
+        // The call's 8 randomly shifted lattices.  A call draws 8*(2*NDIM-1) uniforms from MVNUNI whether it is evaluated or
+        // not: per shift NDIM-1 for DKSMRC's random transposition of the generator vector (the transpositions accumulate
+        // from shift to shift), then NDIM shifts.  The prior call of pattern r is call 2r of the candidate.
+        const int* sp = seeds + i * 6;
+        MrgState sti = {sp[0], sp[1], sp[2], sp[3], sp[4], sp[5]};
+        mrg_apply(sti, a.jumplane + (int64_t)r * 18);   // row r: 2r calls
+        MrgStateF st = mrg_to_f(sti);
+        for (int j = 0; j < Q::NDIM; j++) gen[j] = a.vk[j];
+        double* L = rec + Q::R_LAT;
+        for (int sft = 0; sft < 8; sft++) {
+            for (int j = 1; j <= Q::NDIM - 1; j++) {
+                const double u = mrg_next_f(st);
+                const int jp = (int)(j + u * (Q::NDIM + 1 - j));
+                const double xt = gen[j - 1];
+                gen[j - 1] = gen[jp - 1];
+                gen[jp - 1] = xt;
+            }
+            for (int j = 0; j < Q::NDIM; j++) L[sft * Q::NDIM + j] = gen[j];
+            for (int j = 0; j < Q::NDIM; j++) L[8 * Q::NDIM + sft * Q::NDIM + j] = mrg_next_f(st);
+        }
     }
-}
-
-// mi[p] = sum of the partial sums of position p, in part order (deterministic).
-__global__ __launch_bounds__(256) void score_combine_kernel(const double* __restrict__ part, const uint8_t* __restrict__ alive,
-                                                            int64_t n_cand, int nsplit, double* __restrict__ mi) {
-    const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (p >= n_cand || !alive[p]) return;
-    double s = 0.0;
-    for (int j = 0; j < nsplit; j++) s += part[p * nsplit + j];
-    mi[p] = s;
+    rec[Q::R_META] = __longlong_as_double(meta);
 }
 
 template <int T>
-static int launch_qmc(const ScoreArgs& a, hipStream_t stream) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(ITAL_QMC_WAVES(T), ITAL_QMC_WAVES(T)))) void qmc_main_kernel(
+    const uint8_t* __restrict__ alive, int64_t slab_lo, int64_t slab_n, const double* __restrict__ recs, double eps,
+    int label_mode, double* __restrict__ terms) {
     using Q = Qmc<T>;
-    const size_t lds = (size_t)4 * Q::WAVE_DOUBLES * sizeof(double);
-    const int64_t blocks = (a.n_cand * a.nsplit + 3) / 4;
+    extern __shared__ double lds_all[];
+    const int lane = threadIdx.x & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int64_t item = (int64_t)blockIdx.x * 4 + wid;          // (candidate of the slab, sign pattern)
+    const int64_t i = item >> T;
+    if (i >= slab_n) return;
+    if (!alive[slab_lo + i]) return;
+    const double* rec = recs + item * Q::REC;
+    const long long meta = __double_as_longlong(uniform_f64(rec[Q::R_META]));
+    double pr = (meta & META_PRIOR_ONE) ? 1.0 : 0.0;
+    if (meta & META_EVAL) {
+        double* lat = lds_all + (size_t)wid * Q::WAVE_DOUBLES;
+        double* tailq = lat + Q::LAT;
+        for (int q = lane; q < Q::LAT; q += 64) lat[q] = rec[Q::R_LAT + q];
+        double cf[Q::NCOR > 0 ? Q::NCOR : 1], lm[T];
+#pragma unroll
+        for (int q = 0; q < Q::NCOR; q++) cf[q] = uniform_f64(rec[q]);
+#pragma unroll
+        for (int q = 0; q < T; q++) lm[q] = uniform_f64(rec[Q::R_LIM + q]);
+        const unsigned infi = (unsigned)(meta >> 8);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        const double acc = qmc_lane_sum<T>(lat, cf, lm, infi, tailq, lane);
+        pr = wave_sum(acc) / (16.0 * Q::PRIME);
+    }
+    if (lane == 0) {
+        const double pu = (meta & META_POST_ONE) ? 1.0 : 0.0;
+        const double cur = log_eps(pu, eps) - log_eps(pr, eps);   // perfect user: likelihood weight 1 (ital.py:208)
+        terms[item] = label_mode == 0 ? cur * pr : cur;
+    }
+}
+
+// mi[p] from the terms of the 2^T patterns, in pattern order (the reference's loop, ital.py:207-222).
+__global__ __launch_bounds__(256) void qmc_combine_kernel(const double* __restrict__ terms, const uint8_t* __restrict__ alive,
+                                                          int64_t slab_lo, int64_t slab_n, int npat, int label_mode,
+                                                          double* __restrict__ mi) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= slab_n || !alive[slab_lo + i]) return;
+    double s = 0.0;
+    for (int r = 0; r < npat; r++) {
+        const double cur = terms[i * npat + r];
+        if (label_mode == 1) { if (cur > s) s = cur; }
+        else if (label_mode == 2) { if (s == 0 || cur < s) s = cur; }
+        else s += cur;
+    }
+    mi[slab_lo + i] = s;
+}
+
+template <int T>
+static int launch_qmc(const ScoreArgs& a, double* work, int64_t work_doubles, hipStream_t stream) {
+    using Q = Qmc<T>;
+    int64_t slab = work_doubles / Q::CAND_DOUBLES;
+    if (slab < 1) return ital_fail(-12, "ital_score_step: workspace smaller than one candidate (see ital_score_workspace)");
+    if (slab > a.n_cand) slab = a.n_cand;
+    const size_t lds_main = (size_t)4 * Q::WAVE_DOUBLES * sizeof(double);
+    const size_t lds_prep = (size_t)Q::PREP_THREADS * Q::SLAB * sizeof(double);
     static bool attr_done = false;
-    if (!attr_done && lds > 48 * 1024) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&score_qmc_kernel<T>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return ital_fail(-12, "score_qmc: cannot raise the dynamic LDS limit");
+    if (!attr_done && lds_prep > 48 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&qmc_prep_kernel<T>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_prep);
+        if (e != hipSuccess) return ital_fail(-12, "ital_score_step: cannot raise the dynamic LDS limit");
         attr_done = true;
     }
-    const int64_t items = a.n_cand * a.nsplit;
-    hipLaunchKernelGGL(qmc_seed_kernel, dim3((unsigned)((items + 255) / 256)), dim3(256), 0, stream, a, Q::NCALLS, a.seeds);
-    int rc0 = ital_check_launch("ital_score_step(seeds)");
-    if (rc0) return rc0;
-    hipLaunchKernelGGL(score_qmc_kernel<T>, dim3((unsigned)blocks), dim3(256), lds, stream, a);
-    int rc = ital_check_launch("ital_score_step(qmc)");
-    if (rc || a.nsplit == 1) return rc;
-    hipLaunchKernelGGL(score_combine_kernel, dim3((unsigned)((a.n_cand + 255) / 256)), dim3(256), 0, stream, a.part, a.alive,
-                       a.n_cand, a.nsplit, a.mi);
-    return ital_check_launch("ital_score_step(combine)");
+    double* recs = work;
+    double* terms = recs + slab * Q::NPAT * Q::REC;
+    int* seeds = reinterpret_cast<int*>(terms + slab * Q::NPAT);
+    for (int64_t lo = 0; lo < a.n_cand; lo += slab) {
+        const int64_t n = a.n_cand - lo < slab ? a.n_cand - lo : slab;
+        hipLaunchKernelGGL(qmc_seed_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, a, Q::NCALLS, lo, n, seeds);
+        hipLaunchKernelGGL(qmc_prep_kernel<T>, dim3((unsigned)((n + Q::PREP_THREADS - 1) / Q::PREP_THREADS), Q::NPAT),
+                           dim3(Q::PREP_THREADS), lds_prep, stream, a, lo, n, seeds, recs);
+        hipLaunchKernelGGL(qmc_main_kernel<T>, dim3((unsigned)((n * Q::NPAT + 3) / 4)), dim3(256), lds_main, stream, a.alive, lo,
+                           n, recs, a.eps, a.label_mode, terms);
+        hipLaunchKernelGGL(qmc_combine_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, terms, a.alive, lo, n,
+                           Q::NPAT, a.label_mode, a.mi);
+        int rc = ital_check_launch("ital_score_step(qmc)");
+        if (rc) return rc;
+    }
+    return 0;
+}
+
+template <int T>
+static int64_t qmc_cand_doubles() { return Qmc<T>::CAND_DOUBLES; }
+
+static int64_t cand_doubles(int t) {
+    switch (t) {
+        case 3: return qmc_cand_doubles<3>();
+        case 4: return qmc_cand_doubles<4>();
+        case 5: return qmc_cand_doubles<5>();
+        case 6: return qmc_cand_doubles<6>();
+        case 7: return qmc_cand_doubles<7>();
+        case 8: return qmc_cand_doubles<8>();
+    }
+    return 0;
 }
 
 }  // namespace ital
 
 using namespace ital;
+
+extern "C" int64_t ital_score_workspace(int t, int64_t n_cand) {
+    if (t < 3 || t > ITAL_MAX_T || n_cand <= 0) return 0;
+    return cand_doubles(t) * n_cand;
+}
 
 extern "C" int ital_score_step(const ital_score_desc* d, hipStream_t stream) {
     if (!d) return ital_fail(-22, "ital_score_step: null descriptor");
@@ -560,8 +544,9 @@ extern "C" int ital_score_step(const ital_score_desc* d, hipStream_t stream) {
     if (d->t > d->batch.kmax) return ital_fail(-22, "ital_score_step: t exceeds the batch capacity");
     ScoreArgs a = {};
     a.t = d->t; a.n_cand = d->n_cand; a.cand = d->cand; a.alive = d->alive; a.mu = d->mu; a.s2 = d->s2; a.C = d->C;
-    a.ldc = d->ldc; a.row_offset = d->row_offset; a.pos_offset = d->pos_offset; a.b = d->batch; a.noise = d->noise;
-    a.eps = d->eps; a.label_mode = d->label_mode; a.mi = d->mi; a.jump = d->jump; a.jumplane = d->jumplane; a.vk = d->vk; a.status = d->status;
+    a.ldc = d->ldc; a.row_offset = d->row_offset; a.pos_offset = d->pos_offset; a.gpos = d->gpos; a.b = d->batch;
+    a.noise = d->noise; a.eps = d->eps; a.label_mode = d->label_mode; a.mi = d->mi; a.jump = d->jump;
+    a.jumplane = d->jumppat; a.vk = d->vk; a.status = d->status;
     for (int i = 0; i < 6; i++) a.seed[i] = d->seed[i];
     if (d->t == 1) {
         hipLaunchKernelGGL(score_t1_kernel, dim3((unsigned)((d->n_cand + 255) / 256)), dim3(256), 0, stream, a);
@@ -571,25 +556,15 @@ extern "C" int ital_score_step(const ital_score_desc* d, hipStream_t stream) {
         hipLaunchKernelGGL(score_t2_kernel, dim3((unsigned)((d->n_cand + 31) / 32)), dim3(256), 0, stream, a);
         return ital_check_launch("ital_score_step(t=2)");
     }
-    if (!d->jump || !d->jumplane || !d->vk) return ital_fail(-22, "ital_score_step: jump tables / generators missing for t >= 3");
-    if (!d->seeds) return ital_fail(-22, "ital_score_step: seeds buffer missing for t >= 3");
-    a.seeds = d->seeds;
-    a.nsplit = 1;
-    a.part = nullptr;
-    if (d->split > 1 && d->partial && d->label_mode == 0) {
-        const int max_split = (2 << d->t) >> ITAL_QMC_CHUNK_LOG2(d->t);   // NCALLS / CHUNK
-        int ns = 1;
-        while (ns * 2 <= d->split && ns * 2 <= max_split) ns *= 2;
-        a.nsplit = ns;
-        a.part = d->partial;
-    }
+    if (!d->jump || !d->jumppat || !d->vk) return ital_fail(-22, "ital_score_step: jump tables / generators missing for t >= 3");
+    if (!d->work) return ital_fail(-22, "ital_score_step: workspace missing for t >= 3 (see ital_score_workspace)");
     switch (d->t) {
-        case 3: return launch_qmc<3>(a, stream);
-        case 4: return launch_qmc<4>(a, stream);
-        case 5: return launch_qmc<5>(a, stream);
-        case 6: return launch_qmc<6>(a, stream);
-        case 7: return launch_qmc<7>(a, stream);
-        case 8: return launch_qmc<8>(a, stream);
+        case 3: return launch_qmc<3>(a, d->work, d->work_doubles, stream);
+        case 4: return launch_qmc<4>(a, d->work, d->work_doubles, stream);
+        case 5: return launch_qmc<5>(a, d->work, d->work_doubles, stream);
+        case 6: return launch_qmc<6>(a, d->work, d->work_doubles, stream);
+        case 7: return launch_qmc<7>(a, d->work, d->work_doubles, stream);
+        case 8: return launch_qmc<8>(a, d->work, d->work_doubles, stream);
     }
     return ital_fail(-22, "ital_score_step: unsupported batch dimension");
 }

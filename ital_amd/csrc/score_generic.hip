@@ -749,7 +749,7 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(ITAL_GEN_WA
     // ---------------- stream position of this candidate in the reference's serial order
     MrgState rng = {d.seed[0], d.seed[1], d.seed[2], d.seed[3], d.seed[4], d.seed[5]};
     {
-        const int64_t gpos = d.pos_offset + p;
+        const int64_t gpos = d.gpos ? d.gpos[p] : d.pos_offset + p;
         int64_t before = gpos, n_in = 0;
         for (int i = 0; i < d.n_dead; i++) before -= (d.dead_pos[i] < gpos) ? 1 : 0;
         for (int i = 0; i < d.n_in; i++) n_in += (d.in_pos[i] < gpos) ? 1 : 0;

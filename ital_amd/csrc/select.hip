@@ -17,6 +17,7 @@ namespace ital {
 struct Best {
     double val;
     int64_t pos;  // global list position, < 0: nothing
+    int64_t loc;  // local position on the rank that holds it
 };
 
 // true if a precedes b under "first extreme, NaN wins"
@@ -36,6 +37,7 @@ __device__ __forceinline__ Best wave_best(Best v, int mode) {
         Best o;
         o.val = __shfl_xor(v.val, off, 64);
         o.pos = __shfl_xor(v.pos, off, 64);
+        o.loc = __shfl_xor(v.loc, off, 64);
         if (better(o, v, mode)) v = o;
     }
     return v;
@@ -43,15 +45,15 @@ __device__ __forceinline__ Best wave_best(Best v, int mode) {
 
 __device__ Best block_best(Best v, int mode) {
     __shared__ double sval[16];
-    __shared__ int64_t spos[16];
+    __shared__ int64_t spos[16], sloc[16];
     v = wave_best(v, mode);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
     __syncthreads();
-    if (lane == 0) { sval[wave] = v.val; spos[wave] = v.pos; }
+    if (lane == 0) { sval[wave] = v.val; spos[wave] = v.pos; sloc[wave] = v.loc; }
     __syncthreads();
-    Best r = {0.0, -1};
+    Best r = {0.0, -1, 0};
     if (wave == 0) {
-        if (lane < nw) { r.val = sval[lane]; r.pos = spos[lane]; }
+        if (lane < nw) { r.val = sval[lane]; r.pos = spos[lane]; r.loc = sloc[lane]; }
         r = wave_best(r, mode);
     }
     return r;  // valid in wave 0
@@ -60,8 +62,9 @@ __device__ Best block_best(Best v, int mode) {
 // Best live position of the strided range first, first + step, ...: four positions per trip, their flags and values
 // loaded before any is compared (the single-workgroup selections are a chain of memory round trips otherwise).
 __device__ __forceinline__ Best scan_best(const double* __restrict__ mi, const uint8_t* __restrict__ alive, int64_t n_cand,
-                                          int64_t first, int64_t step, int64_t pos_offset, int mode) {
-    Best v = {0.0, -1};
+                                          int64_t first, int64_t step, int64_t pos_offset, const int64_t* __restrict__ gpos,
+                                          int mode) {
+    Best v = {0.0, -1, 0};
     for (int64_t p = first; p < n_cand; p += 4 * step) {
         bool live[4];
         double val[4];
@@ -75,7 +78,8 @@ __device__ __forceinline__ Best scan_best(const double* __restrict__ mi, const u
 #pragma unroll
         for (int u = 0; u < 4; u++) {
             if (!live[u]) continue;
-            Best c = {val[u], pos_offset + p + u * step};
+            const int64_t q = p + u * step;
+            Best c = {val[u], gpos ? gpos[q] : pos_offset + q, q};
             if (better(c, v, mode)) v = c;
         }
     }
@@ -83,38 +87,41 @@ __device__ __forceinline__ Best scan_best(const double* __restrict__ mi, const u
 }
 
 __global__ __launch_bounds__(256) void select_partial_kernel(const double* __restrict__ mi, const uint8_t* __restrict__ alive,
-                                                             int64_t n_cand, int64_t pos_offset, int mode,
+                                                             int64_t n_cand, int64_t pos_offset,
+                                                             const int64_t* __restrict__ gpos, int mode,
                                                              double* __restrict__ work) {
     Best v = scan_best(mi, alive, n_cand, (int64_t)blockIdx.x * blockDim.x + threadIdx.x, (int64_t)gridDim.x * blockDim.x,
-                       pos_offset, mode);
+                       pos_offset, gpos, mode);
     v = block_best(v, mode);
     if (threadIdx.x == 0) {
-        work[2 * blockIdx.x] = v.val;
-        work[2 * blockIdx.x + 1] = (double)v.pos;
+        work[3 * blockIdx.x] = v.val;
+        work[3 * blockIdx.x + 1] = (double)v.pos;
+        work[3 * blockIdx.x + 2] = (double)v.loc;
     }
 }
 
 struct RecordArgs {
-    const int32_t* cand; int64_t pos_offset, row_offset; int rank, mode, nparts;
+    const int32_t* cand; int64_t pos_offset; const int64_t* gpos; int64_t row_offset; int rank, mode, nparts;
     const double *mu, *s2, *X, *xnorm; int ldx; const double* V; int64_t ldv; int m, ldw;
     const double* C; int64_t ldc; int nprev, kmax;
-    const double* work; double* record;
+    const double* work; double* record; const int* status;
 };
 
 // Packs the record of the winner `v` (valid in thread 0 of the block).
 __device__ void record_body(const RecordArgs& a, Best v) {
-    __shared__ int64_t s_pos;
+    __shared__ int64_t s_pos, s_loc;
     __shared__ double s_val;
-    if (threadIdx.x == 0) { s_pos = v.pos; s_val = v.val; }
+    if (threadIdx.x == 0) { s_pos = v.pos; s_val = v.val; s_loc = v.loc; }
     __syncthreads();
     const int64_t gpos = s_pos;
     double* rec = a.record;
     const int rec_len = ITAL_REC_HEADER + a.ldx + a.ldw + a.kmax;
+    const double status = a.status ? (double)*a.status : 0.0;   // the rank's status word travels with its record
     if (gpos < 0) {
-        for (int i = threadIdx.x; i < rec_len; i += blockDim.x) rec[i] = (i == 1) ? -1.0 : 0.0;
+        for (int i = threadIdx.x; i < rec_len; i += blockDim.x) rec[i] = (i == 1) ? -1.0 : (i == 8 ? status : 0.0);
         return;
     }
-    const int64_t lp = gpos - a.pos_offset;
+    const int64_t lp = s_loc;
     const int row = a.cand[lp];
     if (threadIdx.x == 0) {
         rec[0] = s_val;
@@ -125,6 +132,8 @@ __device__ void record_body(const RecordArgs& a, Best v) {
         rec[5] = a.xnorm[row];
         rec[6] = (double)a.rank;
         rec[7] = (double)lp;
+        rec[8] = status;
+        rec[9] = 0.0;
     }
     for (int k = threadIdx.x; k < a.ldx; k += blockDim.x) rec[ITAL_REC_HEADER + k] = a.X[(int64_t)row * a.ldx + k];
     for (int r = threadIdx.x; r < a.ldw; r += blockDim.x)
@@ -134,9 +143,9 @@ __device__ void record_body(const RecordArgs& a, Best v) {
 }
 
 __global__ __launch_bounds__(256) void select_record_kernel(RecordArgs a) {
-    Best v = {0.0, -1};
+    Best v = {0.0, -1, 0};
     for (int i = threadIdx.x; i < a.nparts; i += blockDim.x) {
-        Best c = {a.work[2 * i], (int64_t)a.work[2 * i + 1]};
+        Best c = {a.work[3 * i], (int64_t)a.work[3 * i + 1], (int64_t)a.work[3 * i + 2]};
         if (better(c, v, a.mode)) v = c;
     }
     v = block_best(v, a.mode);
@@ -147,14 +156,17 @@ __device__ void resolve_body(const double* __restrict__ records, int world, int 
                              ital_batch b, uint8_t* __restrict__ alive, int64_t* __restrict__ ret) {
     __shared__ int s_win;
     if (threadIdx.x == 0) {
-        Best v = {0.0, -1};
+        Best v = {0.0, -1, 0};
         int win = -1;
+        long long status = 0;
         for (int w = 0; w < world; w++) {
             const double* r = records + (int64_t)w * rec_len;
-            Best c = {r[0], (int64_t)r[1]};
+            Best c = {r[0], (int64_t)r[1], 0};
             if (better(c, v, mode)) { v = c; win = w; }
+            status |= (long long)r[8];
         }
         s_win = win;
+        ret[b.kmax] |= status;   // every rank sees the OR of all ranks' status words: fall-backs are decided alike
     }
     __syncthreads();
     const int win = s_win;
@@ -190,7 +202,7 @@ __device__ void resolve_body(const double* __restrict__ records, int world, int 
 // launch more than it saves).
 __global__ __launch_bounds__(1024) void select_local_small_kernel(const double* __restrict__ mi, const uint8_t* __restrict__ alive,
                                                                   int64_t n_cand, RecordArgs a) {
-    Best v = scan_best(mi, alive, n_cand, threadIdx.x, blockDim.x, a.pos_offset, a.mode);
+    Best v = scan_best(mi, alive, n_cand, threadIdx.x, blockDim.x, a.pos_offset, a.gpos, a.mode);
     v = block_best(v, a.mode);
     record_body(a, v);
 }
@@ -205,7 +217,7 @@ __global__ __launch_bounds__(256) void select_resolve_kernel(const double* __res
 // the greedy steps of small problems are launch-latency bound).
 __global__ __launch_bounds__(1024) void select_fused_kernel(const double* __restrict__ mi, int64_t n_cand, RecordArgs a,
                                                             int slot, ital_batch b, uint8_t* alive, int64_t* __restrict__ ret) {
-    Best v = scan_best(mi, alive, n_cand, threadIdx.x, blockDim.x, a.pos_offset, a.mode);
+    Best v = scan_best(mi, alive, n_cand, threadIdx.x, blockDim.x, a.pos_offset, a.gpos, a.mode);
     v = block_best(v, a.mode);
     record_body(a, v);
     __threadfence_block();
@@ -219,41 +231,42 @@ __global__ __launch_bounds__(1024) void select_fused_kernel(const double* __rest
 using namespace ital;
 
 extern "C" int ital_select_local(const double* mi, const int32_t* cand, const uint8_t* alive, int64_t n_cand,
-                                 int64_t pos_offset, int64_t row_offset, int rank, int mode, const double* mu,
-                                 const double* s2, const double* X, const double* xnorm, int ldx, const double* V,
-                                 int64_t ldv, int m, int ldw, const double* C, int64_t ldc, int nprev, int kmax,
-                                 double* work, double* record, hipStream_t stream) {
+                                 int64_t pos_offset, const int64_t* gpos, int64_t row_offset, int rank, int mode,
+                                 const double* mu, const double* s2, const double* X, const double* xnorm, int ldx,
+                                 const double* V, int64_t ldv, int m, int ldw, const double* C, int64_t ldc, int nprev,
+                                 int kmax, const int* status, double* work, double* record, hipStream_t stream) {
     if (mode != 0 && mode != 1) return ital_fail(-22, "ital_select_local: mode must be 0 (argmax) or 1 (argmin)");
     if (m > ldw) return ital_fail(-22, "ital_select_local: m exceeds ldw");
     if (n_cand <= (1 << 18)) {
-        RecordArgs a1 = {cand, pos_offset, row_offset, rank, mode, 0, mu, s2, X, xnorm, ldx, V, ldv, m, ldw,
-                         C, ldc, nprev, kmax, nullptr, record};
+        RecordArgs a1 = {cand, pos_offset, gpos, row_offset, rank, mode, 0, mu, s2, X, xnorm, ldx, V, ldv, m, ldw,
+                         C, ldc, nprev, kmax, nullptr, record, status};
         hipLaunchKernelGGL(select_local_small_kernel, dim3(1), dim3(1024), 0, stream, mi, alive, n_cand, a1);
         return ital_check_launch("ital_select_local(small)");
     }
     int nparts = (int)((n_cand + 255) / 256);
     if (nparts > 1024) nparts = 1024;
     if (nparts < 1) nparts = 1;
-    hipLaunchKernelGGL(select_partial_kernel, dim3(nparts), dim3(256), 0, stream, mi, alive, n_cand, pos_offset, mode, work);
+    hipLaunchKernelGGL(select_partial_kernel, dim3(nparts), dim3(256), 0, stream, mi, alive, n_cand, pos_offset, gpos, mode,
+                       work);
     int rc = ital_check_launch("ital_select_local(partial)");
     if (rc) return rc;
-    RecordArgs a = {cand, pos_offset, row_offset, rank, mode, nparts, mu, s2, X, xnorm, ldx, V, ldv, m, ldw,
-                    C, ldc, nprev, kmax, work, record};
+    RecordArgs a = {cand, pos_offset, gpos, row_offset, rank, mode, nparts, mu, s2, X, xnorm, ldx, V, ldv, m, ldw,
+                    C, ldc, nprev, kmax, work, record, status};
     hipLaunchKernelGGL(select_record_kernel, dim3(1), dim3(256), 0, stream, a);
     return ital_check_launch("ital_select_local(record)");
 }
 
 extern "C" int ital_select_fused(const double* mi, const int32_t* cand, uint8_t* alive, int64_t n_cand, int64_t pos_offset,
-                                 int64_t row_offset, int rank, int mode, const double* mu, const double* s2, const double* X,
-                                 const double* xnorm, int ldx, const double* V, int64_t ldv, int m, int ldw, const double* C,
-                                 int64_t ldc, int nprev, int slot, ital_batch batch, double* record, int64_t* ret,
-                                 hipStream_t stream) {
+                                 const int64_t* gpos, int64_t row_offset, int rank, int mode, const double* mu,
+                                 const double* s2, const double* X, const double* xnorm, int ldx, const double* V, int64_t ldv,
+                                 int m, int ldw, const double* C, int64_t ldc, int nprev, int slot, ital_batch batch,
+                                 const int* status, double* record, int64_t* ret, hipStream_t stream) {
     if (mode != 0 && mode != 1) return ital_fail(-22, "ital_select_fused: mode must be 0 (argmax) or 1 (argmin)");
     if (m > ldw) return ital_fail(-22, "ital_select_fused: m exceeds ldw");
     if (slot < 0 || slot >= batch.kmax) return ital_fail(-22, "ital_select_fused: slot outside the batch capacity");
     if (ldx != batch.ldx || ldw != batch.ldw) return ital_fail(-22, "ital_select_fused: batch layout mismatch");
-    RecordArgs a = {cand, pos_offset, row_offset, rank, mode, 0, mu, s2, X, xnorm, ldx, V, ldv, m, ldw,
-                    C, ldc, nprev, batch.kmax, nullptr, record};
+    RecordArgs a = {cand, pos_offset, gpos, row_offset, rank, mode, 0, mu, s2, X, xnorm, ldx, V, ldv, m, ldw,
+                    C, ldc, nprev, batch.kmax, nullptr, record, status};
     hipLaunchKernelGGL(select_fused_kernel, dim3(1), dim3(1024), 0, stream, mi, n_cand, a, slot, batch, alive, ret);
     return ital_check_launch("ital_select_fused");
 }

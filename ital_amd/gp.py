@@ -251,9 +251,11 @@ class GaussianProcess(object):
                                          float(self.var), float(self.length_scale), _ptr(self.mu), _ptr(self.s2), st))
             self.m += c
 
-    def check_status(self):
-        """Raises if a kernel flagged a numerical failure (synchronises)."""
-        s = int(self.status.item())
+    def check_status(self, status=None):
+        """Raises if a kernel flagged a numerical failure.  `status`: the word as already downloaded (e.g. the OR over all
+        ranks that the selection step returns); otherwise this rank's word is read (synchronises).  Bit 1 comes from the
+        replicated Cholesky append and is therefore the same on every rank."""
+        s = int(self.status.item()) if status is None else int(status)
         if s & 1:
             raise np.linalg.LinAlgError("kernel matrix of the labelled samples is not positive definite "
                                         "(the reference would warn at gp.py:31)")

@@ -60,7 +60,8 @@ class ITAL(ActiveRetrievalBase):
         self.keep_scores = False
         self.force_generic = False  # route the perfect-user case through the general scorer too (cross-check in tests)
         self._ce_subset = None
-        self.qmc_split = 8       # waves a candidate's orthant calls may be spread over (t >= 3, label_estimation 'mean')
+        self.qmc_work_bytes = int(os.environ.get("ITAL_QMC_WORK_BYTES", 1 << 30))   # cap of the lattice scorer's workspace
+        self._last_batch = None  # (batch buffers, picks) of the last fast-path round: update() reuses the winners' rows
         self.event_pool = []     # pre-created timing events (bench.py)
         self.profile = None      # list to receive (stage, t, size, start_event, end_event) per launch (bench.py)
         self._fetch_bufs = None
@@ -200,6 +201,28 @@ class ITAL(ActiveRetrievalBase):
             raise ValueError("attempt to get argmax of an empty sequence")
         return self._select(k, candidates)
 
+    def _shard(self, candidates):
+        """Candidate shard of this rank as device arrays: local rows, alive flags, explicit list positions (or None when
+        the local positions are one contiguous run of the list), and the list position of the first one."""
+        gp = self.gp
+        dev = gp.device
+        cand = np.asarray(candidates, dtype=np.int64)
+        loc_rows, pos_offset, gpos = sharding.shard_candidates(cand, gp.row0, gp.row1)
+        n_loc = len(loc_rows)
+        cand_d = torch.from_numpy((loc_rows - gp.row0).astype(np.int32)).to(dev) if n_loc else \
+            torch.zeros(1, dtype=torch.int32, device=dev)
+        gpos_d = torch.from_numpy(gpos).to(dev) if gpos is not None else None
+        alive = torch.ones(max(n_loc, 1), dtype=torch.uint8, device=dev)
+        return cand, n_loc, pos_offset, cand_d, gpos_d, alive
+
+    def _qmc_workspace(self, b, t, n_loc):
+        """Workspace of the lattice scorer (prepared calls of a slab of candidates), grown on demand up to `qmc_work_bytes`."""
+        want = min(int(_lib.lib().ital_score_workspace(t, max(n_loc, 1))), max(self.qmc_work_bytes // 8, 1 << 16))
+        w = b.get("qmc_work")
+        if w is None or w.numel() < want:
+            b["qmc_work"] = w = torch.empty(want, dtype=torch.float64, device=self.gp.device)
+        return w
+
     def _select(self, k, candidates):
         """Greedy construction of a batch of k out of `candidates` (k <= len(candidates))."""
         gp = self.gp
@@ -211,24 +234,20 @@ class ITAL(ActiveRetrievalBase):
             b = self._buffers(k)
             st = _stream()
             # ---- candidate shard of this rank (list positions keep their global numbering)
-            cand = np.asarray(candidates, dtype=np.int64)
-            loc_rows, pos_offset = sharding.shard_candidates(cand, gp.row0, gp.row1)
-            n_loc = len(loc_rows)
-            cand_d = torch.from_numpy((loc_rows - gp.row0).astype(np.int32)).to(dev) if n_loc else \
-                torch.zeros(1, dtype=torch.int32, device=dev)
-            alive = torch.ones(max(n_loc, 1), dtype=torch.uint8, device=dev)
+            cand, n_loc, pos_offset, cand_d, gpos_d, alive = self._shard(candidates)
             mi = torch.empty(max(n_loc, 1), dtype=torch.float64, device=dev)   # every live position is written by the scorer
             self.last_scores = []
             stream = mvn_stream.GLOBAL
             saved_stream = (stream.state, stream.draws)
             n_alive = len(candidates)
+            b["ret"][b["kmax"]:].zero_()      # the resolve steps OR every rank's status word into this slot
             for t in range(1, k + 1):
                 desc = ItalScoreDesc()
                 desc.t = t
                 desc.n_cand = n_loc
                 desc.cand, desc.alive, desc.mu, desc.s2 = _ptr(cand_d), _ptr(alive), _ptr(gp.mu), _ptr(gp.s2)
                 desc.C, desc.ldc = _ptr(b["C"]), gp.ldv
-                desc.row_offset, desc.pos_offset = gp.row0, pos_offset
+                desc.row_offset, desc.pos_offset, desc.gpos = gp.row0, pos_offset, _ptr(gpos_d)
                 desc.batch = b["batch"]
                 desc.noise, desc.eps = float(self.noise), float(self.eps)
                 desc.label_mode = _LABEL_MODES[self.label_estimation]
@@ -237,31 +256,28 @@ class ITAL(ActiveRetrievalBase):
                 if t >= 3:
                     if t not in b["jump"]:
                         b["jump"][t] = torch.from_numpy(mvn_stream.jump_table(t, ITAL_JUMP_BITS)).to(dev)
-                        b["jumplane"][t] = torch.from_numpy(mvn_stream.jump_lane_table(t, 64)).to(dev)
+                        b["jumppat"][t] = torch.from_numpy(mvn_stream.jump_pattern_table(t)).to(dev)
                         b["vk"][t] = torch.from_numpy(mvn_stream.korobov_vk(t)).to(dev)
-                    desc.jump, desc.jumplane, desc.vk = _ptr(b["jump"][t]), _ptr(b["jumplane"][t]), _ptr(b["vk"][t])
+                    desc.jump, desc.jumppat, desc.vk = _ptr(b["jump"][t]), _ptr(b["jumppat"][t]), _ptr(b["vk"][t])
                     for j in range(6):
                         desc.seed[j] = stream.state[j]
-                    nsp = max(int(self.qmc_split), 1)
-                    if b.get("partial") is None or b["partial"].numel() < max(n_loc, 1) * nsp:
-                        b["partial"] = torch.empty(max(n_loc, 1) * nsp, dtype=torch.float64, device=dev)
-                        b["seeds"] = torch.empty(max(n_loc, 1) * nsp * 6, dtype=torch.int32, device=dev)
-                    desc.split, desc.partial, desc.seeds = nsp, _ptr(b["partial"]), _ptr(b["seeds"])
+                    work = self._qmc_workspace(b, t, n_loc)
+                    desc.work, desc.work_doubles = _ptr(work), work.numel()
                 ev0 = self._mark()
                 check(lib.ital_score_step(ctypes.byref(desc), st))
                 self._mark("score", t, n_alive, ev0)
                 if self.keep_scores:
                     self.last_scores.append(mi.clone())
                 if not gp.collective and n_loc <= _FUSED_SELECT_MAX:
-                    check(lib.ital_select_fused(_ptr(mi), _ptr(cand_d), _ptr(alive), n_loc, pos_offset, gp.row0, gp.rank, 0,
-                                                _ptr(gp.mu), _ptr(gp.s2), _ptr(gp.Xd), _ptr(gp.xnorm), gp.ldx, _ptr(gp.V),
-                                                gp.ldv, gp.m, gp.cap, _ptr(b["C"]), gp.ldv, t - 1, t - 1, b["batch"],
-                                                _ptr(b["rec"]), _ptr(b["ret"]), st))
+                    check(lib.ital_select_fused(_ptr(mi), _ptr(cand_d), _ptr(alive), n_loc, pos_offset, _ptr(gpos_d), gp.row0,
+                                                gp.rank, 0, _ptr(gp.mu), _ptr(gp.s2), _ptr(gp.Xd), _ptr(gp.xnorm), gp.ldx,
+                                                _ptr(gp.V), gp.ldv, gp.m, gp.cap, _ptr(b["C"]), gp.ldv, t - 1, t - 1, b["batch"],
+                                                _ptr(gp.status), _ptr(b["rec"]), _ptr(b["ret"]), st))
                 else:
-                    check(lib.ital_select_local(_ptr(mi), _ptr(cand_d), _ptr(alive), n_loc, pos_offset, gp.row0, gp.rank, 0,
-                                                _ptr(gp.mu), _ptr(gp.s2), _ptr(gp.Xd), _ptr(gp.xnorm), gp.ldx, _ptr(gp.V),
-                                                gp.ldv, gp.m, gp.cap, _ptr(b["C"]), gp.ldv, t - 1, b["kmax"],
-                                                _ptr(b["work"]), _ptr(b["rec"]), st))
+                    check(lib.ital_select_local(_ptr(mi), _ptr(cand_d), _ptr(alive), n_loc, pos_offset, _ptr(gpos_d), gp.row0,
+                                                gp.rank, 0, _ptr(gp.mu), _ptr(gp.s2), _ptr(gp.Xd), _ptr(gp.xnorm), gp.ldx,
+                                                _ptr(gp.V), gp.ldv, gp.m, gp.cap, _ptr(b["C"]), gp.ldv, t - 1, b["kmax"],
+                                                _ptr(gp.status), _ptr(b["work"]), _ptr(b["rec"]), st))
                     recs = sharding.gather_records(b["rec"], b["rec_all"], gp.group) if gp.collective else b["rec"]
                     check(lib.ital_select_resolve(_ptr(recs), gp.world, b["rec_len"], gp.rank, 0, t - 1, b["batch"],
                                                   _ptr(alive), _ptr(b["ret"]), st))
@@ -276,24 +292,30 @@ class ITAL(ActiveRetrievalBase):
                 # the reference's serial loop has now consumed this many uniforms of mvndst's stream
                 stream.advance(n_alive * (2 << t) * mvn_stream.draws_per_call(t))
                 n_alive -= 1
-            b["ret"][b["kmax"]:].copy_(gp.status)
             host = b["ret"].cpu().tolist()     # the only synchronisation of the round: the picks and the status word
-            ret, status = host[:k], host[b["kmax"]]
-            if status & 2:
-                # linearly dependent variables inside a batch (duplicate samples): the fast scorer does not carry
-                # MVNDFN's limit-intersection logic; redo the round with the general scorer from the same stream position
-                gp.status.zero_()
+            ret, status = host[:k], host[b["kmax"]]   # status: OR over the greedy steps and over all ranks (same everywhere)
+            self._last_batch = (b, list(ret))
+            if status & 6:
+                # linearly dependent variables inside a batch (duplicate samples), or a simulated update that does not pin the
+                # labels (large noise): the fast scorer carries neither MVNDFN's limit-intersection logic nor the updated
+                # integrals; redo the round with the general scorer from the same stream position -- on every rank alike
+                gp.status.bitwise_and_(~6)
                 stream.state, stream.draws = saved_stream
                 return self._fetch_generic(k, candidates)
         if status:
-            gp.check_status()
+            gp.check_status(status)
         return [int(i) for i in ret]
 
     # ------------------------------------------------------------------ general scorer (noisy users, estimation subset)
     def _fetch_generic(self, k, candidates):
         """Greedy batch construction through ital_score_generic: any user model (reference ital.py:300-342), with or
-        without a change-estimation subset (ital.py:227-275, 541-582).  One host synchronisation per greedy step (the
-        winner's record is read back to extend the base set); the perfect-user path above has none."""
+        without a change-estimation subset (ital.py:227-275, 541-582).
+
+        Without a subset the base set of the scorer IS the batch so far: it lives in the replicated device batch state that
+        ital_select_resolve / ital_select_fused maintain, and a round is enqueued without any host round trip (one download
+        of the picks at the end) unless an option needs the host between the steps (Monte-Carlo sampling on numpy's
+        generator, the counting pass of clip_cov).  With a subset the base set also holds the subset members and grows only
+        when a pick lies outside it: that bookkeeping stays on the host (one synchronisation per greedy step)."""
         lib = _lib.lib()
         gp = self.gp
         dev = gp.device
@@ -303,22 +325,25 @@ class ITAL(ActiveRetrievalBase):
         kmax_e = len(E) + k
         GN = ITAL_GENERIC_MAX_DIM
         stream = mvn_stream.GLOBAL
+        h = ITAL_REC_HEADER
         with torch.cuda.device(dev):
             st = _stream()
-            b = make_batch_buffers(dev, max(kmax_e, 4), gp.ldx, gp.cap, gp.ldv, gp.world)
-            cand = np.asarray(candidates, dtype=np.int64)
+            b = self._buffers(max(kmax_e, 4))
+            kmax = b["kmax"]
+            cand, n_loc, pos_offset, cand_d, gpos_d, alive = self._shard(candidates)
             pos_of = {int(c): i for i, c in enumerate(cand.tolist())}
-            loc_rows, pos_offset = sharding.shard_candidates(cand, gp.row0, gp.row1)
-            n_loc = len(loc_rows)
-            cand_d = torch.from_numpy((loc_rows - gp.row0).astype(np.int32)).to(dev) if n_loc else \
-                torch.zeros(1, dtype=torch.int32, device=dev)
-            alive = torch.ones(max(n_loc, 1), dtype=torch.uint8, device=dev)
             mi = torch.zeros(max(n_loc, 1), dtype=torch.float64, device=dev)
-            jump1 = torch.from_numpy(mvn_stream.jump1_table(ITAL_JUMP_BITS)).to(dev)
-            vk = torch.from_numpy(mvn_stream.vk_table(GN)).to(dev)
+            if "jump1" not in b:
+                b["jump1"] = torch.from_numpy(mvn_stream.jump1_table(ITAL_JUMP_BITS)).to(dev)
+                b["vk_all"] = torch.from_numpy(mvn_stream.vk_table(GN)).to(dev)
+                b["iota"] = torch.arange(kmax, dtype=torch.int32, device=dev)
+                b["zero64"] = torch.zeros(1, dtype=torch.int64, device=dev)
+            jump1, vk = b["jump1"], b["vk_all"]
             C = b["C"]
             e_mu = np.zeros(kmax_e)
             e_sig = np.zeros((kmax_e, kmax_e))
+            keep = []                     # device temporaries of the enqueued work (released after the round's synchronisation)
+            b["ret"][kmax:].zero_()
             if E:
                 # covariance columns of the subset members with every row, and among themselves
                 rows = gp._gather_rows(E)
@@ -333,7 +358,8 @@ class ITAL(ActiveRetrievalBase):
                                                   _ptr(norms[c0:c0 + c]), c, _ptr(Wt), gp.cap, _ptr(gp.V), gp.ldv, gp.m,
                                                   float(self.var), float(self.length_scale), _ptr(C[c0:c0 + c]), gp.ldv,
                                                   st))
-                    torch.cuda.current_stream().synchronize()   # Wt is a temporary
+                    keep.append(Wt)
+                keep += [rows, norms, vcols]
                 e_sig[: len(E), : len(E)] = gp.gather_columns(C[: len(E)], E).cpu().numpy()
                 e_mu[: len(E)] = self.rel_mean[np.asarray(E)]
             picks, pick_pos = [], []
@@ -341,9 +367,11 @@ class ITAL(ActiveRetrievalBase):
             n_alive = len(candidates)
             z_next = None
             for t in range(1, k + 1):
-                nE = len(E)
+                nE = len(E) if subset_mode else t - 1
                 nr = t
                 rel_mc, npat, fb_mc, nfb = self._mc_plan(nr, fb_mode)
+                clip_count = self._clip_active() and nE + 1 > 5
+                host_step = subset_mode or rel_mc or fb_mc or clip_count   # the host needs this step's winner before the next
                 dpc = mvn_stream.draws_per_call
                 if subset_mode:
                     draws_out = npat * (dpc(nr) + (1 + nfb) * dpc(nE + 1))
@@ -355,26 +383,43 @@ class ITAL(ActiveRetrievalBase):
                     in_pos = []
                 mc = None
                 if rel_mc or fb_mc:
-                    mc = self._mc_samples(nr, npat, rel_mc, fb_mc, nfb, fb_mode, cand, picks, pos_of, E, pick_pos, e_mu,
-                                          e_sig, C, subset_mode, z_next, (pos_offset, pos_offset + n_loc))
+                    if not subset_mode and t > 1:
+                        # batch state kept by the device: the members' means / covariances for the pattern sampler
+                        picks = [int(i) for i in b["ret"][: t - 1].cpu().tolist()]
+                        pick_pos = list(range(t - 1))
+                        e_mu[: t - 1] = b["bmu"][: t - 1].cpu().numpy()
+                        e_sig[: t - 1, : t - 1] = b["sig"].view(kmax, kmax)[: t - 1, : t - 1].cpu().numpy()
+                    mc = self._mc_samples(nr, npat, rel_mc, fb_mc, nfb, fb_mode, cand, picks, pos_of,
+                                          E if subset_mode else picks, pick_pos, e_mu, e_sig, C, subset_mode, z_next,
+                                          (pos_offset, pos_offset + n_loc) if gpos_d is None else None)
                 z_next = None
-                dead_pos = [pos_of[q] for q in picks]
                 desc = ItalGscoreDesc()
                 desc.n_cand = n_loc
                 desc.cand, desc.alive, desc.mu, desc.s2 = _ptr(cand_d), _ptr(alive), _ptr(gp.mu), _ptr(gp.s2)
                 desc.C, desc.ldc = _ptr(C), gp.ldv
-                desc.row_offset, desc.pos_offset = gp.row0, pos_offset
-                t_eidx = torch.as_tensor(E if E else [0], dtype=torch.int64, device=dev)
-                t_esort = torch.as_tensor(np.argsort(np.asarray(E, dtype=np.int64), kind="stable") if E else [0],
-                                          dtype=torch.int32, device=dev)
-                t_emu = torch.from_numpy(np.ascontiguousarray(e_mu)).to(dev)
-                t_esig = torch.from_numpy(np.ascontiguousarray(e_sig)).to(dev)
-                t_ppos = torch.as_tensor(pick_pos if pick_pos else [0], dtype=torch.int32, device=dev)
-                t_in = torch.as_tensor(in_pos if in_pos else [0], dtype=torch.int64, device=dev)
-                t_dead = torch.as_tensor(dead_pos if dead_pos else [0], dtype=torch.int64, device=dev)
-                desc.nE, desc.E_idx, desc.E_sort, desc.E_mu, desc.E_sig, desc.ldE = nE, _ptr(t_eidx), _ptr(t_esort), \
-                    _ptr(t_emu), _ptr(t_esig), kmax_e
-                desc.n_picks, desc.pick_pos = len(picks), _ptr(t_ppos)
+                desc.row_offset, desc.pos_offset, desc.gpos = gp.row0, pos_offset, _ptr(gpos_d)
+                if subset_mode:
+                    dead_pos = [pos_of[q] for q in picks]
+                    t_eidx = torch.as_tensor(E if E else [0], dtype=torch.int64, device=dev)
+                    t_esort = torch.as_tensor(np.argsort(np.asarray(E, dtype=np.int64), kind="stable") if E else [0],
+                                              dtype=torch.int32, device=dev)
+                    t_emu = torch.from_numpy(np.ascontiguousarray(e_mu)).to(dev)
+                    t_esig = torch.from_numpy(np.ascontiguousarray(e_sig)).to(dev)
+                    t_ppos = torch.as_tensor(pick_pos if pick_pos else [0], dtype=torch.int32, device=dev)
+                    t_in = torch.as_tensor(in_pos if in_pos else [0], dtype=torch.int64, device=dev)
+                    t_dead = torch.as_tensor(dead_pos if dead_pos else [0], dtype=torch.int64, device=dev)
+                    keep += [t_eidx, t_esort, t_emu, t_esig, t_ppos, t_in, t_dead]
+                    desc.nE, desc.E_idx, desc.E_sort, desc.E_mu, desc.E_sig, desc.ldE = nE, _ptr(t_eidx), _ptr(t_esort), \
+                        _ptr(t_emu), _ptr(t_esig), kmax_e
+                    desc.n_picks, desc.pick_pos = len(picks), _ptr(t_ppos)
+                    desc.n_in, desc.in_pos, desc.n_dead, desc.dead_pos = len(in_pos), _ptr(t_in), len(dead_pos), _ptr(t_dead)
+                else:
+                    # the base set is the batch so far: members, their order by data index, means, covariances and list
+                    # positions are the device batch state itself
+                    desc.nE, desc.E_idx, desc.E_sort, desc.E_mu, desc.E_sig, desc.ldE = nE, _ptr(b["bidx"]), \
+                        _ptr(b["bsort"]), _ptr(b["bmu"]), _ptr(b["sig"]), kmax
+                    desc.n_picks, desc.pick_pos = nE, _ptr(b["iota"])
+                    desc.n_in, desc.in_pos, desc.n_dead, desc.dead_pos = 0, _ptr(b["zero64"]), nE, _ptr(b["bgpos"])
                 desc.subset_mode, desc.fb_mode = int(subset_mode), fb_mode
                 desc.label_prob, desc.mistake_prob = float(self.label_prob), float(self.mistake_prob)
                 desc.label_mode = _LABEL_MODES[self.label_estimation]
@@ -384,71 +429,108 @@ class ITAL(ActiveRetrievalBase):
                     desc.seed[j] = stream.state[j]
                 desc.jump1, desc.vk = _ptr(jump1), _ptr(vk)
                 desc.draws_out, desc.draws_in = draws_out, draws_in
-                desc.n_in, desc.in_pos, desc.n_dead, desc.dead_pos = len(in_pos), _ptr(t_in), len(dead_pos), _ptr(t_dead)
                 desc.mi, desc.status = _ptr(mi), _ptr(gp.status)
                 total_draws = None
                 if mc is not None:
                     rel_arr, fb_arr, draws_pp = mc          # per list position (dead positions hold zeros)
-                    lo, hi = pos_offset, pos_offset + max(n_loc, 1)
+                    if gpos_d is None:
+                        mine = slice(pos_offset, pos_offset + max(n_loc, 1))
+                    else:
+                        mine = gpos_d.cpu().numpy()
                     if rel_arr is not None:
-                        t_rel = torch.from_numpy(np.ascontiguousarray(rel_arr[lo:hi])).to(dev)
+                        t_rel = torch.from_numpy(np.ascontiguousarray(rel_arr[mine])).to(dev)
                         desc.mc_rel, desc.rel_samples = npat, _ptr(t_rel)
+                        keep.append(t_rel)
                     if fb_arr is not None:
-                        t_fb = torch.from_numpy(np.ascontiguousarray(fb_arr[lo:hi])).to(dev)
+                        t_fb = torch.from_numpy(np.ascontiguousarray(fb_arr[mine])).to(dev)
                         desc.mc_fb, desc.fb_samples = nfb, _ptr(t_fb)
+                        keep.append(t_fb)
                     off = np.concatenate(([0], np.cumsum(draws_pp)[:-1])).astype(np.int64)
-                    t_off = torch.from_numpy(np.ascontiguousarray(off[lo:hi])).to(dev)
+                    t_off = torch.from_numpy(np.ascontiguousarray(off[mine])).to(dev)
+                    keep.append(t_off)
                     desc.draw_off = _ptr(t_off)
                     total_draws = int(draws_pp.sum())
-                if self._clip_active() and nE + 1 > 5:
+                if clip_count:
                     # with clip_cov the number of mvndst calls (one per group of correlated variables) and hence the
                     # stream consumption depends on the data: a counting pass of the same kernel reports it per candidate
                     counts = torch.zeros(max(n_loc, 1), dtype=torch.int64, device=dev)
                     desc.draw_count = _ptr(counts)
                     check(lib.ital_score_generic(ctypes.byref(desc), st))
                     desc.draw_count = None
-                    local_total = counts.sum().reshape(1)
                     if gp.collective:
-                        totals = sharding.all_gather_parts(local_total, [1] * gp.world, gp.group)
+                        # uniforms consumed before each of this rank's candidates: prefix over the whole list
+                        full = torch.zeros(len(cand), dtype=torch.int64, device=dev)
+                        if n_loc:
+                            if gpos_d is None:
+                                full[pos_offset:pos_offset + n_loc] = counts[:n_loc]
+                            else:
+                                full[gpos_d] = counts[:n_loc]
+                        sharding.all_reduce_sum(full, gp.group)
+                        excl = torch.cumsum(full, 0) - full
+                        t_off = (excl[pos_offset:pos_offset + max(n_loc, 1)] if gpos_d is None else excl[gpos_d]).contiguous()
+                        total_draws = int(full.sum().item())
                     else:
-                        totals = local_total
-                    totals_h = totals.cpu().tolist()
-                    lower = sum(totals_h[: gp.rank]) if gp.collective else 0
-                    t_off = torch.cumsum(counts, 0) - counts + lower
+                        t_off = torch.cumsum(counts, 0) - counts
+                        total_draws = int(counts.sum().item())
+                    keep += [counts, t_off]
                     desc.draw_off = _ptr(t_off)
-                    total_draws = int(sum(totals_h))
                 ev0 = self._mark()
                 check(lib.ital_score_generic(ctypes.byref(desc), st))
                 self._mark("score_generic", t, n_alive, ev0)
                 if self.keep_scores:
                     self.last_scores.append(mi.clone())
-                check(lib.ital_select_local(_ptr(mi), _ptr(cand_d), _ptr(alive), n_loc, pos_offset, gp.row0, gp.rank, 0,
-                                            _ptr(gp.mu), _ptr(gp.s2), _ptr(gp.Xd), _ptr(gp.xnorm), gp.ldx, _ptr(gp.V),
-                                            gp.ldv, gp.m, gp.cap, _ptr(C), gp.ldv, nE, b["kmax"], _ptr(b["work"]),
-                                            _ptr(b["rec"]), st))
-                recs = sharding.gather_records(b["rec"], b["rec_all"], gp.group) if gp.collective else b["rec"].unsqueeze(0)
+                n_in_alive = len(in_pos)
+                stream.advance(total_draws if total_draws is not None else
+                               (n_alive - n_in_alive) * draws_out + n_in_alive * draws_in)
+                n_alive -= 1
                 if t < k:
                     # the standard normals of the next step's pattern sampling depend on nothing but their count: drawn
                     # now, while the scorer runs, they are off the critical path (same order on numpy's global generator)
                     rel_nx, npat_nx, fb_nx, _ = self._mc_plan(nr + 1, fb_mode)
                     if rel_nx and not fb_nx:
-                        z_next = np.random.standard_normal((n_alive - 1, npat_nx, nr + 1))
+                        z_next = np.random.standard_normal((n_alive, npat_nx, nr + 1))
+                if not subset_mode:
+                    slot = t - 1
+                    if not gp.collective and n_loc <= _FUSED_SELECT_MAX:
+                        check(lib.ital_select_fused(_ptr(mi), _ptr(cand_d), _ptr(alive), n_loc, pos_offset, _ptr(gpos_d),
+                                                    gp.row0, gp.rank, 0, _ptr(gp.mu), _ptr(gp.s2), _ptr(gp.Xd),
+                                                    _ptr(gp.xnorm), gp.ldx, _ptr(gp.V), gp.ldv, gp.m, gp.cap, _ptr(C), gp.ldv,
+                                                    slot, slot, b["batch"], _ptr(gp.status), _ptr(b["rec"]), _ptr(b["ret"]),
+                                                    st))
+                    else:
+                        check(lib.ital_select_local(_ptr(mi), _ptr(cand_d), _ptr(alive), n_loc, pos_offset, _ptr(gpos_d),
+                                                    gp.row0, gp.rank, 0, _ptr(gp.mu), _ptr(gp.s2), _ptr(gp.Xd),
+                                                    _ptr(gp.xnorm), gp.ldx, _ptr(gp.V), gp.ldv, gp.m, gp.cap, _ptr(C), gp.ldv,
+                                                    slot, kmax, _ptr(gp.status), _ptr(b["work"]), _ptr(b["rec"]), st))
+                        recs = sharding.gather_records(b["rec"], b["rec_all"], gp.group) if gp.collective else b["rec"]
+                        check(lib.ital_select_resolve(_ptr(recs), gp.world, b["rec_len"], gp.rank, 0, slot, b["batch"],
+                                                      _ptr(alive), _ptr(b["ret"]), st))
+                    if t < k:
+                        ev0 = self._mark()
+                        check(lib.ital_cross_cov_cols(_ptr(gp.Xd), _ptr(gp.xnorm), gp.n, gp.ldx, _ptr(b["XB"][slot]),
+                                                      _ptr(b["XBn"][slot:]), 1, _ptr(b["VB"][slot]), gp.cap, _ptr(gp.V),
+                                                      gp.ldv, gp.m, float(self.var), float(self.length_scale),
+                                                      _ptr(C[slot]), gp.ldv, st))
+                        self._mark("cross_cov", t, gp.m, ev0)
+                    continue
+                # ---- subset mode: the winner is resolved on the host (it may or may not extend the base set)
+                check(lib.ital_select_local(_ptr(mi), _ptr(cand_d), _ptr(alive), n_loc, pos_offset, _ptr(gpos_d), gp.row0,
+                                            gp.rank, 0, _ptr(gp.mu), _ptr(gp.s2), _ptr(gp.Xd), _ptr(gp.xnorm), gp.ldx,
+                                            _ptr(gp.V), gp.ldv, gp.m, gp.cap, _ptr(C), gp.ldv, nE, kmax, _ptr(gp.status),
+                                            _ptr(b["work"]), _ptr(b["rec"]), st))
+                recs = sharding.gather_records(b["rec"], b["rec_all"], gp.group) if gp.collective else b["rec"].unsqueeze(0)
                 recs_h = recs.cpu().numpy()          # host synchronisation of this greedy step
+                keep.clear()
                 w = sharding.winner(recs_h, 0)
                 rec = recs_h[w]
                 pick = int(rec[2])
                 if int(rec[6]) == gp.rank:
                     alive[int(rec[7])] = 0
-                n_in_alive = len(in_pos)
-                stream.advance(total_draws if total_draws is not None else
-                               (n_alive - n_in_alive) * draws_out + n_in_alive * draws_in)
-                n_alive -= 1
                 picks.append(pick)
                 if pick in E:
                     pick_pos.append(E.index(pick))
                 else:
                     # new member of the base set: its covariance column, mean and covariances with the members so far
-                    h = ITAL_REC_HEADER
                     e_mu[nE] = rec[3]
                     e_sig[nE, nE] = rec[4]
                     e_sig[nE, :nE] = rec[h + gp.ldx + gp.cap: h + gp.ldx + gp.cap + nE]
@@ -461,10 +543,17 @@ class ITAL(ActiveRetrievalBase):
                         check(lib.ital_cross_cov_cols(_ptr(gp.Xd), _ptr(gp.xnorm), gp.n, gp.ldx, _ptr(xrow), _ptr(xn), 1,
                                                       _ptr(vcol), gp.cap, _ptr(gp.V), gp.ldv, gp.m, float(self.var),
                                                       float(self.length_scale), _ptr(C[nE]), gp.ldv, st))
-                        torch.cuda.current_stream().synchronize()   # xrow / vcol are temporaries
+                        keep += [xrow, vcol, xn]
                     pick_pos.append(nE)
                     E.append(pick)
-        gp.check_status()
+            if not subset_mode:
+                host = b["ret"].cpu().tolist()        # picks and the status word (OR over steps and ranks)
+                picks, status = host[:k], host[kmax]
+                self._last_batch = (b, [int(i) for i in picks])
+            else:
+                status = None                         # only the replicated Cholesky append reports here: same on all ranks
+            keep.clear()
+        gp.check_status(status)
         return [int(i) for i in picks]
 
     def _mc_samples(self, nr, npat, rel_mc, fb_mc, nfb, fb_mode, cand, picks, pos_of, E, pick_pos, e_mu, e_sig, C, subset_mode,

@@ -133,13 +133,15 @@ class MCMI_min(ActiveRetrievalBase):
                 if self.keep_scores:
                     self.last_scores.append(ce.clone())
                 if not gp.collective and n_i <= (1 << 18):
-                    check(lib.ital_select_fused(_ptr(ce), _ptr(pos_d), _ptr(alive), n_i, i0, 0, gp.rank, 1, _ptr(muc),
+                    check(lib.ital_select_fused(_ptr(ce), _ptr(pos_d), _ptr(alive), n_i, i0, None, 0, gp.rank, 1, _ptr(muc),
                                                 _ptr(s2c), _ptr(Xc), _ptr(xnc), gp.ldx, _ptr(Vc), ldc, gp.m, gp.cap,
-                                                _ptr(b["C"]), ldc, t - 1, t - 1, b["batch"], _ptr(b["rec"]), _ptr(b["ret"]), st))
+                                                _ptr(b["C"]), ldc, t - 1, t - 1, b["batch"], _ptr(gp.status), _ptr(b["rec"]),
+                                                _ptr(b["ret"]), st))
                 else:
-                    check(lib.ital_select_local(_ptr(ce), _ptr(pos_d), _ptr(alive), n_i, i0, 0, gp.rank, 1, _ptr(muc),
+                    check(lib.ital_select_local(_ptr(ce), _ptr(pos_d), _ptr(alive), n_i, i0, None, 0, gp.rank, 1, _ptr(muc),
                                                 _ptr(s2c), _ptr(Xc), _ptr(xnc), gp.ldx, _ptr(Vc), ldc, gp.m, gp.cap,
-                                                _ptr(b["C"]), ldc, t - 1, b["kmax"], _ptr(b["work"]), _ptr(b["rec"]), st))
+                                                _ptr(b["C"]), ldc, t - 1, b["kmax"], _ptr(gp.status), _ptr(b["work"]),
+                                                _ptr(b["rec"]), st))
                     recs = sharding.gather_records(b["rec"], b["rec_all"], gp.group) if gp.collective else b["rec"]
                     check(lib.ital_select_resolve(_ptr(recs), gp.world, b["rec_len"], gp.rank, 1, t - 1, b["batch"],
                                                   _ptr(alive), _ptr(b["ret"]), st))

@@ -118,18 +118,19 @@ def jump_table(n, bits=48):
     return _jump_cache[key]
 
 
-def jump_lane_table(n, lanes=64):
-    """int64 [lanes][18]: transition matrices of both components for 0..lanes-1 lattice shifts of a call of dimension n
-    (a shift draws 2(n-1)-1 uniforms, a call consists of 8 shifts)."""
-    key = ("lane", n, lanes)
+def jump_pattern_table(n):
+    """int64 [2^n][18]: transition matrices of both components for 2r calls of dimension n, r = 0..2^n-1 (the reference
+    evaluates, per sign pattern r, the prior probability -- call 2r of the candidate -- and the probability after the
+    simulated update, ital.py:191-206)."""
+    key = ("pattern", n)
     if key not in _jump_cache:
-        d = draws_per_call(n) // 8
+        d = 2 * draws_per_call(n)
         j1, j2 = _matpow(A1, d, M1), _matpow(A2, d, M2)
         c1 = c2 = ((1, 0, 0), (0, 1, 0), (0, 0, 1))
-        out = np.empty((lanes, 18), dtype=np.int64)
-        for l in range(lanes):
-            out[l, :9] = np.array(c1, dtype=np.int64).ravel()
-            out[l, 9:] = np.array(c2, dtype=np.int64).ravel()
+        out = np.empty((1 << n, 18), dtype=np.int64)
+        for r in range(1 << n):
+            out[r, :9] = np.array(c1, dtype=np.int64).ravel()
+            out[r, 9:] = np.array(c2, dtype=np.int64).ravel()
             c1, c2 = _matmul(j1, c1, M1), _matmul(j2, c2, M2)
         _jump_cache[key] = out
     return _jump_cache[key]

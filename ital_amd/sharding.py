@@ -14,15 +14,17 @@ def row_range(n_total, world, rank):
 def shard_candidates(candidates, row0, row1):
     """Positions of the global candidate list that fall into this rank's rows.
 
-    Returns (global data indices of the local positions, list position of the first one).  The local positions
-    must form one contiguous run of the list (true for the ascending `get_unseen()` order) so that
-    `global position = pos_offset + local position`, which is what the arg-max tie-break and the replay of the
-    mvndst stream are keyed on."""
+    Returns (global data indices of the local positions, list position of the first one, explicit list positions or
+    None).  With the ascending `get_unseen()` order the local positions are one contiguous run of the list and
+    `global position = pos_offset + local position`; after the `top_candidates` restriction (np.argpartition order,
+    reference ital/ital.py:111-117) they are not, and the third value carries the list position of every local one.
+    The arg-max tie-break and the replay of the mvndst stream are keyed on list positions either way."""
     cand = np.asarray(candidates, dtype=np.int64)
     mine = np.flatnonzero((cand >= row0) & (cand < row1))
-    if len(mine) and not np.array_equal(mine, np.arange(mine[0], mine[0] + len(mine))):
-        raise NotImplementedError("candidate order is not contiguous per rank (top_candidates across several ranks)")
-    return cand[mine], (int(mine[0]) if len(mine) else 0)
+    first = int(mine[0]) if len(mine) else 0
+    if len(mine) and not np.array_equal(mine, np.arange(first, first + len(mine))):
+        return cand[mine], first, mine.astype(np.int64)
+    return cand[mine], first, None
 
 
 def _host_staged(t, group):

@@ -12,7 +12,7 @@ import torch.multiprocessing as mp  # noqa: E402
 
 from ital_amd import sharding  # noqa: E402
 
-REC = 8 + 16 + 16 + 4
+REC = 10 + 16 + 16 + 4
 
 
 def _free_port():
@@ -23,20 +23,21 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, n_total, seen, scores, mode, ret):
+def _worker(rank, world, port, n_total, seen, scores, mode, ret, order=None):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
-        cand = [i for i in range(n_total) if i not in seen]
+        cand = [i for i in range(n_total) if i not in seen] if order is None else list(order)
         row0, row1 = sharding.row_range(n_total, world, rank)
-        loc, pos_offset = sharding.shard_candidates(cand, row0, row1)
+        loc, pos_offset, gpos = sharding.shard_candidates(cand, row0, row1)
         rec = torch.zeros(REC, dtype=torch.float64)
         if len(loc):
             vals = scores[loc]
-            # local arg-extreme with the reference's rule (first extreme, NaN wins)
+            # local arg-extreme with the reference's rule (first extreme, NaN wins); local positions keep list order
             lp = int(np.argmax(vals) if mode == 0 else np.argmin(vals))
-            rec[0], rec[1], rec[2], rec[6], rec[7] = float(vals[lp]), pos_offset + lp, int(loc[lp]), rank, lp
+            gp = pos_offset + lp if gpos is None else int(gpos[lp])
+            rec[0], rec[1], rec[2], rec[6], rec[7] = float(vals[lp]), gp, int(loc[lp]), rank, lp
         else:
             rec[1] = -1
         out = torch.zeros((world, REC), dtype=torch.float64)
@@ -85,6 +86,28 @@ def test_row_range_tiles():
             assert max(sizes) - min(sizes) <= 1
 
 
-def test_top_candidates_order_is_rejected_across_ranks():
-    with pytest.raises(NotImplementedError):
-        sharding.shard_candidates([5, 30, 6, 31], 0, 20)
+def test_top_candidates_order_carries_explicit_list_positions():
+    loc, first, gpos = sharding.shard_candidates([5, 30, 6, 31], 0, 20)
+    assert loc.tolist() == [5, 6] and first == 0 and gpos.tolist() == [0, 2]
+    loc, first, gpos = sharding.shard_candidates([5, 30, 6, 31], 20, 40)
+    assert loc.tolist() == [30, 31] and first == 1 and gpos.tolist() == [1, 3]
+    loc, first, gpos = sharding.shard_candidates([5, 6, 30, 31], 20, 40)
+    assert loc.tolist() == [30, 31] and first == 2 and gpos is None
+
+
+def test_two_rank_exchange_in_argpartition_order():
+    """Candidate list in an arbitrary order (np.argpartition after top_candidates, reference ital/ital.py:116-117): ties
+    are broken by list position, not by data index, on whichever rank the samples live."""
+    rng = np.random.default_rng(3)
+    n_total = 40
+    scores = rng.normal(size=n_total)
+    order = rng.permutation(n_total)[:25].tolist()
+    scores[[order[4], order[17], order[9]]] = scores.max() + 1.0
+    world, port = 2, _free_port()
+    with mp.Manager() as mgr:
+        ret = mgr.dict()
+        mp.spawn(_worker, args=(world, port, n_total, set(), scores, 0, ret, order), nprocs=world, join=True)
+        r0, r1 = ret[0], ret[1]
+    expect = order[int(np.argmax(scores[order]))]
+    assert expect == order[4]
+    assert r0[0] == expect and r1[0] == expect

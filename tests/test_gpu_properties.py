@@ -35,17 +35,17 @@ def test_ties_resolve_to_lowest_list_position(dev):
 
 
 @pytest.mark.parametrize("n,k", [(700, 5), (100, 5), (3300, 4)])
-def test_scores_do_not_depend_on_the_work_item_split(dev, n, k):
-    """One wave per candidate against work items of one preparation pass, at sizes below, around and above one
-    scheduling round of the grid."""
+def test_scores_do_not_depend_on_the_workspace_slabs(dev, n, k):
+    """The lattice scorer walks the candidates in slabs that fit its workspace: one slab against many (down to a
+    handful of candidates per slab) must give the same bits."""
     from ital_amd import ITAL, mvn_stream
     rng = np.random.default_rng(2)
     X = rng.random((n, 12))
     out = []
-    for split in (1, 2, 8, 16):
+    for work_bytes in (1 << 30, 1 << 22, 1 << 19):
         mvn_stream.GLOBAL.reset()
         L = ITAL(X, length_scale=1.0, device=dev)
-        L.qmc_split = split
+        L.qmc_work_bytes = work_bytes
         L.keep_scores = True
         L.update({3: 1, 4: -1, 5: 1})
         ret = L.fetch_unlabelled(k)
@@ -54,7 +54,7 @@ def test_scores_do_not_depend_on_the_work_item_split(dev, n, k):
         assert ret == out[0][0] and draws == out[0][2]
         for a, b in zip(scores, out[0][1]):
             live = ~np.isnan(a)
-            np.testing.assert_allclose(a[live], b[live], rtol=1e-13, atol=0)   # same terms, different association
+            np.testing.assert_array_equal(a[live], b[live])
 
 
 def test_stream_position_is_a_function_of_the_work_done(dev):

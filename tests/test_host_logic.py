@@ -121,13 +121,13 @@ def test_unsupported_option_combinations_are_named():
 
 
 def test_stream_tables_are_consistent():
-    """jump tables: 2^b calls, 0..63 calls and single draws describe the same generator."""
+    """jump tables: 2^b calls, the prior call of every sign pattern and single draws describe the same generator."""
     from ital_amd import mvn_stream as ms
     n = 5
     d = ms.draws_per_call(n)
     s = ms.MvnStream()
     base = s.state
-    jl = ms.jump_lane_table(n, 64)
+    jl = ms.jump_pattern_table(n)
     j2 = ms.jump_table(n, 8)
     j1 = ms.jump1_table(16)
 
@@ -136,8 +136,8 @@ def test_stream_tables_are_consistent():
         b = [sum(int(row[9 + 3 * i + k]) * st[3 + k] for k in range(3)) % ms.M2 for i in range(3)]
         return tuple(a + b)
 
-    assert apply(jl[0], base) == base
-    assert apply(jl[5], base) == s.peek(5 * d // 8) and apply(jl[16], base) == s.peek(2 * d)
+    assert apply(jl[0], base) == base and len(jl) == 2 ** n
+    assert apply(jl[5], base) == s.peek(10 * d) and apply(jl[31], base) == s.peek(62 * d)
     assert apply(j2[3], base) == s.peek(8 * d)
     st = base
     for bit in range(16):
@@ -155,8 +155,8 @@ def test_ctypes_structs_have_the_layout_of_the_header(tmp_path):
     from ital_amd import _lib
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     probes = {"ital_batch": (_lib.ItalBatch, ["kmax", "bidx", "VB"]),
-              "ital_score_desc": (_lib.ItalScoreDesc, ["t", "batch", "label_mode", "seed", "jumplane", "status", "seeds"]),
-              "ital_gscore_desc": (_lib.ItalGscoreDesc, ["n_cand", "nE", "ldE", "pick_pos", "label_prob", "clip_cov", "seed",
+              "ital_score_desc": (_lib.ItalScoreDesc, ["t", "gpos", "batch", "label_mode", "seed", "jumppat", "status", "work", "work_doubles"]),
+              "ital_gscore_desc": (_lib.ItalGscoreDesc, ["n_cand", "gpos", "nE", "ldE", "pick_pos", "label_prob", "clip_cov", "seed",
                                                          "draws_in", "dead_pos", "fb_samples", "draw_count", "status"]),
               "ital_mcmi_desc": (_lib.ItalMcmiDesc, ["t", "alive", "ld_cov", "batch", "ce"])}
     lines = []
