@@ -27,6 +27,7 @@ typedef struct ihipStream_t* hipStream_t; /* same declaration as hip_runtime_api
 #define ITAL_GENERIC_MAX_DIM 20  /* largest orthant dimension of the general scorer (subset + picks + candidate) */
 #define ITAL_GENERIC_MAX_REL 16  /* largest number of enumerated / sampled variables of the general scorer */
 #define ITAL_GENERIC_MAX_CALLS (1 << 22) /* orthant probabilities per candidate and greedy step */
+#define ITAL_TOPK_MAX 4096  /* largest k of ital_topk */
 
 /* Library identification / error reporting. */
 const char* ital_version(void);
@@ -68,11 +69,22 @@ int ital_whiten_append(const double* X, const double* xnorm, int64_t n, int ldx,
                        const double* alpha_new, double* V, int64_t ldv, int m, double var, double length_scale,
                        double* mu, double* s2, hipStream_t stream);
 
-/* Predictive mean (and variance, if pvar != NULL, clamped at 0) at nt external points.
- * Replaces GaussianProcess.predict, reference ital/gp.py:264-292. */
+/* Predictive mean and variance at nt external points: the points are whitened against the labelled set in sweeps of 16
+ * labelled points (the MFMA kernel of ital_whiten_append), mean = Vt^T alpha, pvar = var - colsum(Vt^2) (clamped at 0
+ * when `clamp`).  xtn: nt doubles of scratch (squared norms); Vt: [m][ldvt] receives the whitened columns of the test
+ * points -- the full predictive covariance is then ital_cov_block(Xt, xtn, nt, Xt, xtn, nt, ldx, Vt, ldvt, Vt, ldvt, m, ...).
+ * Replaces GaussianProcess.predict, reference ital/gp.py:264-292 (cov_mode None / 'diag' / 'full'). */
 int ital_predict(const double* Xt, int64_t nt, int ldx, const double* XT, const double* XTn, int m, const double* L,
-                 int ldl, const double* alpha, double var, double length_scale, double* mean, double* pvar,
-                 hipStream_t stream);
+                 int ldl, const double* alpha, double var, double length_scale, double* mean, double* pvar, double* xtn,
+                 double* Vt, int64_t ldvt, int clamp, hipStream_t stream);
+
+/* The k largest of v[0..n) in descending order (NaN first, equal values by descending index -- the order of
+ * np.argsort(v)[::-1][:k] with a stable sort): out_vals[k], out_idx[k] = index_offset + position.  Exact radix select on
+ * the device, nothing of size n leaves it.  work: ital_topk_workspace() bytes of device memory.  1 <= k <= ITAL_TOPK_MAX,
+ * k <= n.  Replaces ActiveRetrievalBase.top_results, reference ital/retrieval_base.py:64-75. */
+int ital_topk(const double* v, int64_t n, int64_t index_offset, int k, double* out_vals, int64_t* out_idx, void* work,
+              hipStream_t stream);
+int64_t ital_topk_workspace(void);
 
 /* ---- greedy batch construction ------------------------------------------------------------------------
  * Batch state, replicated on every rank, updated only by ital_select_resolve (device side, no host sync). */

@@ -16,6 +16,7 @@ ITAL_JUMP_BITS = 48
 ITAL_GENERIC_MAX_DIM = 20
 ITAL_GENERIC_MAX_REL = 16
 ITAL_GENERIC_MAX_CALLS = 1 << 22
+ITAL_TOPK_MAX = 4096
 
 
 class ItalBatch(ctypes.Structure):
@@ -65,7 +66,9 @@ SIGNATURES = {
                                    c_void_p, c_void_p, c_void_p, c_int64, c_int, c_double, c_double, c_void_p,
                                    c_void_p, c_void_p]),
     "ital_predict": (c_int, [c_void_p, c_int64, c_int, c_void_p, c_void_p, c_int, c_void_p, c_int, c_void_p,
-                             c_double, c_double, c_void_p, c_void_p, c_void_p]),
+                             c_double, c_double, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_void_p]),
+    "ital_topk": (c_int, [c_void_p, c_int64, c_int64, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "ital_topk_workspace": (c_int64, []),
     "ital_score_step": (c_int, [ctypes.POINTER(ItalScoreDesc), c_void_p]),
     "ital_score_workspace": (c_int64, [c_int, c_int64]),
     "ital_cov_block": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_int, c_void_p, c_int64,

@@ -31,6 +31,27 @@ __device__ __forceinline__ double fast_div(double n, double d) {
     return fma(fma(-d, q, n), r, q);
 }
 
+// Polynomial coefficients as operands.  With literals (LitK) the compiler materialises every coefficient next to its use:
+// in a loop that already fills the scalar register file it parks them in vector registers and emits `v_mov_b64 acc, K;
+// v_fmac_f64 acc, p, r` per Horner step -- the copy is a full-rate FP64 issue slot, 12 % of the lattice loop's vector
+// instructions.  HotK holds the coefficients of exp and log as opaque vector-register values instead: the steps become
+// three-operand `v_fma_f64 p, p, r, K` with no copy (same 20 + 18 registers the parked literals took).
+struct LitK {};
+__device__ __forceinline__ double opaque_v(double k) { asm volatile("" : "+v"(k)); return k; }
+struct HotK {
+    double e[10];   // exp_neg: q(r) of exp(r) = 1 + r + r^2 q(r)
+    double l[9];    // log_pos: odd atanh series 2/19 .. 2/3
+    __device__ __forceinline__ void load() {
+        e[0] = opaque_v(2.5100375832561321544e-8); e[1] = opaque_v(2.7620075879983480862e-7);
+        e[2] = opaque_v(2.7557268480310025341e-6); e[3] = opaque_v(0.000024801521322368693026);
+        e[4] = opaque_v(0.00019841269863040545271); e[5] = opaque_v(0.0013888888917196719077);
+        e[6] = opaque_v(0.0083333333333300644495); e[7] = opaque_v(0.041666666666624161903);
+        e[8] = opaque_v(0.16666666666666667452); e[9] = opaque_v(0.50000000000000010211);
+#pragma unroll
+        for (int i = 0; i < 9; i++) l[i] = opaque_v(2.0 / (19 - 2 * i));
+    }
+};
+
 // exp(x) for x in [-745, 0]: Cody-Waite reduction by ln2, degree-13 Taylor polynomial on |r| <= ln2/2 (relative error
 // < 1e-16), scaling by v_ldexp_f64.  19 VALU instructions against ~42 for the general-purpose library routine.
 __device__ __forceinline__ double exp_neg(double x) {
@@ -69,6 +90,20 @@ __device__ __forceinline__ double exp_neg(double x) {
     return ldexp(p, (int)n);
 }
 
+__device__ __forceinline__ double exp_neg(double x, const LitK&) { return exp_neg(x); }
+__device__ __forceinline__ double exp_neg(double x, const HotK& k) {
+    const double LOG2E = 1.4426950408889634074, LN2_HI = 6.93147180369123816490e-01, LN2_LO = 1.90821492927058770002e-10;
+    const double n = rint(x * LOG2E);
+    double r = fma(-n, LN2_HI, x);
+    r = fma(-n, LN2_LO, r);
+    double p = k.e[0];
+#pragma unroll
+    for (int i = 1; i < 10; i++) p = fma(p, r, k.e[i]);
+    p = fma(p, r, 1.0);
+    p = fma(p, r, 1.0);
+    return ldexp(p, (int)n);
+}
+
 // log(x) for finite x > 0: x = 2^e * m, m in [sqrt(1/2), sqrt(2)), log m = 2 atanh(s), s = (m-1)/(m+1), odd series to s^19
 // (|s| <= 0.1716: truncation < 3e-17 relative).  ~30 VALU instructions against ~98 for the library routine.
 __device__ __forceinline__ double log_pos(double x) {
@@ -95,6 +130,25 @@ __device__ __forceinline__ double log_pos(double x) {
     return fma(de, LN2_HI, fma(de, LN2_LO, lm));
 }
 
+__device__ __forceinline__ double log_pos(double x, const LitK&) { return log_pos(x); }
+__device__ __forceinline__ double log_pos(double x, const HotK& k) {
+    const double LN2_HI = 6.93147180369123816490e-01, LN2_LO = 1.90821492927058770002e-10;
+    int e = __builtin_amdgcn_frexp_exp(x);
+    double m = __builtin_amdgcn_frexp_mant(x);  // [0.5, 1)
+    const bool lowm = m < 0.70710678118654752440;
+    m = lowm ? m + m : m;
+    e = lowm ? e - 1 : e;
+    const double f = m - 1.0;
+    const double s = fast_div(f, 2.0 + f);
+    const double z = s * s;
+    double p = k.l[0];
+#pragma unroll
+    for (int i = 1; i < 9; i++) p = fma(p, z, k.l[i]);
+    const double lm = fma(s * z, p, s + s);
+    const double de = (double)e;
+    return fma(de, LN2_HI, fma(de, LN2_LO, lm));
+}
+
 // sqrt(a) for a in a normal, well-scaled range (here [1e-3, 1e3]): reciprocal-square-root seed (~2^-23), one Goldschmidt step (2^-46)
 // and a final residual correction that squares the error again (~1 ulp).
 __device__ __forceinline__ double sqrt_pos(double a) {
@@ -114,7 +168,8 @@ __device__ __forceinline__ double sqrt_pos(double a) {
 
 // MVNPHI (Hart 5666).  The far-tail continued fraction z + 1/(z + 2/(z + 3/(z + 4/(z + 0.65)))) is evaluated as the
 // ratio of its convergents' numerators N1/N2 (one division instead of six).
-__device__ __forceinline__ double mvn_phi(double z) {
+template <class K>
+__device__ __forceinline__ double mvn_phi(double z, const K& kk) {
     const double P0 = 220.2068679123761, P1 = 221.2135961699311, P2 = 112.0792914978709, P3 = 33.91286607838300,
                  P4 = 6.373962203531650, P5 = .7003830644436881, P6 = .03526249659989109;
     const double Q0 = 440.4137358247522, Q1 = 793.8265125199484, Q2 = 637.3336333788311, Q3 = 296.5642487796737,
@@ -125,7 +180,7 @@ __device__ __forceinline__ double mvn_phi(double z) {
     if (zabs > 37.0) {
         p = 0.0;
     } else {
-        const double expntl = exp_neg(-zabs * zabs / 2);
+        const double expntl = exp_neg(-zabs * zabs / 2, kk);
         if (zabs < CUTOFF) {
             const double num = fma_k(fma_k(fma_k(fma_k(fma_k(fma_k(P6, zabs, P5), zabs, P4), zabs, P3), zabs, P2), zabs, P1), zabs, P0);
             const double den = fma_k(fma_k(fma_k(fma_k(fma_k(fma_k(fma_k(Q7, zabs, Q6), zabs, Q5), zabs, Q4), zabs, Q3), zabs, Q2), zabs, Q1), zabs, Q0);
@@ -143,29 +198,34 @@ __device__ __forceinline__ double mvn_phi(double z) {
     return p;
 }
 
+__device__ __forceinline__ double mvn_phi(double z) { return mvn_phi(z, LitK()); }
+
 // PHINV (Wichura AS241 PPND16), split so that a wave can run the cheap central branch on every lane and the
 // log/sqrt tail branch only on the (compacted) lanes that need it.
 __device__ __forceinline__ bool phinv_is_central(double p) { return fabs(p - 0.5) <= 0.425; }
 
-__device__ __forceinline__ double phinv_central(double p) {
+// central branch on q = p - 1/2 (bit-identical to AS241's (2p - 1)/2: doubling and halving are exact)
+__device__ __forceinline__ double phinv_central_q(double q) {
     const double A0 = 3.3871328727963666080E0, A1 = 1.3314166789178437745E+2, A2 = 1.9715909503065514427E+3,
                  A3 = 1.3731693765509461125E+4, A4 = 4.5921953931549871457E+4, A5 = 6.7265770927008700853E+4,
                  A6 = 3.3430575583588128105E+4, A7 = 2.5090809287301226727E+3, B1 = 4.2313330701600911252E+1,
                  B2 = 6.8718700749205790830E+2, B3 = 5.3941960214247511077E+3, B4 = 2.1213794301586595867E+4,
                  B5 = 3.9307895800092710610E+4, B6 = 2.8729085735721942674E+4, B7 = 5.2264952788528545610E+3;
-    const double q = (2 * p - 1) / 2;
     const double r = 0.180625 - q * q;
     const double num = fma_k(fma_k(fma_k(fma_k(fma_k(fma_k(fma_k(A7, r, A6), r, A5), r, A4), r, A3), r, A2), r, A1), r, A0);
     const double den = fma(fma_k(fma_k(fma_k(fma_k(fma_k(fma_k(B7, r, B6), r, B5), r, B4), r, B3), r, B2), r, B1), r, 1.0);
     return fast_div(q * num, den);
 }
 
-__device__ __forceinline__ double phinv_tail(double p) {
-    const double q = (2 * p - 1) / 2;
+__device__ __forceinline__ double phinv_central(double p) { return phinv_central_q(p - 0.5); }
+
+template <class K>
+__device__ __forceinline__ double phinv_tail(double p, const K& kk) {
+    const double q = p - 0.5;
     double r = fmin(p, 1 - p);
     double v;
     if (r > 0) {
-        r = sqrt_pos(-log_pos(r));
+        r = sqrt_pos(-log_pos(r, kk));
         if (r <= 5.0) {
             const double C0 = 1.42343711074968357734E0, C1 = 4.63033784615654529590E0, C2 = 5.76949722146069140550E0,
                          C3 = 3.64784832476320460504E0, C4 = 1.27045825245236838258E0, C5 = 2.41780725177450611770E-1,
@@ -190,6 +250,8 @@ __device__ __forceinline__ double phinv_tail(double p) {
     }
     return q < 0 ? -v : v;
 }
+
+__device__ __forceinline__ double phinv_tail(double p) { return phinv_tail(p, LitK()); }
 
 __device__ __forceinline__ double mvn_phinv(double p) {
     return phinv_is_central(p) ? phinv_central(p) : phinv_tail(p);

@@ -30,15 +30,17 @@ __device__ __forceinline__ double uniform_f64(double v) {
 // expensive log/sqrt branch runs on full waves of tail arguments only (typically once per 256 inversions instead of
 // once per 64).
 // q: wave-private LDS queue of 64*NC doubles.
-template <int NC>
-__device__ __forceinline__ void phinv_wave(const double (&p)[NC], double (&out)[NC], double* __restrict__ q, int lane) {
+template <int NC, class K>
+__device__ __forceinline__ void phinv_wave(const double (&p)[NC], double (&out)[NC], double* __restrict__ q, int lane,
+                                           const K& kk) {
     bool need[NC];
     int slot[NC];
     int total = 0;
 #pragma unroll
     for (int c = 0; c < NC; c++) {
-        need[c] = !phinv_is_central(p[c]);
-        out[c] = phinv_central(p[c]);   // garbage (never a trap) for tail arguments: replaced below
+        const double qc = p[c] - 0.5;
+        need[c] = !(fabs(qc) <= 0.425);
+        out[c] = phinv_central_q(qc);   // garbage (never a trap) for tail arguments: replaced below
         const unsigned long long m = __ballot(need[c]);
         slot[c] = total + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
         total += __popcll(m);
@@ -50,7 +52,7 @@ __device__ __forceinline__ void phinv_wave(const double (&p)[NC], double (&out)[
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     for (int s0 = 0; s0 < total; s0 += 64) {
         const int sl = s0 + lane;
-        if (sl < total) q[sl] = phinv_tail(q[sl]);   // in place: each lane rewrites the slot it read
+        if (sl < total) q[sl] = phinv_tail(q[sl], kk);   // in place: each lane rewrites the slot it read
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
@@ -60,20 +62,23 @@ __device__ __forceinline__ void phinv_wave(const double (&p)[NC], double (&out)[
         if (need[c]) out[c] = q[slot[c]];
 }
 
-__device__ __forceinline__ void phinv_wave4(const double (&p)[4], double (&out)[4], double* __restrict__ q, int lane) {
-    phinv_wave<4>(p, out, q, lane);
+template <int NC>
+__device__ __forceinline__ void phinv_wave(const double (&p)[NC], double (&out)[NC], double* __restrict__ q, int lane) {
+    phinv_wave<NC>(p, out, q, lane, LitK());
 }
 
 // The integrand of NCB lattice points per lane (MVNDFN for one-sided limits): sequential conditioning over the T
 // variables, every chain independent of the others; returns the lane's sum of the integrand values.  cf: packed strict
 // lower triangle of the row-scaled factor, lm: scaled limits (wave-uniform), bit i of infi: variable i is bounded below.
-template <int T, int NCB>
+template <int T, int NCB, class K>
 __device__ __forceinline__ double eval_chains(const double (&xx)[NCB][(T - 1 > 0 ? T - 1 : 1)], bool (&dead)[NCB],
                                               const double (&cf)[(T * (T - 1) / 2 > 0 ? T * (T - 1) / 2 : 1)],
-                                              const double (&lm)[T], unsigned infi_c, double* tailq, int lane) {
+                                              const double (&lm)[T], unsigned infi_c, double* tailq, int lane, const K& kk) {
+    // a chain whose interval closes (w == 0, MVNDFN's early return) keeps ff == 0 through the finite values that follow
+    // (Phi^-1 of exactly 0 or 1 is -+9 here); chains beyond the end of the lattice start from 0
     double yy[NCB][(T - 1 > 0 ? T - 1 : 1)], ff[NCB];
 #pragma unroll
-    for (int c = 0; c < NCB; c++) ff[c] = 1.0;
+    for (int c = 0; c < NCB; c++) ff[c] = dead[c] ? 0.0 : 1.0;
 #pragma unroll
     for (int i = 0; i < T; i++) {
         const bool lower = (infi_c >> i) & 1u;
@@ -83,33 +88,33 @@ __device__ __forceinline__ double eval_chains(const double (&xx)[NCB][(T - 1 > 0
             double sc = 0;
 #pragma unroll
             for (int j = 0; j < i; j++) sc = fma(cf[i * (i - 1) / 2 + j], yy[c][j], sc);
-            const double ph = mvn_phi(lm[i] - sc);
+            const double ph = mvn_phi(lm[i] - sc, kk);
             const double d = lower ? ph : 0.0;
             const double w = lower ? 1.0 - ph : ph;
-            dead[c] = dead[c] || !(w > 0);
             ff[c] *= w;
             if (i < T - 1) pin[c] = fma(xx[c][i], w, d);   // a dead chain (w == 0) just inverts d: finite, discarded
         }
         if (i < T - 1) {
             double out[NCB];
-            phinv_wave<NCB>(pin, out, tailq, lane);
+            phinv_wave<NCB>(pin, out, tailq, lane, kk);
 #pragma unroll
             for (int c = 0; c < NCB; c++) yy[c][i] = out[c];
         }
     }
     double acc = 0.0;
 #pragma unroll
-    for (int c = 0; c < NCB; c++) acc += dead[c] ? 0.0 : ff[c];
+    for (int c = 0; c < NCB; c++) acc += ff[c];
     return acc;
 }
 
 // Sum over this lane's share of the 16 P lattice points of one orthant call of compile-time dimension T (8 randomly
 // shifted Korobov lattices of P points, each point with its antithetic partner).  lat: [8][NDIM] permuted generators, then
 // [8][NDIM] shifts; cf / lm / infi as eval_chains.  The caller adds the lanes up and divides by 16 P.
-template <int T>
+template <int T, class K = LitK>
 __device__ __forceinline__ double qmc_lane_sum(const double* __restrict__ lat,
                                                const double (&cf)[(T * (T - 1) / 2 > 0 ? T * (T - 1) / 2 : 1)],
-                                               const double (&lm)[T], unsigned infi_c, double* __restrict__ tailq, int lane) {
+                                               const double (&lm)[T], unsigned infi_c, double* __restrict__ tailq, int lane,
+                                               const K& kk = K()) {
     constexpr int NDIM = T - 1, PRIME = P_TAB[(NDIM < 10 ? NDIM : 10) - 1];
     double acc = 0.0;
     // NC = 2*NH independent chains per lane: NH lattice items, each with its antithetic partner.  The 16 P
@@ -140,7 +145,7 @@ __device__ __forceinline__ double qmc_lane_sum(const double* __restrict__ lat,
             }
             dead[2 * h] = dead[2 * h + 1] = !ok;
         }
-        acc += eval_chains<T, NC>(xx, dead, cf, lm, infi_c, tailq, lane);
+        acc += eval_chains<T, NC>(xx, dead, cf, lm, infi_c, tailq, lane, kk);
     }
     if (NCL > 0 && NCL != NC) {
         constexpr int NCLA = NCL > 0 ? NCL : 1;
@@ -178,7 +183,7 @@ __device__ __forceinline__ double qmc_lane_sum(const double* __restrict__ lat,
             }
             dead[NCLA - 1] = !ok;
         }
-        acc += eval_chains<T, NCLA>(xx, dead, cf, lm, infi_c, tailq, lane);
+        acc += eval_chains<T, NCLA>(xx, dead, cf, lm, infi_c, tailq, lane, kk);
     }
     return acc;
 }

@@ -184,51 +184,19 @@ __global__ __launch_bounds__(256) void kcols_kernel(KcolsArgs a) {
     }
 }
 
-// gp.predict on external points (reference ital/gp.py:264-292): mean = w^T k(T, x), var = max(0, v - |L^-1 k|^2).
-// Small (the harness calls it once per round on the test split); one wave per test point, k vector in LDS.
-__global__ __launch_bounds__(256) void predict_kernel(const double* __restrict__ Xt, int64_t nt, int ldx,
-                                                      const double* __restrict__ XT, const double* __restrict__ XTn,
-                                                      int m, const double* __restrict__ L, int ldl,
-                                                      const double* __restrict__ alpha, double var, double s,
-                                                      double* __restrict__ mean, double* __restrict__ pvar) {
-    extern __shared__ double kv_all[];  // [4][m]
-    const int lane = threadIdx.x & 63;
-    const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-    if (wave >= nt) return;
-    const double* x = Xt + wave * ldx;
-    double* kv = kv_all + (threadIdx.x >> 6) * m;
-    double xn = 0;
-    for (int k = lane; k < ldx; k += 64) xn += x[k] * x[k];
-    xn = wave_sum(xn);
-    for (int r = 0; r < m; r++) {
-        const double* t = XT + (int64_t)r * ldx;
-        double dot = 0;
-        for (int k = lane; k < ldx; k += 64) dot += x[k] * t[k];
-        dot = wave_sum(dot);
-        if (lane == 0) kv[r] = var * exp((XTn[r] + xn - 2 * dot) / s);
-    }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    // forward substitution u = L^-1 k (serial over r, dot products across lanes)
-    double mu = 0, nrm = 0;
-    for (int r = 0; r < m; r++) {
-        double acc = 0;
-        for (int q = lane; q < r; q += 64) acc += L[(int64_t)r * ldl + q] * kv[q];
-        acc = wave_sum(acc);
-        double u = (kv[r] - acc) / L[(int64_t)r * ldl + r];
-        __builtin_amdgcn_wave_barrier();
-        if (lane == 0) kv[r] = u;
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        mu += u * alpha[r];
-        nrm += u * u;
-    }
-    if (lane == 0) {
-        mean[wave] = mu;
-        if (pvar) pvar[wave] = fmax(0.0, var - nrm);
-    }
+// gp.predict on external points (reference ital/gp.py:264-292): the test points are whitened against the labelled set
+// exactly as the data rows are -- 16 labelled points per sweep of kcols_kernel in MODE_WHITEN (-2 Xt XT^T on FP64 MFMA,
+// forward substitution against the Cholesky factor, mean += V^T alpha, var -= colsum(V^2)) -- which also leaves the
+// whitened columns Vt for the full predictive covariance K(Xt, Xt) - Vt^T Vt (ital_cov_block).
+__global__ __launch_bounds__(256) void predict_init_kernel(int64_t nt, double var, double* __restrict__ mean,
+                                                           double* __restrict__ pvar) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < nt) { mean[i] = 0.0; pvar[i] = var; }
+}
+
+__global__ __launch_bounds__(256) void clamp0_kernel(int64_t nt, double* __restrict__ pvar) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < nt) pvar[i] = fmax(0.0, pvar[i]);     // np.maximum(0, ...) of gp.py:290
 }
 
 }  // namespace ital
@@ -288,11 +256,22 @@ extern "C" int ital_whiten_append(const double* X, const double* xnorm, int64_t 
 
 extern "C" int ital_predict(const double* Xt, int64_t nt, int ldx, const double* XT, const double* XTn, int m,
                             const double* L, int ldl, const double* alpha, double var, double length_scale,
-                            double* mean, double* pvar, hipStream_t stream) {
+                            double* mean, double* pvar, double* xtn, double* Vt, int64_t ldvt, int clamp,
+                            hipStream_t stream) {
     if (nt <= 0) return 0;
     if (m <= 0) return ital_fail(-22, "ital_predict: GP is not fitted");
-    int64_t blocks = (nt + 3) / 4;
-    hipLaunchKernelGGL(predict_kernel, dim3((unsigned)blocks), dim3(256), (size_t)4 * m * sizeof(double), stream, Xt, nt,
-                       ldx, XT, XTn, m, L, ldl, alpha, var, -2.0 * length_scale * length_scale, mean, pvar);
+    if (!mean || !pvar || !xtn || !Vt) return ital_fail(-22, "ital_predict: mean / pvar / xtn / Vt must all be given");
+    if (ldvt < nt) return ital_fail(-22, "ital_predict: ldvt smaller than the number of test points");
+    int rc = ital_row_norms(Xt, nt, ldx, xtn, stream);
+    if (rc) return rc;
+    const unsigned blocks = (unsigned)((nt + 255) / 256);
+    hipLaunchKernelGGL(predict_init_kernel, dim3(blocks), dim3(256), 0, stream, nt, var, mean, pvar);
+    for (int c0 = 0; c0 < m; c0 += 16) {
+        const int c = m - c0 < 16 ? m - c0 : 16;
+        rc = ital_whiten_append(Xt, xtn, nt, ldx, XT + (int64_t)c0 * ldx, XTn + c0, c, L + (int64_t)c0 * ldl, ldl,
+                                L + (int64_t)c0 * ldl + c0, alpha + c0, Vt, ldvt, c0, var, length_scale, mean, pvar, stream);
+        if (rc) return rc;
+    }
+    if (clamp) hipLaunchKernelGGL(clamp0_kernel, dim3(blocks), dim3(256), 0, stream, nt, pvar);
     return ital_check_launch("ital_predict");
 }

@@ -23,6 +23,9 @@
 #include "ital_internal.h"
 #include "qmc_common.h"
 
+#ifndef ITAL_QMC_HOTK
+#define ITAL_QMC_HOTK 1   // exp / log coefficients of the lattice loop as vector-register operands (device_math.h HotK)
+#endif
 #ifndef ITAL_QMC_WAVES
 #define ITAL_QMC_WAVES(T) ((T) <= 4 ? 3 : 2)   // waves per SIMD the register allocation aims at (measured)
 #endif
@@ -454,7 +457,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(ITAL_QMC_WA
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#if ITAL_QMC_HOTK
+        HotK kk;
+        kk.load();
+        const double acc = qmc_lane_sum<T, HotK>(lat, cf, lm, infi, tailq, lane, kk);
+#else
         const double acc = qmc_lane_sum<T>(lat, cf, lm, infi, tailq, lane);
+#endif
         pr = wave_sum(acc) / (16.0 * Q::PRIME);
     }
     if (lane == 0) {

@@ -54,11 +54,18 @@ class GaussianProcess(object):
         # the exchange steps run whenever there is more than one rank -- or, with ITAL_FORCE_COLLECTIVES=1, also on a
         # one-rank process group (lets a single-GPU box drive the RCCL code path end to end)
         self.collective = self.world > 1 or (group is not None and os.environ.get("ITAL_FORCE_COLLECTIVES") == "1")
-        data = np.asarray(data, dtype=np.float64)
+        local = None
+        if isinstance(data, sharding.ShardedRows):
+            local = data
+        else:
+            data = np.asarray(data, dtype=np.float64)
         if data.ndim != 2:
             raise ValueError("data must be an n-by-d array")
         self.n_total, self.d = data.shape
         self.row0, self.row1 = sharding.row_range(self.n_total, self.world, self.rank)
+        if local is not None and (local.row0, local.row1) != (self.row0, self.row1):
+            raise ValueError("ShardedRows holds rows [%d, %d), this rank owns [%d, %d)"
+                             % (local.row0, local.row1, self.row0, self.row1))
         self.n = self.row1 - self.row0
         self.ldx = _pad16(self.d)
         self.ldv = _pad16(max(self.n, 1))
@@ -70,7 +77,8 @@ class GaussianProcess(object):
         with torch.cuda.device(self.device):
             Xp = torch.zeros((max(self.n, 1), self.ldx), dtype=torch.float64, device=self.device)
             if self.n:
-                Xp[: self.n, : self.d] = torch.from_numpy(np.ascontiguousarray(data[self.row0:self.row1])).to(self.device)
+                rows = local.local if local is not None else data[self.row0:self.row1]
+                Xp[: self.n, : self.d] = torch.from_numpy(np.ascontiguousarray(rows)).to(self.device)
             self.Xd = Xp
             self.xnorm = torch.empty(max(self.n, 1), dtype=torch.float64, device=self.device)
             check(self._lib.ital_row_norms(_ptr(self.Xd), self.n, self.ldx, _ptr(self.xnorm), _stream()))
@@ -162,6 +170,8 @@ class GaussianProcess(object):
         self.m = 0
         self.mu = torch.zeros(max(self.n, 1), dtype=torch.float64, device=self.device)
         self.s2 = torch.full((max(self.n, 1),), float(self.var), dtype=torch.float64, device=self.device)
+        self.mu_all = torch.zeros(self.n_total, dtype=torch.float64, device=self.device) if self.collective else self.mu[: self.n]
+        self._mean_host = None
         self.status.zero_()
 
     # ------------------------------------------------------------------ fitting
@@ -170,18 +180,27 @@ class GaussianProcess(object):
         self.reset()
         return self.update(ind, y)
 
-    def update(self, ind, y):
-        """Adds labelled samples (reference gp.py:164-200), as a rank-c Cholesky append."""
+    def update(self, ind, y, row_cache=None):
+        """Adds labelled samples (reference gp.py:164-200), as a rank-c Cholesky append.
+
+        `row_cache`: optional (device matrix [k, ldx], {data index: row of that matrix}) holding feature rows that are
+        already replicated on every rank -- the batch state of the last fetch_unlabelled: the winners' rows travelled in
+        the selection records, so labelling them needs no further exchange between the ranks."""
         ind = [int(i) for i in ind]
         y = np.asarray(y, dtype=np.float64).reshape(-1)
         if len(ind) != len(y):
             raise ValueError("ind and y differ in length")
         if len(ind) == 0:
             return self
-        rows = self._gather_rows(ind)
+        if row_cache is not None and all(i in row_cache[1] for i in ind):
+            slots = torch.as_tensor([row_cache[1][i] for i in ind], dtype=torch.int64, device=self.device)
+            rows = row_cache[0].index_select(0, slots)
+        else:
+            rows = self._gather_rows(ind)
         self._append(rows, y)
         self.ind += ind
         self.y = y.copy() if self.y is None else np.concatenate((self.y, y))
+        self._replicate_mean()
         return self
 
     def update_points(self, points, y, ind=None):
@@ -194,6 +213,7 @@ class GaussianProcess(object):
         self._append(rows, y)
         self.ind += list(ind) if ind is not None else list(range(self.n_total + self.m - len(y), self.n_total + self.m))
         self.y = y.copy() if self.y is None else np.concatenate((self.y, y))
+        self._replicate_mean()
         return self
 
     def _owned(self, ind):
@@ -265,19 +285,60 @@ class GaussianProcess(object):
 
     # ------------------------------------------------------------------ prediction
     def _full(self, t):
-        """Local shard vector -> full-length numpy array (all ranks)."""
+        """Local shard vector -> full-length numpy array (all ranks; a collective when the rows are sharded)."""
+        return self._full_device(t).cpu().numpy()
+
+    def _full_device(self, t):
+        """Local shard vector -> full-length device vector, replicated on every rank (one all-gather of equal-sized,
+        padded shards when the rows are sharded)."""
         loc = t[: self.n]
         if not self.collective:
-            return loc.cpu().numpy()
-        sizes = [b - a for a, b in (sharding.row_range(self.n_total, self.world, r) for r in range(self.world))]
-        return sharding.all_gather_parts(loc, sizes, self.group).cpu().numpy()
+            return loc
+        pad = (self.n_total + self.world - 1) // self.world
+        send = torch.zeros(pad, dtype=loc.dtype, device=self.device)
+        send[: self.n] = loc
+        recv = torch.empty((self.world, pad), dtype=loc.dtype, device=self.device)
+        sharding.gather_records(send, recv, self.group)
+        parts = []
+        for r in range(self.world):
+            a, b = sharding.row_range(self.n_total, self.world, r)
+            parts.append(recv[r, : b - a])
+        return torch.cat(parts)
+
+    def _replicate_mean(self):
+        """Called by every rank at the end of an update: the predictive means of ALL samples as a device vector on every
+        rank (asynchronous, on the stream).  What reads them later -- `rel_mean`, top_results(), the candidate restriction
+        of `top_candidates` -- is then a local operation: reading an attribute on one rank only cannot dead-lock the
+        others (the reference refreshes `rel_mean` inside update() too, retrieval_base.py:58,120)."""
+        self.mu_all = self._full_device(self.mu)
+        self._mean_host = None
+
+    def mean_host(self):
+        """Predictive mean of every sample as a numpy array (downloaded on first use after an update; no collective)."""
+        if self._mean_host is None:
+            self._mean_host = self.mu_all.cpu().numpy()
+        return self._mean_host
+
+    def topk_mean(self, k):
+        """Indices of the k samples of largest predictive mean, descending (NaN first, ties by descending index), selected
+        on the device (ital_topk): nothing of size N is downloaded.  Local operation on the replicated means."""
+        k = int(k)
+        n = self.n_total
+        if not (1 <= k <= min(_lib.ITAL_TOPK_MAX, n)):
+            raise ValueError("k outside 1..min(%d, number of samples)" % _lib.ITAL_TOPK_MAX)
+        if getattr(self, "_topk_work", None) is None:
+            self._topk_work = torch.empty(int(self._lib.ital_topk_workspace()), dtype=torch.uint8, device=self.device)
+        vals = torch.empty(k, dtype=torch.float64, device=self.device)
+        idx = torch.empty(k, dtype=torch.int64, device=self.device)
+        check(self._lib.ital_topk(_ptr(self.mu_all), n, 0, k, _ptr(vals), _ptr(idx), _ptr(self._topk_work), _stream()))
+        return idx.cpu().numpy()
 
     def predict_stored(self, ind=None, cov_mode=None):
         """Predictive mean / variance / covariance of samples of the data matrix (reference gp.py:203-232)."""
         if self.m == 0:
             raise RuntimeError("the GP has not been fitted: call fit()/update() first "
                                "(the reference fails with an AttributeError at gp.py:222)")
-        mean = self._full(self.mu)
+        mean = self.mean_host()
         if ind is not None:
             ind = np.asarray(ind, dtype=np.int64)
             mean = mean[ind]
@@ -293,25 +354,21 @@ class GaussianProcess(object):
         raise ValueError("cov_mode must be None, 'diag' or 'full'")
 
     def _cov_full(self, ind):
-        """K[S,S] - V[:,S]^T V[:,S] for a short index list S (single-rank helper, not on the hot path)."""
-        if self.world != 1:
-            raise NotImplementedError("full covariance blocks are only provided on a single rank")
-        out = np.empty((len(ind), len(ind)))
-        rows = self._gather_rows([int(i) for i in ind])
-        norms = torch.empty(len(ind), dtype=torch.float64, device=self.device)
-        check(self._lib.ital_row_norms(_ptr(rows), len(ind), self.ldx, _ptr(norms), _stream()))
-        idx = torch.as_tensor(ind, dtype=torch.int64, device=self.device)
-        Vs = self.V[: self.m].index_select(1, idx).contiguous()  # m x |S|
-        for c0 in range(0, len(ind), 16):
-            c = min(16, len(ind) - c0)
-            W = Vs[:, c0:c0 + c].t().contiguous()
-            buf = torch.empty((c, self.ldv), dtype=torch.float64, device=self.device)
-            check(self._lib.ital_cross_cov_cols(_ptr(self.Xd), _ptr(self.xnorm), self.n, self.ldx, _ptr(rows[c0:c0 + c]),
-                                                _ptr(norms[c0:c0 + c]), c, _ptr(W), max(self.m, 1), _ptr(self.V), self.ldv,
-                                                self.m, float(self.var), float(self.length_scale), _ptr(buf), self.ldv,
-                                                _stream()))
-            out[c0:c0 + c] = buf[:, : self.n].index_select(1, idx).cpu().numpy()
-        return out
+        """K[S,S] - V[:,S]^T V[:,S] for a short index list S: feature rows and whitened columns of S are replicated (owners
+        contribute), every rank then forms the |S| x |S| block itself (ital_cov_block, FP64 MFMA)."""
+        ind = [int(i) for i in ind]
+        ns = len(ind)
+        rows = self._gather_rows(ind)
+        norms = torch.empty(ns, dtype=torch.float64, device=self.device)
+        check(self._lib.ital_row_norms(_ptr(rows), ns, self.ldx, _ptr(norms), _stream()))
+        lds = _pad16(ns)
+        Vs = torch.zeros((max(self.m, 1), lds), dtype=torch.float64, device=self.device)
+        Vs[: self.m, :ns] = self.gather_columns(self.V[: max(self.m, 1)], ind)[: self.m]
+        out = torch.empty((ns, lds), dtype=torch.float64, device=self.device)
+        check(self._lib.ital_cov_block(_ptr(rows), _ptr(norms), ns, _ptr(rows), _ptr(norms), ns, self.ldx, _ptr(Vs), lds,
+                                       _ptr(Vs), lds, self.m, float(self.var), float(self.length_scale), _ptr(out), lds,
+                                       _stream()))
+        return out[:, :ns].cpu().numpy()
 
     def updated_prediction(self, ind, y, pred_ind, cov_mode=None):
         """Prediction for `pred_ind` after a simulated update with (ind, y), without updating (reference gp.py:295-344).
@@ -350,20 +407,31 @@ class GaussianProcess(object):
         return out[:, : self.n]
 
     def predict(self, X, cov_mode=None):
-        """Predictive mean (and variance) for external samples (reference gp.py:264-292)."""
+        """Predictive mean (and variance / full covariance) for external samples (reference gp.py:264-292).  Every rank
+        computes it for all of X (the labelled-set state is replicated): no collective."""
         if self.m == 0:
             raise RuntimeError("the GP has not been fitted")
-        if cov_mode == "full":
-            raise NotImplementedError("full predictive covariance of external samples is not on the hot path")
+        if cov_mode not in (None, "diag", "full"):
+            raise ValueError("cov_mode must be None, 'diag' or 'full'")
         X = np.atleast_2d(np.asarray(X, dtype=np.float64))
         nt = X.shape[0]
-        Xt = torch.zeros((nt, self.ldx), dtype=torch.float64, device=self.device)
-        Xt[:, : self.d] = torch.from_numpy(np.ascontiguousarray(X)).to(self.device)
-        mean = torch.empty(nt, dtype=torch.float64, device=self.device)
-        pvar = torch.empty(nt, dtype=torch.float64, device=self.device) if cov_mode == "diag" else None
+        dev = self.device
+        Xt = torch.zeros((nt, self.ldx), dtype=torch.float64, device=dev)
+        Xt[:, : self.d] = torch.from_numpy(np.ascontiguousarray(X)).to(dev)
+        ldvt = _pad16(nt)
+        mean = torch.empty(nt, dtype=torch.float64, device=dev)
+        pvar = torch.empty(nt, dtype=torch.float64, device=dev)
+        xtn = torch.empty(nt, dtype=torch.float64, device=dev)
+        Vt = torch.empty((self.m, ldvt), dtype=torch.float64, device=dev)
         check(self._lib.ital_predict(_ptr(Xt), nt, self.ldx, _ptr(self.XT), _ptr(self.XTn), self.m, _ptr(self.L), self.cap,
                                      _ptr(self.alpha), float(self.var), float(self.length_scale), _ptr(mean), _ptr(pvar),
-                                     _stream()))
+                                     _ptr(xtn), _ptr(Vt), ldvt, 1, _stream()))
         if cov_mode == "diag":
             return mean.cpu().numpy(), pvar.cpu().numpy()
+        if cov_mode == "full":
+            cov = torch.empty((nt, ldvt), dtype=torch.float64, device=dev)
+            check(self._lib.ital_cov_block(_ptr(Xt), _ptr(xtn), nt, _ptr(Xt), _ptr(xtn), nt, self.ldx, _ptr(Vt), ldvt,
+                                           _ptr(Vt), ldvt, self.m, float(self.var), float(self.length_scale), _ptr(cov),
+                                           ldvt, _stream()))
+            return mean.cpu().numpy(), cov[:, :nt].cpu().numpy()
         return mean.cpu().numpy()

@@ -154,6 +154,7 @@ class MCMI_min(ActiveRetrievalBase):
             picked = b["ret"][:k].cpu().tolist()  # block positions; the only synchronisation of the round
         gp.check_status()
         ret = [int(cand[p]) for p in picked]
+        self._last_batch = (b, ret)
         gone = set(picked)
         self.candidates = [int(c) for p, c in enumerate(cand) if p not in gone]  # as `del self.candidates[min_ind]`
         return ret

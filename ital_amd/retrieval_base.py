@@ -37,26 +37,30 @@ class ActiveRetrievalBase(object):
         self.relevant_ids = set()
         self.irrelevant_ids = set()
         self.unnameable_ids = set()
-        self._rel_mean = None
+        self._last_batch = None
         self.gp.reset()
         if len(self.queries) > 0:
             n = len(self.data)
             self.gp.update_points(self.queries, [1] * len(self.queries), ind=list(range(n, n + len(self.queries))))
-            self._rel_mean_dirty = True
+            self._fitted = True
         else:
-            self._rel_mean_dirty = False
+            self._fitted = False
 
     @property
     def rel_mean(self):
-        """Predictive mean of every sample (numpy), refreshed lazily from the device after an update."""
-        if self._rel_mean_dirty:
-            self._rel_mean = self.gp.predict_stored()
-            self._rel_mean_dirty = False
-        return self._rel_mean
+        """Predictive mean of every sample (numpy; None before the first update, as reference retrieval_base.py:61).
+        gp.update() replicates the means on every rank's device (asynchronously, all ranks take part in update()); this
+        attribute only downloads that vector when somebody reads it -- a local operation, safe to read on one rank."""
+        return self.gp.mean_host() if self._fitted else None
 
     def top_results(self, k=None):
-        """reference retrieval_base.py:64-75"""
-        ind = np.argsort(self.rel_mean)[::-1]
+        """reference retrieval_base.py:64-75.  Up to ITAL_TOPK_MAX results are selected on the device (ital_topk, exact;
+        ties by descending index as the reversal of a stable ascending sort gives); the complete ranking (k = None) is
+        N-sized by definition and sorts the downloaded means on the host."""
+        from ._lib import ITAL_TOPK_MAX
+        if k is not None and self._fitted and 1 <= int(k) <= min(ITAL_TOPK_MAX, len(self.data)):
+            return self.gp.topk_mean(int(k))
+        ind = np.argsort(self.rel_mean, kind="stable")[::-1]
         return ind[:k] if k is not None else ind
 
     def get_unseen(self):
@@ -78,12 +82,21 @@ class ActiveRetrievalBase(object):
         """reference retrieval_base.py:105-126"""
         rel, irr, unnameable = self.partition_feedback(feedback)
         if len(rel) + len(irr) > 0:
-            self.gp.update(rel + irr, np.concatenate((np.ones(len(rel)), -1 * np.ones(len(irr)))))
-            self._rel_mean_dirty = True
+            self.gp.update(rel + irr, np.concatenate((np.ones(len(rel)), -1 * np.ones(len(irr)))),
+                           row_cache=self._batch_rows())
+            self._fitted = True
             self.relevant_ids.update(rel)
             self.irrelevant_ids.update(irr)
             self.rounds += 1
         self.unnameable_ids.update(unnameable)
+
+    def _batch_rows(self):
+        """Feature rows of the last fetched batch as kept (replicated) in the device batch state, or None."""
+        last = getattr(self, "_last_batch", None)
+        if not last:
+            return None
+        b, picks = last
+        return b["XB"], {int(i): slot for slot, i in enumerate(picks)}
 
     def updated_prediction(self, feedback, test_ind, cov_mode='full'):
         """Prediction after a simulated update with `feedback`, without performing it (reference

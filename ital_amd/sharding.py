@@ -11,6 +11,21 @@ def row_range(n_total, world, rank):
     return n_total * rank // world, n_total * (rank + 1) // world
 
 
+class ShardedRows(object):
+    """Stand-in for the n x d data matrix on a rank that holds only its own row block (the reference keeps the whole
+    matrix in every worker; at 1M x 512 x 8 ranks that is 32 GB of host memory for rows nobody reads).  `local` holds
+    rows [row0, row1) of an n_total x d matrix, (row0, row1) = row_range(n_total, world, rank)."""
+
+    def __init__(self, local, n_total, row0):
+        self.local = np.asarray(local, dtype=np.float64)
+        self.n_total, self.row0, self.row1 = int(n_total), int(row0), int(row0) + len(self.local)
+        self.shape = (self.n_total, self.local.shape[1])
+        self.ndim = 2
+
+    def __len__(self):
+        return self.n_total
+
+
 def shard_candidates(candidates, row0, row1):
     """Positions of the global candidate list that fall into this rank's rows.
 

@@ -52,13 +52,20 @@ def _worker(rank, world, port, name, out):
             ret = L.fetch_unlabelled(int(z["k"]))
             picks.append(ret)
             L.update({int(i): float(rel[i]) for i in ret})
-        out[rank] = (picks, np.asarray(L.rel_mean).copy(), (L.gp.row0, L.gp.row1))
+        top = None
+        if rank == 0:
+            # reading the means / the ranking on ONE rank only must not need the others (they are replicated by update())
+            top = (np.asarray(L.top_results(10)).tolist(), np.asarray(L.rel_mean).copy())
+        dist.barrier()
+        upd = L.updated_prediction({int(rel.argmax()): 1, int(rel.argmin()): -1}, [0, len(rel) // 2, len(rel) - 1])
+        out[rank] = (picks, np.asarray(L.rel_mean).copy(), (L.gp.row0, L.gp.row1), top, upd)
     finally:
         dist.destroy_process_group()
 
 
 @pytest.mark.parametrize("name", ["usps500", "synth96_k6", "synth300_mcmi", "usps500_mcmi", "emoc_synth150",
-                                  "entropy_synth80", "synth80_mcrel", "synth50_mcboth"])
+                                  "entropy_synth80", "synth80_mcrel", "synth50_mcboth", "synth200_topcand",
+                                  "synth200_noisy", "synth50_clip"])
 def test_two_ranks_match_golden(name):
     if not torch.cuda.is_available():
         pytest.skip("no GPU")
@@ -73,6 +80,58 @@ def test_two_ranks_match_golden(name):
     np.testing.assert_allclose(r0[1], z["final_rel_mean"], rtol=0, atol=1e-9)
     np.testing.assert_array_equal(r0[1], r1[1])
     assert r0[2][0] == 0 and r0[2][1] == r1[2][0] and r1[2][1] == len(z["X"])   # each rank held half of the rows
+    top10, mean0 = r0[3]
+    assert top10 == np.argsort(mean0, kind="stable")[::-1][:10].tolist()
+    if "top_results_10" in z:
+        assert top10 == z["top_results_10"].tolist()
+    # full covariance blocks across the shards: both ranks hold the same simulated update (reference retrieval_base.py:129-164)
+    np.testing.assert_array_equal(r0[4][0], r1[4][0])
+    np.testing.assert_array_equal(r0[4][1], r1[4][1])
+    assert r0[4][1].shape == (3, 3) and np.all(np.isfinite(r0[4][1]))
+
+
+def _dup_worker(rank, world, port, X, out):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    if world > 1:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from ital_amd import ITAL, mvn_stream
+        mvn_stream.GLOBAL.reset()
+        L = ITAL(X, length_scale=0.9, device="cuda:0", rank=rank, world=world,
+                 group=dist.group.WORLD if world > 1 else None)
+        L.keep_scores = True
+        L.update({58: 1, 59: -1})
+        picks = [L.fetch_unlabelled(4)]
+        L.update({i: 1.0 if X[i, 0] > 0.5 else -1.0 for i in picks[0]})
+        picks.append(L.fetch_unlabelled(3))
+        out[rank] = (picks, mvn_stream.GLOBAL.draws, int(L.gp.status.item()))
+    finally:
+        if world > 1:
+            dist.destroy_process_group()
+
+
+def test_duplicate_rows_on_different_shards_fall_back_on_every_rank():
+    """A batch that contains a sample and its exact copy makes the conditional covariance singular: only the rank that
+    scores the copy notices, but the fall-back to the general scorer (and its collectives) must be taken by all ranks.
+    The status word travels in the selection record; picks and stream position equal the single-rank run's."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    rng = np.random.default_rng(9)
+    X = rng.random((60, 5))
+    X[30:58] = X[0:28]     # every sample of rank 0's shard but two has an exact copy on rank 1: whatever is picked first,
+                           # its copy is scored against it from the third greedy step on
+    res = {}
+    for world in (1, 2):
+        port = _free_port()
+        with mp.Manager() as mgr:
+            out = mgr.dict()
+            mp.spawn(_dup_worker, args=(world, port, X, out), nprocs=world, join=True)
+            res[world] = dict(out)
+    assert res[2][0][0] == res[2][1][0] == res[1][0][0]
+    assert res[2][0][1] == res[2][1][1] == res[1][0][1]
+    assert res[2][0][2] == 0 and res[2][1][2] == 0      # the fall-back bits were cleared on both ranks
 
 
 def _nccl_worker(rank, world, port, name, out):
