@@ -6,12 +6,19 @@
 
 One "step" = one round of the reference's retrieval loop (run_experiment.py:160-164): fetch_unlabelled(k) on the
 current relevance model followed by update() with the simulated feedback for the fetched batch (the update is
-inside the timed region: nothing is skipped).  Workload (BASELINE.json configs[1], SURVEY.md section 8d C2'):
-synthetic USPS-shaped features, 9298 x 256 fp64 in [0,1], length_scale 3.0, k = 4, perfect user; with N > 1 every
-rank holds 9298 rows (weak scaling) and the greedy steps exchange one record per rank over RCCL.
-A scored candidate = one (candidate, greedy step) MI evaluation with full 2^t sign-pattern enumeration.
+inside the timed region: nothing is skipped).
+
+Headline (`value`): BASELINE.json configs[1], SURVEY.md section 8d C2': synthetic USPS-shaped features, 9298 x 256 fp64 in
+[0,1], length_scale 3.0, k = 4, perfect user; with N > 1 every rank holds 9298 rows (weak scaling) and the greedy steps
+exchange one record per rank over RCCL.  A scored candidate = one (candidate, greedy step) MI evaluation with full 2^t
+sign-pattern enumeration.
+
+Every line also carries `scaling_workload`: the curve north_star asks for -- 1 000 000 x 512, k = 4, full enumeration,
+the rows STRONG-scaled over the N ranks (each rank generates and holds only its own row block), timed the same way
+(barrier + synchronize on both sides, maximum over ranks), with the per-step record exchange priced separately.
 """
 import argparse
+import gc
 import json
 import os
 import sys
@@ -26,7 +33,9 @@ ROWS_PER_GPU = 9298
 DIM = 256
 BATCH = 4
 LENGTH_SCALE = 3.0
+SCALE_ROWS, SCALE_DIM, SCALE_BATCH = 1_000_000, 512, 4
 FP64_VALU_PEAK_TFLOPS = 78.6   # MI355X vector FP64 (= half the 157.3 TF FP32 vector rate of MI355X_MICROARCH.md)
+FP64_MFMA_PEAK_TFLOPS = 78.6   # MI355X matrix FP64 (MI355X_MICROARCH.md: same rate as the vector unit on gfx950)
 HBM_PEAK_GBS = 8000.0
 PRIMES = (31, 47, 73, 113, 173, 263, 397, 593, 907, 1361)
 # FP64 work of one (Phi, Phi^-1) pair of the lattice integrand in flops (FMA = 2, multiply / add = 1), counted in the ISA
@@ -35,11 +44,31 @@ PRIMES = (31, 47, 73, 113, 173, 263, 397, 593, 907, 1361)
 # 15 % of the arguments that need it.  The chain, not the kernel: bookkeeping the kernel adds is not achieved work.
 FLOP_PER_PAIR = 53 + 0.85 * 48 + 0.15 * 126
 VALU_PER_PAIR_CHAIN = 47 + 0.85 * 45 + 0.15 * 121      # vector instructions of the isolated chain per pair
+# flops of one term of the MCMI objective (Phi: 53, two logs: 2 x 44, products / sums: 6), counted the same way
+FLOP_PER_MCMI_TERM = 53 + 2 * 44 + 6
+# committed counter summaries (rocprofv3 --pmc passes of this very command, tools/profile_gpu.sh + tools/pmc_summary.py):
+# HBM traffic and instruction counts per launch are read from these files and the file is named in the output
+PMC_FILES = {"headline": "profiles/r2_pmc_summary.csv", "general": "profiles/r2_general_pmc_summary.csv",
+             "mcmi": "profiles/r2_mcmi_pmc_summary.csv"}
+CALIBRATION_FILE = "profiles/r2_oracle_calibration.json"
 
 
 def make_data(n, d, seed):
     rng = np.random.default_rng(seed)
     return rng.random((n, d))
+
+
+def block_rows(row0, row1, d, seed, block=65536):
+    """Rows [row0, row1) of the synthetic n x d matrix whose row block b (65536 rows) is default_rng([seed, b]).random():
+    every rank can generate exactly its own rows, whatever the number of ranks."""
+    out = np.empty((row1 - row0, d))
+    b = row0 // block
+    while b * block < row1:
+        lo, hi = max(row0, b * block), min(row1, (b + 1) * block)
+        blk = np.random.default_rng([seed, b]).random((block, d))
+        out[lo - row0:hi - row0] = blk[lo - b * block:hi - b * block]
+        b += 1
+    return out
 
 
 def qmc_pairs(t, n_cand):
@@ -91,9 +120,42 @@ def hbm_stream_probe(device, rows=1_000_000, d=DIM, m=21, reps=10):
             "note": "same kernel as the greedy steps' cross-covariance column, at 1M rows (2.2 GB per launch)"}
 
 
+def pmc_row(which, kernel_prefix):
+    """Row of a kernel in the committed PMC summary named by PMC_FILES[which] (collected with tools/profile_gpu.sh in
+    separate passes and corrected as MI355X_MICROARCH.md prescribes), or None."""
+    import csv
+    path = os.path.join(ROOT, PMC_FILES[which])
+    if not os.path.exists(path):
+        return None
+    with open(path, newline="") as f:
+        for row in csv.DictReader(f):
+            if row["kernel"].startswith(kernel_prefix):
+                return row
+    return None
+
+
+def pmc_fields(which, kernel_prefix, launch_s):
+    """traffic (HBM bytes per launch, fetch + write), share of the chip's vector-issue cycles the kernel's VALU instructions
+    fill (a wave64 instruction holds its SIMD's 16 lanes for 4 cycles; 256 CUs x 4 SIMDs at 2.4 GHz; count from the
+    committed pass, launch time live), and the name of the file both came from."""
+    row = pmc_row(which, kernel_prefix)
+    out = {"traffic": None, "valu_issue_frac": None, "pmc_file": PMC_FILES[which] if row else None}
+    if row:
+        try:
+            out["traffic"] = float(row["fetch_bytes_corrected_avg"]) + float(row["write_bytes_avg"])
+        except (KeyError, ValueError):
+            pass
+        try:
+            out["valu_issue_frac"] = float(row["SQ_INSTS_VALU_avg"]) * 4.0 / (1024 * 2.4e9 * launch_s)
+        except (KeyError, ValueError):
+            pass
+    return out
+
+
 def other_workloads(X, rel, device):
     """Secondary timings on the same synthetic data (rank 0, N = 1 only; not part of `value`): the general scorer with a
-    noisy user (reference configs usps-mistakes / mirflickr-mistakes style) and MCMI_min with the reference's subsample."""
+    noisy user (reference configs usps-mistakes / mirflickr-mistakes style) and MCMI_min with the reference's subsample,
+    each with the roofline of its dominant kernel."""
     import torch
     from ital_amd import ITAL, MCMI_min, mvn_stream
     out = {}
@@ -102,6 +164,8 @@ def other_workloads(X, rel, device):
         learner.update({0: 1})
         ret = learner.fetch_unlabelled(k)                 # warm-up round
         learner.update({int(i): float(rel[i]) for i in ret})
+        learner.profile = []
+        learner.event_pool = [torch.cuda.Event(enable_timing=True) for _ in range(32 * k * rounds)]
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         scored = 0
@@ -112,52 +176,62 @@ def other_workloads(X, rel, device):
             scored += sum(n_c - t for t in range(k))
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
-        return {"ms_per_round": dt / rounds * 1e3, "candidates_per_s": scored / dt}
+        prof = {}
+        for name, t, n_c, e0, e1 in learner.profile:
+            prof.setdefault((name, t), []).append((e0.elapsed_time(e1) * 1e-3, n_c))
+        return {"ms_per_round": dt / rounds * 1e3, "candidates_per_s": scored / dt}, prof
 
     mvn_stream.GLOBAL.reset()
-    out["ital_general_user_k4"] = dict(timed(ITAL(X, length_scale=LENGTH_SCALE, label_prob=0.5, mistake_prob=0.25,
-                                                  device=device), 2, BATCH),
+    L = ITAL(X, length_scale=LENGTH_SCALE, label_prob=0.5, mistake_prob=0.25, device=device)
+    L.pair_counter = torch.zeros(1, dtype=torch.int64, device=device)
+    res, prof = timed(L, 2, BATCH)
+    top = prof.get(("score_generic", BATCH), [])
+    roof = None
+    if top:
+        # pairs of the t = 4 launches: the counter runs over all steps; the closed forms of t <= 2 add none, t = 3 is
+        # priced by its own launches' share of the scorer time (same kernel, same rate)
+        sec4 = float(np.mean([d for d, _ in top]))
+        sec_all = sum(d for key, v in prof.items() if key[0] == "score_generic" and key[1] >= 3 for d, _ in v)
+        pairs_all = float(L.pair_counter.item())
+        rate = pairs_all / sec_all if sec_all > 0 else 0.0
+        ach = rate * FLOP_PER_PAIR / 1e12
+        roof = dict({"bound": "fp64-valu", "kernel": "score_generic_kernel", "achieved": ach, "peak": FP64_VALU_PEAK_TFLOPS,
+                     "unit": "TFLOP/s", "frac": ach / FP64_VALU_PEAK_TFLOPS, "avg_launch_ms": sec4 * 1e3,
+                     "pairs_per_s": rate, "pairs_counted_on_device": pairs_all,
+                     "note": "pairs = lattice points x (n - 1) of the calls the kernel really evaluates (counted by the "
+                             "kernel, ital_gscore_desc.pair_count: 240 of the 1296 calls per candidate at t = 4); "
+                             "the per-call preparation of the other 1056 is overhead by this measure"},
+                    **pmc_fields("general", "void ital::score_generic_kernel", sec4))
+    out["ital_general_user_k4"] = dict(res, roofline=roof,
                                        config="label_prob 0.5, mistake_prob 0.25: 3^t - 1 feedback configurations per pattern")
     np.random.seed(0)
     m = MCMI_min(X, length_scale=LENGTH_SCALE, subsample=1000, device=device)
-    r = timed(m, 5, BATCH)
+    r, prof = timed(m, 5, BATCH)
     r["candidates_per_s"] = BATCH * 1000 / (r["ms_per_round"] * 1e-3)
-    out["mcmi_min_subsample1000_k4"] = dict(r, config="MCMI_min, subsample 1000 (reference configs/usps.conf)")
+    roofs = {}
+    cb = prof.get(("cov_block", 0), [])
+    if cb:
+        sec = float(np.mean([d for d, _ in cb]))
+        nc = float(np.mean([c for _, c in cb]))
+        flops = 2.0 * nc * nc * (DIM + m.gp.m)
+        ach = flops / sec / 1e12
+        roofs["cov_block_kernel"] = dict({"bound": "mfma", "achieved": ach, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                                          "frac": ach / FP64_MFMA_PEAK_TFLOPS, "avg_launch_ms": sec * 1e3,
+                                          "note": "1000 x 1000 block: 0.55 GFLOP per launch, launch-latency bound at the "
+                                                  "reference's subsample; 42 TFLOP/s at 9273^2 (profiles/r1_mcmi_*)"},
+                                         **pmc_fields("mcmi", "ital::cov_block_kernel", sec))
+    ms = prof.get(("mcmi_score", BATCH), [])
+    if ms:
+        sec = float(np.mean([d for d, _ in ms]))
+        nc = float(np.mean([c for _, c in ms]))
+        terms = nc * nc * (2 ** BATCH)
+        ach = terms * FLOP_PER_MCMI_TERM / sec / 1e12
+        roofs["mcmi_score_kernel<%d>" % BATCH] = dict({"bound": "fp64-valu", "achieved": ach, "peak": FP64_VALU_PEAK_TFLOPS,
+                                                       "unit": "TFLOP/s", "frac": ach / FP64_VALU_PEAK_TFLOPS,
+                                                       "avg_launch_ms": sec * 1e3, "terms_per_s": terms / sec},
+                                                      **pmc_fields("mcmi", "void ital::mcmi_score_kernel<%d>" % BATCH, sec))
+    out["mcmi_min_subsample1000_k4"] = dict(r, roofline=roofs, config="MCMI_min, subsample 1000 (reference configs/usps.conf)")
     return out
-
-
-def pmc_row(kernel_prefix):
-    """Row of a kernel in the committed PMC summary (profiles/, collected with tools/profile_gpu.sh in separate passes and
-    corrected as MI355X_MICROARCH.md prescribes), or None."""
-    import csv
-    import glob
-    files = sorted(f for f in glob.glob(os.path.join(ROOT, "profiles", "*pmc_summary*.csv")) if "mcmi" not in f)
-    if not files:
-        return None
-    with open(files[-1], newline="") as f:
-        for row in csv.DictReader(f):
-            if row["kernel"].startswith(kernel_prefix):
-                return row
-    return None
-
-
-def pmc_traffic(kernel_prefix):
-    """HBM bytes per launch of a kernel (fetch + write), or None."""
-    row = pmc_row(kernel_prefix)
-    try:
-        return float(row["fetch_bytes_corrected_avg"]) + float(row["write_bytes_avg"])
-    except (TypeError, KeyError, ValueError):
-        return None
-
-
-def pmc_valu_issue_frac(kernel_prefix, launch_s):
-    """Share of the chip's vector-issue cycles the kernel's VALU instructions fill: a wave64 instruction holds its SIMD's
-    16 lanes for 4 cycles; 256 CUs x 4 SIMDs at 2.4 GHz.  Instruction count from the committed PMC pass, launch time live."""
-    row = pmc_row(kernel_prefix)
-    try:
-        return float(row["SQ_INSTS_VALU_avg"]) * 4.0 / (1024 * 2.4e9 * launch_s)
-    except (TypeError, KeyError, ValueError):
-        return None
 
 
 def cpu_baseline(X, cores):
@@ -170,9 +244,86 @@ def cpu_baseline(X, cores):
     t0 = time.time()
     _, scored = fetch_unlabelled_parallel(learner, BATCH, processes=cores)
     dt = time.time() - t0
-    return {"value": scored / dt, "unit": "candidates/s", "cores": cores, "kind": "port",
-            "sample": "one fetch_unlabelled(%d) round on the first %d rows of the workload (%d scored candidates, "
-                      "%.1f s), fork pool per greedy step as reference ital/ital.py:124-126" % (BATCH, n, scored, dt)}
+    out = {"value": scored / dt, "unit": "candidates/s", "cores": cores, "kind": "port",
+           "sample": "one fetch_unlabelled(%d) round on the first %d rows of the workload (%d scored candidates, "
+                     "%.1f s), fork pool per greedy step as reference ital/ital.py:124-126" % (BATCH, n, scored, dt)}
+    path = os.path.join(ROOT, CALIBRATION_FILE)
+    if os.path.exists(path):
+        with open(path) as f:
+            cal = json.load(f)
+        out["calibration"] = {"oracle_over_reference_time": cal["oracle_over_reference"], "file": CALIBRATION_FILE,
+                              "note": "oracle vs the real reference on identical inputs in the build container (%s): "
+                                      "the port is a fair stand-in for the reference, which cannot run on the GPU box"
+                                      % cal["workload"]}
+    return out
+
+
+def scaling_workload(device, rank, world, group, rounds=3):
+    """north_star's scaling curve: n = 1M synthetic, d = 512, k = 4 with full enumeration, rows split over the ranks."""
+    import torch
+    from ital_amd import ITAL, mvn_stream, sharding
+    n, d, k = SCALE_ROWS, SCALE_DIM, SCALE_BATCH
+    row0, row1 = sharding.row_range(n, world, rank)
+    local = block_rows(row0, row1, d, seed=1)
+    data = sharding.ShardedRows(local, n, row0)
+    mvn_stream.GLOBAL.reset()
+    L = ITAL(data, length_scale=float(np.sqrt(d / 12.0)), device=device, rank=rank, world=world, group=group)
+    del local
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            import torch.distributed as dist
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    def label(i):
+        # the simulated perfect user's answer for sample i: any fixed function of the sample will do (every rank must
+        # give the same one without holding the sample's features); a multiplicative hash of the index
+        return 1.0 if (i * 2654435761) % (1 << 32) < (1 << 31) else -1.0
+
+    def one_round():
+        ret = L.fetch_unlabelled(k)
+        L.update({int(i): label(int(i)) for i in ret})
+        return ret
+
+    L.update({0: 1})
+    one_round()                                            # warm-up
+    L.profile = []
+    L.event_pool = [torch.cuda.Event(enable_timing=True) for _ in range(16 * k * rounds)]
+    scored = 0
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(rounds):
+        n_cand = n - len(L.relevant_ids) - len(L.irrelevant_ids)
+        one_round()
+        scored += sum(n_cand - t for t in range(k))
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        import torch.distributed as dist
+        tt = torch.tensor([dt], dtype=torch.float64, device=device)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+    prof = {}
+    for name, t, n_c, e0, e1 in L.profile:
+        prof.setdefault((name, t), []).append(e0.elapsed_time(e1))
+    ex = [v for key, vs in prof.items() if key[0] == "exchange" for v in vs]
+    backend = None
+    if world > 1:
+        import torch.distributed as dist
+        backend = dist.get_backend(group)
+    mem = torch.cuda.max_memory_allocated(device) / 2 ** 30
+    del L
+    gc.collect()
+    torch.cuda.empty_cache()
+    return {"workload": "synthetic %d x %d, k=%d, perfect user, full 2^t enumeration, fetch_unlabelled + update per round"
+                        % (n, d, k), "scaling": "strong", "rows_per_rank": row1 - row0, "world_size": world,
+            "backend": backend, "rounds": rounds, "ms_per_round": dt / rounds * 1e3, "candidates_per_s": scored / dt,
+            "exchange_ms_per_greedy_step": float(np.mean(ex)) if ex else None,
+            "kernel_ms": {"%s_t%d" % key: float(np.mean(v)) for key, v in sorted(prof.items())},
+            "peak_device_memory_gib": mem,
+            "note": "per-step exchange = all_gather_into_tensor of one record per rank (null on one rank: no collective)"}
 
 
 def main():
@@ -181,6 +332,7 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-scaling-workload", action="store_true", help="skip the 1M x 512 strong-scaling record")
     ap.add_argument("--rows", type=int, default=9298, help="rows per GPU (experiments; the default is the metric's workload)")
     ap.add_argument("--batch", type=int, default=4, help="batch size k (experiments)")
     ap.add_argument("--label-prob", type=float, default=1.0, help="user model (experiments; != 1 selects the general scorer)")
@@ -244,7 +396,12 @@ def main():
     restart()
     learner.profile = None if os.environ.get("ITAL_BENCH_NO_EVENTS") else []
     # timing events are created before the timed region (only recorded inside it)
-    learner.event_pool = [torch.cuda.Event(enable_timing=True) for _ in range(4 * (2 * BATCH) * args.steps)]
+    learner.event_pool = [torch.cuda.Event(enable_timing=True) for _ in range(8 * (2 * BATCH) * args.steps)]
+    # a serving process freezes its start-up heap: without this CPython's generation-2 collector walks torch's ~10^5
+    # objects once every few rounds (a 40 ms pause, measured: ten 3.4 ms rounds cost 73 ms), which has nothing to do with
+    # the path under test
+    gc.collect()
+    gc.freeze()
     scored = 0
     barrier()
     t0 = time.perf_counter()
@@ -264,32 +421,41 @@ def main():
     prof = {}
     for name, t, n_c, e0, e1 in (learner.profile or []):
         prof.setdefault((name, t), []).append((e0.elapsed_time(e1) * 1e-3, n_c))
+    learner.profile = None
+    scale = None
+    if not args.no_scaling_workload:
+        del learner
+        gc.collect()
+        torch.cuda.empty_cache()
+        scale = scaling_workload(device, rank, world, group)
     out = None
     if rank == 0:
-        qm = prof.get(("score", BATCH), [])
+        qm = prof.get(("qmc_main", BATCH), [])
         roof = None
         if qm:
             avg_s = float(np.mean([d for d, _ in qm]))
             avg_c = float(np.mean([c for _, c in qm]))
             flops = qmc_pairs(BATCH, avg_c) * FLOP_PER_PAIR
             ach = flops / avg_s / 1e12
-            roof = {"bound": "fp64-valu", "kernel": "score_qmc_kernel<%d>" % BATCH, "achieved": ach,
-                    "peak": FP64_VALU_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach / FP64_VALU_PEAK_TFLOPS,
-                    "traffic": pmc_traffic("void ital::score_qmc_kernel<%d>" % BATCH), "avg_launch_ms": avg_s * 1e3,
-                    "pairs_per_s": qmc_pairs(BATCH, avg_c) / avg_s,
-                    "flop_per_pair": FLOP_PER_PAIR, "valu_per_pair_isolated_chain": VALU_PER_PAIR_CHAIN,
-                    "valu_issue_frac": pmc_valu_issue_frac("void ital::score_qmc_kernel<%d>" % BATCH, avg_s),
-                    "note": "transcendental FP64 chains (Phi, Phi^-1): neither HBM nor MFMA bounds this kernel "
-                            "(SURVEY.md 8d S-qmc), so the peak is the FP64 vector rate; achieved = algorithmic pairs x "
-                            "flops of the isolated chain / launch time.  Only ~55 % of the chain's instructions are "
-                            "FMAs, so the flop fraction understates how busy the vector unit is: valu_issue_frac is "
-                            "the share of its issue slots the kernel fills.  HBM-bound streaming kernel in roofline_hbm"}
+            kname = "void ital::qmc_main_kernel<%d>" % BATCH
+            roof = dict({"bound": "fp64-valu", "kernel": "qmc_main_kernel<%d>" % BATCH, "achieved": ach,
+                         "peak": FP64_VALU_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach / FP64_VALU_PEAK_TFLOPS,
+                         "avg_launch_ms": avg_s * 1e3, "pairs_per_s": qmc_pairs(BATCH, avg_c) / avg_s,
+                         "flop_per_pair": FLOP_PER_PAIR, "valu_per_pair_isolated_chain": VALU_PER_PAIR_CHAIN,
+                         "algorithmic_pairs_per_launch": qmc_pairs(BATCH, avg_c),
+                         "note": "transcendental FP64 chains (Phi, Phi^-1): neither HBM nor MFMA bounds this kernel "
+                                 "(SURVEY.md 8d S-qmc), so the peak is the FP64 vector rate; achieved = algorithmic pairs x "
+                                 "flops of the isolated chain / launch time (HIP events the library records around this "
+                                 "kernel alone).  Only ~55 % of the chain's instructions are FMAs, so the flop fraction "
+                                 "understates how busy the vector unit is: valu_issue_frac is the share of its issue slots "
+                                 "the kernel fills.  HBM-bound streaming kernel in roofline_hbm"},
+                        **pmc_fields("headline", kname, avg_s))
         cc = prof.get(("cross_cov", 1), []) + prof.get(("cross_cov", 2), []) + prof.get(("cross_cov", 3), [])
         roof_hbm = None
         if cc:
             avg_s = float(np.mean([d for d, _ in cc]))
             m_avg = float(np.mean([c for _, c in cc]))
-            bytes_alg = learner.gp.n * 8.0 * (DIM + m_avg + 1)
+            bytes_alg = ROWS_PER_GPU * 8.0 * (DIM + m_avg + 1)
             ach = bytes_alg / avg_s / 1e9
             roof_hbm = {"bound": "hbm", "kernel": "kcols_kernel (cross-covariance column)", "achieved": ach,
                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": None,
@@ -305,7 +471,8 @@ def main():
                           "parallelism": "candidate rows sharded over %d GPU(s), 1 record all-gather per greedy step" % world},
                "roofline": roof, "roofline_hbm": hbm_stream_probe(device) if world == 1 else roof_hbm,
                "roofline_hbm_at_workload_size": roof_hbm,
-               "kernel_ms": {"%s_t%d" % k: float(np.mean([d for d, _ in v])) * 1e3 for k, v in sorted(prof.items())}}
+               "kernel_ms": {"%s_t%d" % k: float(np.mean([d for d, _ in v])) * 1e3 for k, v in sorted(prof.items())},
+               "scaling_workload": scale}
         if world == 1 and not os.environ.get("ITAL_BENCH_NO_EXTRAS"):
             out["other_workloads"] = other_workloads(X, rel, device)
         out["cpu_baseline"] = cpu_base

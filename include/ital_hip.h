@@ -133,6 +133,8 @@ typedef struct ital_score_desc {
      * lattices of every evaluated call -- 0.5 to 1 KB per call) */
     double* work;
     int64_t work_doubles;
+    void* ev_start;         /* optional hipEvent_t pair recorded on the stream right before / after the lattice-sum kernel */
+    void* ev_stop;          /* (the FP64-VALU bound kernel of the step; with several slabs: the last one) */
 } ital_score_desc;
 
 /* Scores every live candidate position: mi[p] = MI(batch + candidate p).
@@ -264,6 +266,8 @@ typedef struct ital_gscore_desc {
                                ([n_cand]; with clip_cov the count depends on the data) and scores nothing */
     double* mi;             /* [n_cand] out */
     int* status;
+    unsigned long long* pair_count; /* non-NULL: += the (Phi, Phi^-1) pairs of the lattice sums that were evaluated
+                               (16 P(n-1) points x (n-1) pairs per evaluated call; instrumentation for the roofline) */
 } ital_gscore_desc;
 
 /* mi[p] = MI(batch + candidate p) for any user model / with a change-estimation subset.  Replaces

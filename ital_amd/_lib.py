@@ -30,7 +30,8 @@ class ItalScoreDesc(ctypes.Structure):
                 ("s2", c_void_p), ("C", c_void_p), ("ldc", c_int64), ("row_offset", c_int64),
                 ("pos_offset", c_int64), ("gpos", c_void_p), ("batch", ItalBatch), ("noise", c_double), ("eps", c_double),
                 ("label_mode", c_int), ("mi", c_void_p), ("seed", c_int * 6), ("jump", c_void_p), ("jumppat", c_void_p),
-                ("vk", c_void_p), ("status", c_void_p), ("work", c_void_p), ("work_doubles", c_int64)]
+                ("vk", c_void_p), ("status", c_void_p), ("work", c_void_p), ("work_doubles", c_int64), ("ev_start", c_void_p),
+                ("ev_stop", c_void_p)]
 
 
 class ItalGscoreDesc(ctypes.Structure):
@@ -43,7 +44,7 @@ class ItalGscoreDesc(ctypes.Structure):
                 ("draws_out", c_int64), ("draws_in", c_int64), ("n_in", c_int), ("in_pos", c_void_p),
                 ("n_dead", c_int), ("dead_pos", c_void_p), ("mc_rel", c_int), ("rel_samples", c_void_p),
                 ("mc_fb", c_int), ("fb_samples", c_void_p), ("draw_off", c_void_p), ("draw_count", c_void_p), ("mi", c_void_p),
-                ("status", c_void_p)]
+                ("status", c_void_p), ("pair_count", c_void_p)]
 
 
 class ItalMcmiDesc(ctypes.Structure):

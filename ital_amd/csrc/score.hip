@@ -490,7 +490,7 @@ __global__ __launch_bounds__(256) void qmc_combine_kernel(const double* __restri
 }
 
 template <int T>
-static int launch_qmc(const ScoreArgs& a, double* work, int64_t work_doubles, hipStream_t stream) {
+static int launch_qmc(const ScoreArgs& a, double* work, int64_t work_doubles, hipEvent_t ev0, hipEvent_t ev1, hipStream_t stream) {
     using Q = Qmc<T>;
     int64_t slab = work_doubles / Q::CAND_DOUBLES;
     if (slab < 1) return ital_fail(-12, "ital_score_step: workspace smaller than one candidate (see ital_score_workspace)");
@@ -512,8 +512,10 @@ static int launch_qmc(const ScoreArgs& a, double* work, int64_t work_doubles, hi
         hipLaunchKernelGGL(qmc_seed_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, a, Q::NCALLS, lo, n, seeds);
         hipLaunchKernelGGL(qmc_prep_kernel<T>, dim3((unsigned)((n + Q::PREP_THREADS - 1) / Q::PREP_THREADS), Q::NPAT),
                            dim3(Q::PREP_THREADS), lds_prep, stream, a, lo, n, seeds, recs);
+        if (ev0) (void)hipEventRecord(ev0, stream);
         hipLaunchKernelGGL(qmc_main_kernel<T>, dim3((unsigned)((n * Q::NPAT + 3) / 4)), dim3(256), lds_main, stream, a.alive, lo,
                            n, recs, a.eps, a.label_mode, terms);
+        if (ev1) (void)hipEventRecord(ev1, stream);
         hipLaunchKernelGGL(qmc_combine_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, terms, a.alive, lo, n,
                            Q::NPAT, a.label_mode, a.mi);
         int rc = ital_check_launch("ital_score_step(qmc)");
@@ -567,13 +569,14 @@ extern "C" int ital_score_step(const ital_score_desc* d, hipStream_t stream) {
     }
     if (!d->jump || !d->jumppat || !d->vk) return ital_fail(-22, "ital_score_step: jump tables / generators missing for t >= 3");
     if (!d->work) return ital_fail(-22, "ital_score_step: workspace missing for t >= 3 (see ital_score_workspace)");
+    hipEvent_t ev0 = static_cast<hipEvent_t>(d->ev_start), ev1 = static_cast<hipEvent_t>(d->ev_stop);
     switch (d->t) {
-        case 3: return launch_qmc<3>(a, d->work, d->work_doubles, stream);
-        case 4: return launch_qmc<4>(a, d->work, d->work_doubles, stream);
-        case 5: return launch_qmc<5>(a, d->work, d->work_doubles, stream);
-        case 6: return launch_qmc<6>(a, d->work, d->work_doubles, stream);
-        case 7: return launch_qmc<7>(a, d->work, d->work_doubles, stream);
-        case 8: return launch_qmc<8>(a, d->work, d->work_doubles, stream);
+        case 3: return launch_qmc<3>(a, d->work, d->work_doubles, ev0, ev1, stream);
+        case 4: return launch_qmc<4>(a, d->work, d->work_doubles, ev0, ev1, stream);
+        case 5: return launch_qmc<5>(a, d->work, d->work_doubles, ev0, ev1, stream);
+        case 6: return launch_qmc<6>(a, d->work, d->work_doubles, ev0, ev1, stream);
+        case 7: return launch_qmc<7>(a, d->work, d->work_doubles, ev0, ev1, stream);
+        case 8: return launch_qmc<8>(a, d->work, d->work_doubles, ev0, ev1, stream);
     }
     return ital_fail(-22, "ital_score_step: unsupported batch dimension");
 }

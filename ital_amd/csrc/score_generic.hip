@@ -769,6 +769,7 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(ITAL_GEN_WA
     const bool clamp_prior = !subset && nr == 1;   // first greedy step: predict_stored(cov_mode='diag') (ital.py:558)
 
     double mi = 0.0, pr_cur = 0.0, logpr_cur = 0.0;
+    unsigned long long pairs = 0;   // (Phi, Phi^-1) pairs of the lattice sums this wave evaluates (bench.py roofline)
     int64_t cand_draws = 0;     // uniforms this candidate's calls consume (reported by the counting pass)
     for (int chunk0 = 0; chunk0 < total; chunk0 += a.chunk) {
         // ---------------- Phase B: lane l prepares call chunk0 + l
@@ -838,6 +839,7 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(ITAL_GEN_WA
                         const unsigned closes_c = (unsigned)__builtin_amdgcn_readlane((int)gp.closes, cl);
                         const double* slab_c = slabs + (size_t)cl * a.stride;
                         const double v = qmc_eval<NMAX, NH>(n_c, slab_c, infi_c, closes_c, slab_c + a.lat, lane, tailq);
+                        pairs += 16ull * P_TAB[(n_c - 1 < 10 ? n_c - 1 : 10) - 1] * (n_c - 1);
                         if (lane == cl) gval = v;
                     }
                     if (!(gp.flags & 64)) gprod *= gval;
@@ -871,6 +873,7 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(ITAL_GEN_WA
                     value = qmc_eval_fixed<(TFIX > 0 ? TFIX : 3)>(slab_c, infi_c, slab_c + a.lat, lane, tailq);
                 else
                     value = qmc_eval<NMAX, NH>(n_c, slab_c, infi_c, closes_c, slab_c + a.lat, lane, tailq);
+                pairs += 16ull * P_TAB[(n_c - 1 < 10 ? n_c - 1 : 10) - 1] * (n_c - 1);
             }
             const CallInfo ci = decode_call(d, p, chunk0 + cl, cpp, npre, nr, npat);
             if (entropy) {
@@ -910,6 +913,7 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(ITAL_GEN_WA
     if (d.mc_rel > 0) mi /= d.mc_rel;   // ital.py:221-222
     if (entropy) mi = -mi;
     if (lane == 0) d.mi[p] = mi;
+    if (lane == 0 && d.pair_count) atomicAdd(d.pair_count, pairs);
 }
 
 }  // namespace ital

@@ -62,6 +62,7 @@ class ITAL(ActiveRetrievalBase):
         self._ce_subset = None
         self.qmc_work_bytes = int(os.environ.get("ITAL_QMC_WORK_BYTES", 1 << 30))   # cap of the lattice scorer's workspace
         self._last_batch = None  # (batch buffers, picks) of the last fast-path round: update() reuses the winners' rows
+        self.pair_counter = None  # optional int64 device tensor [1]: the general scorer adds its evaluated (Phi, Phi^-1) pairs
         self.event_pool = []     # pre-created timing events (bench.py)
         self.profile = None      # list to receive (stage, t, size, start_event, end_event) per launch (bench.py)
         self._fetch_bufs = None
@@ -263,6 +264,12 @@ class ITAL(ActiveRetrievalBase):
                         desc.seed[j] = stream.state[j]
                     work = self._qmc_workspace(b, t, n_loc)
                     desc.work, desc.work_doubles = _ptr(work), work.numel()
+                    if self.profile is not None:
+                        # the lattice-sum kernel alone, bracketed by events the library records on the launch stream
+                        # (an event has to be recorded once before its handle exists)
+                        k0, k1 = self._mark(), self._mark()
+                        desc.ev_start, desc.ev_stop = k0.cuda_event, k1.cuda_event
+                        self.profile.append(("qmc_main", t, n_alive, k0, k1))
                 ev0 = self._mark()
                 check(lib.ital_score_step(ctypes.byref(desc), st))
                 self._mark("score", t, n_alive, ev0)
@@ -278,7 +285,9 @@ class ITAL(ActiveRetrievalBase):
                                                 gp.rank, 0, _ptr(gp.mu), _ptr(gp.s2), _ptr(gp.Xd), _ptr(gp.xnorm), gp.ldx,
                                                 _ptr(gp.V), gp.ldv, gp.m, gp.cap, _ptr(b["C"]), gp.ldv, t - 1, b["kmax"],
                                                 _ptr(gp.status), _ptr(b["work"]), _ptr(b["rec"]), st))
+                    ev0 = self._mark()
                     recs = sharding.gather_records(b["rec"], b["rec_all"], gp.group) if gp.collective else b["rec"]
+                    self._mark("exchange", t, gp.world, ev0)
                     check(lib.ital_select_resolve(_ptr(recs), gp.world, b["rec_len"], gp.rank, 0, t - 1, b["batch"],
                                                   _ptr(alive), _ptr(b["ret"]), st))
                 if t < k:
@@ -430,6 +439,7 @@ class ITAL(ActiveRetrievalBase):
                 desc.jump1, desc.vk = _ptr(jump1), _ptr(vk)
                 desc.draws_out, desc.draws_in = draws_out, draws_in
                 desc.mi, desc.status = _ptr(mi), _ptr(gp.status)
+                desc.pair_count = _ptr(self.pair_counter)
                 total_draws = None
                 if mc is not None:
                     rel_arr, fb_arr, draws_pp = mc          # per list position (dead positions hold zeros)

@@ -42,11 +42,12 @@ class MCMI_min(ActiveRetrievalBase):
         self.keep_scores = False
         self.last_scores = None
         self.profile = None
+        self.event_pool = []
 
     def _mark(self, stage=None, t=0, size=0, start=None):
         if self.profile is None:
             return None
-        ev = torch.cuda.Event(enable_timing=True)
+        ev = self.event_pool.pop() if self.event_pool else torch.cuda.Event(enable_timing=True)
         ev.record()
         if start is not None:
             self.profile.append((stage, t, size, start, ev))

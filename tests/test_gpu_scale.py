@@ -1,0 +1,259 @@
+"""Parity at the sizes BASELINE.json names (SURVEY.md section 8d C3' - C5'), where the dense oracle cannot hold the
+N x N kernel: per greedy step a sample of candidates is re-scored by the oracle on the SUB-PROBLEM made of the labelled
+samples, the batch and the sampled candidates (a GP posterior at a point depends on nothing else), with the oracle's
+mvndst stream placed at the offset the reference's serial loop would have reached for that (step, candidate) -- and, for
+the Monte-Carlo switch, numpy's generator walked to the candidate's normals.  Plus the size-independent properties:
+picks are unseen and distinct, the stream position is a function of the work done, a repeated run gives the same picks.
+
+Runtime budget on the GPU box (one MI355X, 16 host cores): C3' ~15 s, C4' ~25 s, C5' k=4 ~25 s, C5' share k=16 ~70 s.
+"""
+import os
+import sys
+import time
+from concurrent.futures import ProcessPoolExecutor
+import multiprocessing as mp
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+torch = pytest.importorskip("torch")
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def dev():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    return "cuda:0"
+
+
+# ---------------------------------------------------------------------------------------------- oracle side (CPU workers)
+def _oracle_scores(job):
+    """Runs in a spawned worker (no GPU): MI of the sampled candidates of a sub-problem.  job: dict with the sub-matrix
+    Xs (rows in ascending data-index order), length_scale, learner kwargs, labelled [(sub index, y)], picks (sub indices,
+    selection order) and tasks [(t, sub index, mvndst state (6 ints), normals to skip from the seed or None)] sorted by
+    (t, stream order)."""
+    sys.path.insert(0, job["root"])
+    os.environ.update(OMP_NUM_THREADS="1", OPENBLAS_NUM_THREADS="1", MKL_NUM_THREADS="1")
+    from oracle import mvn as omvn
+    from oracle.ital import OracleITAL, _Appended
+    L = OracleITAL(job["Xs"], length_scale=job["ls"], **job["kw"])
+    L.update({int(i): float(y) for i, y in job["labelled"]})
+    L._ce_subset = None
+    state = _Appended(L)
+    out = []
+    t_now = 1
+    consumed = 0
+    if job["seed"] is not None:
+        np.random.seed(job["seed"])
+    for t, i, rng_state, skip in job["tasks"]:
+        while t_now < t:
+            state.append(int(job["picks"][t_now - 1]))
+            t_now += 1
+        if skip is not None:
+            todo = skip - consumed
+            assert todo >= 0
+            while todo > 0:
+                c = min(todo, 1 << 24)
+                np.random.standard_normal(c)
+                todo -= c
+            consumed = skip
+        omvn.rng_set_state(rng_state)
+        before = omvn.rng_draws()
+        val = state.score(int(i))
+        if skip is not None:
+            consumed += job["normals_per_cand"][t]
+        out.append((t, int(i), float(val), omvn.rng_draws() - before))
+    return out
+
+
+def _check_against_sub_oracle(X, ls, L, picks, cand0, scores, samples, kw, stream0, draws_per_cand, seed=None,
+                              normals_per_cand=None, workers=8, rtol=1e-8, allow_mismatch=0):
+    """samples: {t: list positions in the ORIGINAL candidate list (live at step t)}.  draws_per_cand(t): uniforms of the
+    mvndst stream one candidate consumes at step t.  normals_per_cand(t): standard normals of numpy's generator per
+    candidate (Monte-Carlo pattern sampling; 0 where the step enumerates)."""
+    from ital_amd import mvn_stream
+    n_cand = len(cand0)
+    k = len(picks)
+    pos_of = {int(c): p for p, c in enumerate(cand0)}
+    pick_pos = [pos_of[int(p)] for p in picks]
+    labelled = list(zip(L.gp.ind, L.gp.y.tolist()))
+    ids = sorted(set(int(i) for i, _ in labelled) | set(int(p) for p in picks)
+                 | set(int(cand0[p]) for ps in samples.values() for p in ps))
+    sub = {g: s for s, g in enumerate(ids)}
+    Xs = X[np.asarray(ids)]
+    # stream state at the start of every step, and of every sampled candidate
+    stream = mvn_stream.MvnStream()
+    stream.state, stream.draws = stream0
+    tasks = []
+    normals_before_step = 0
+    for t in range(1, k + 1):
+        dead = sorted(pick_pos[: t - 1])
+        n_alive = n_cand - (t - 1)
+        dpc = draws_per_cand(t)
+        npc = normals_per_cand(t) if normals_per_cand else 0
+        for p in sorted(samples.get(t, [])):
+            rank = p - int(np.searchsorted(dead, p))
+            st = stream.peek(rank * dpc)
+            skip = normals_before_step + rank * npc if normals_per_cand else None
+            tasks.append((t, sub[int(cand0[p])], tuple(int(v) for v in st), skip, p))
+        stream.advance(n_alive * dpc)
+        normals_before_step += n_alive * npc
+    # cut the task list into contiguous slices of about equal cost (each worker walks numpy's stream forward once); a
+    # task of step t costs ~ calls x lattice points x dimension
+    primes = (31, 47, 73, 113, 173, 263, 397, 593, 907, 1361)
+    cost = np.array([draws_per_cand(tk[0]) * primes[min(max(tk[0] - 1, 1), 10) - 1] * tk[0] + 1000.0 for tk in tasks])
+    workers = max(1, min(workers, len(tasks)))
+    acc = np.cumsum(cost)
+    cuts = [0] + [int(np.searchsorted(acc, acc[-1] * w / workers)) for w in range(1, workers)] + [len(tasks)]
+    cuts = np.maximum.accumulate(np.asarray(cuts))
+    jobs = []
+    for a, b in zip(cuts[:-1], cuts[1:]):
+        if b > a:
+            jobs.append(dict(root=ROOT, Xs=Xs, ls=ls, kw=kw, labelled=[(sub[int(i)], y) for i, y in labelled],
+                             picks=[sub[int(p)] for p in picks], tasks=[tk[:4] for tk in tasks[a:b]], seed=seed,
+                             normals_per_cand={t: (normals_per_cand(t) if normals_per_cand else 0) for t in range(1, k + 1)}))
+    with ProcessPoolExecutor(max_workers=len(jobs), mp_context=mp.get_context("spawn")) as pool:
+        results = [r for part in pool.map(_oracle_scores, jobs) for r in part]
+    assert len(results) == len(tasks)
+    bad = []
+    for (t, si, val, drawn), tk in zip(results, tasks):
+        p = tk[4]
+        mine = scores[t - 1][p]
+        assert drawn == draws_per_cand(t), (t, p, drawn)      # the oracle consumed what the offsets assume
+        if not np.isclose(mine, val, rtol=rtol, atol=1e-12):
+            bad.append((t, p, mine, val))
+    assert len(bad) <= allow_mismatch, bad[:5]
+    return len(tasks), bad
+
+
+def _sample_positions(rng, n_cand, pick_pos, k, per_step):
+    """Per step: the winner, its runner-up in list order and a random sample of live positions."""
+    samples = {}
+    for t in range(1, k + 1):
+        dead = set(pick_pos[: t - 1])
+        want = per_step(t)
+        pool = rng.choice(n_cand, size=min(n_cand, want + k), replace=False).tolist()
+        chosen = [p for p in pool if p not in dead][:want]
+        chosen.append(pick_pos[t - 1])
+        samples[t] = sorted(set(chosen))
+    return samples
+
+
+def _full_enumeration_case(dev, n, d, k, per_step, seed=0, repeat=True, workers=8):
+    from ital_amd import ITAL, mvn_stream
+    rng = np.random.default_rng(seed)
+    X = rng.random((n, d))
+    ls = float(np.sqrt(d / 12.0))
+    mvn_stream.GLOBAL.reset()
+    L = ITAL(X, length_scale=ls, device=dev)
+    L.keep_scores = True
+    L.update({0: 1, 1: -1, 2: 1})
+    cand0 = np.asarray(L.get_unseen())
+    stream0 = (mvn_stream.GLOBAL.state, mvn_stream.GLOBAL.draws)
+    t0 = time.perf_counter()
+    picks = L.fetch_unlabelled(k)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    scores = [s.cpu().numpy() for s in L.last_scores]
+    # ---- properties
+    assert len(set(picks)) == k and not (set(picks) & {0, 1, 2})
+    n_cand = len(cand0)
+    want_draws = sum((n_cand - (t - 1)) * (2 << t) * mvn_stream.draws_per_call(t) for t in range(1, k + 1))
+    assert mvn_stream.GLOBAL.draws - stream0[1] == want_draws
+    pos_of = {int(c): p for p, c in enumerate(cand0)}
+    pick_pos = [pos_of[int(p)] for p in picks]
+    for t in range(k):
+        live = np.ones(n_cand, dtype=bool)
+        live[pick_pos[:t]] = False
+        s = scores[t]
+        assert np.all(np.isfinite(s[live]))
+        assert pick_pos[t] == int(np.flatnonzero(live)[np.argmax(s[live])])          # first maximum among the live ones
+        assert np.all(s[live] <= (t + 1) * np.log(2) + 1e-9) and np.all(s[live] > -1e-6)   # MI <= joint sign entropy
+    if repeat:
+        mvn_stream.GLOBAL.state, mvn_stream.GLOBAL.draws = stream0
+        assert L.fetch_unlabelled(k) == picks                                          # same stream position, same picks
+    # ---- sampled oracle check at the replayed offsets
+    samples = _sample_positions(np.random.default_rng(seed + 1), n_cand, pick_pos, k, per_step)
+    ntask, _ = _check_against_sub_oracle(X, ls, L, picks, cand0, scores, samples, {}, stream0,
+                                         lambda t: (2 << t) * mvn_stream.draws_per_call(t), workers=workers)
+    return dt, ntask
+
+
+def test_c3_mirflickr_shaped_25000x512_k8(dev):
+    """BASELINE configs[2] shape: 25 000 x 512, batch of 8, full enumeration (t = 8: 2^8 patterns x 2 orthant calls)."""
+    dt, ntask = _full_enumeration_case(dev, 25_000, 512, 8, lambda t: 64 if t <= 5 else (32 if t == 6 else 16))
+    print("C3': fetch_unlabelled(8) on 25000 x 512: %.2f s, %d oracle evaluations" % (dt, ntask))
+
+
+def test_c4_imagenet_shaped_50000x2048_k8(dev):
+    """BASELINE configs[3] shape: ~50 000 x 2048, batch of 8, the whole set on one GPU."""
+    dt, ntask = _full_enumeration_case(dev, 50_000, 2048, 8, lambda t: 64 if t <= 5 else (32 if t == 6 else 16),
+                                       seed=3, repeat=False)
+    print("C4': fetch_unlabelled(8) on 50000 x 2048: %.2f s, %d oracle evaluations" % (dt, ntask))
+
+
+def test_c5_one_million_x512_k4_full_enumeration(dev):
+    """BASELINE configs[4], the k = 4 full-enumeration run of the scaling curve: 1 000 000 x 512 on one GPU (the lattice
+    scorer walks the candidates in slabs of its 1 GiB workspace)."""
+    dt, ntask = _full_enumeration_case(dev, 1_000_000, 512, 4, lambda t: 64, seed=5, repeat=False)
+    print("C5': fetch_unlabelled(4) on 1000000 x 512: %.2f s, %d oracle evaluations" % (dt, ntask))
+
+
+def test_c5_share_125000x512_k16_monte_carlo(dev):
+    """BASELINE configs[4] as one of 8 ranks sees it: 125 000 x 512, batch of 16, monte_carlo_num_rel = 1 (2^16 patterns
+    are infeasible anywhere): the general scorer up to orthant dimension 16, patterns sampled on numpy's generator in the
+    reference's order.  Oracle checks at steps 1, 2, 3, 5, 8, 12, 16."""
+    from ital_amd import ITAL, mvn_stream
+    n, d, k, mc = 125_000, 512, 16, 1
+    rng = np.random.default_rng(7)
+    X = rng.random((n, d))
+    ls = float(np.sqrt(d / 12.0))
+    mvn_stream.GLOBAL.reset()
+    L = ITAL(X, length_scale=ls, monte_carlo_num_rel=mc, device=dev)
+    L.keep_scores = True
+    L.update({0: 1, 1: -1, 2: 1})
+    cand0 = np.asarray(L.get_unseen())
+    stream0 = (mvn_stream.GLOBAL.state, mvn_stream.GLOBAL.draws)
+    np.random.seed(11)
+    t0 = time.perf_counter()
+    picks = L.fetch_unlabelled(k)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    scores = [s.cpu().numpy() for s in L.last_scores]
+    assert len(set(picks)) == k and not (set(picks) & {0, 1, 2})
+    n_cand = len(cand0)
+
+    def npat(t):
+        return L._mc_plan(t, 0)[1]
+
+    def draws(t):
+        return npat(t) * 2 * mvn_stream.draws_per_call(t)
+
+    def normals(t):
+        return npat(t) * t if L._mc_plan(t, 0)[0] else 0
+
+    assert all(L._mc_plan(t, 0)[0] for t in range(1, k + 1))          # every step samples its patterns
+    want_draws = sum((n_cand - (t - 1)) * draws(t) for t in range(1, k + 1))
+    assert mvn_stream.GLOBAL.draws - stream0[1] == want_draws
+    pos_of = {int(c): p for p, c in enumerate(cand0)}
+    pick_pos = [pos_of[int(p)] for p in picks]
+    for t in range(k):
+        live = np.ones(n_cand, dtype=bool)
+        live[pick_pos[:t]] = False
+        s = scores[t]
+        assert np.all(np.isfinite(s[live]))
+        assert pick_pos[t] == int(np.flatnonzero(live)[np.argmax(s[live])])
+    checked = {1: 48, 2: 48, 3: 32, 5: 24, 8: 16, 12: 8, 16: 8}
+    samples = _sample_positions(np.random.default_rng(8), n_cand, pick_pos, k, lambda t: checked.get(t, 0))
+    samples = {t: ps for t, ps in samples.items() if t in checked}
+    # the reference maps its normals through an SVD of the candidate's covariance: LAPACK's sign of a singular vector can
+    # flip under a last-bit difference of that matrix -- such a candidate receives other, equally valid sign
+    # patterns.  Rare (one candidate in ~150 problems of the fuzz tool); one of the ~190 checked here may be hit.
+    ntask, bad = _check_against_sub_oracle(X, ls, L, picks, cand0, scores, samples, dict(monte_carlo_num_rel=mc), stream0,
+                                           draws, seed=11, normals_per_cand=normals, workers=8, allow_mismatch=1)
+    print("C5' share: fetch_unlabelled(16) on 125000 x 512, monte_carlo_num_rel=1: %.1f s, %d oracle evaluations, "
+          "%d sign-flip mismatches" % (dt, ntask, len(bad)))
