@@ -165,6 +165,13 @@ int ital_select_local(const double* mi, const int32_t* cand, const uint8_t* aliv
 int ital_select_resolve(const double* records, int world, int rec_len, int rank, int mode, int slot,
                         ital_batch batch, uint8_t* alive, int64_t* ret, hipStream_t stream);
 
+/* The exchange between ital_select_local and ital_select_resolve, for hosts that drive the ranks themselves: ONE
+ * ncclAllGather (RCCL) per greedy step -- records_all[w][rec_len] receives the record of rank w, in rank order, on every
+ * rank.  nccl_comm: this rank's ncclComm_t.  RCCL is looked up in the running process (a PyTorch host already carries one;
+ * ital_amd's own learners go through torch.distributed, i.e. the same RCCL call) and opened by name otherwise.
+ * Replaces the Pool.map gather of the per-candidate scores, reference ital/ital.py:124-130. */
+int ital_select_exchange(const double* record, double* records_all, int rec_len, void* nccl_comm, hipStream_t stream);
+
 /* ital_select_local + ital_select_resolve for ONE rank in a single launch (small problems are launch-latency bound).
  * Same semantics; `record` is scratch of ITAL_REC_HEADER + ldx + ldw + kmax doubles. */
 int ital_select_fused(const double* mi, const int32_t* cand, uint8_t* alive, int64_t n_cand, int64_t pos_offset,

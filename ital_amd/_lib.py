@@ -85,6 +85,7 @@ SIGNATURES = {
     "ital_select_fused": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_void_p, c_int64, c_int, c_int, c_void_p,
                                   c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int64, c_int, c_int, c_void_p,
                                   c_int64, c_int, c_int, ItalBatch, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "ital_select_exchange": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p]),
     "ital_select_resolve": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, ItalBatch, c_void_p, c_void_p,
                                     c_void_p]),
 }

@@ -178,3 +178,37 @@ def test_rccl_code_path_on_a_one_rank_group(name):
         r0 = out[0]
     assert r0[0] == [z[f"r{r}_ret"].tolist() for r in range(int(z["rounds"]))]
     np.testing.assert_allclose(r0[1], z["final_rel_mean"], rtol=0, atol=1e-9)
+
+
+def test_record_exchange_below_the_c_abi_through_rccl():
+    """ital_select_exchange: the per-step all-gather as a non-Python host would drive it -- a raw ncclComm_t (here a
+    one-rank communicator created through RCCL's own C API) and a HIP stream; no torch.distributed involved."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    import ctypes
+    from ital_amd import _lib
+    lib = _lib.lib()
+    rccl = ctypes.CDLL(os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so"), mode=ctypes.RTLD_GLOBAL)
+
+    class UniqueId(ctypes.Structure):
+        _fields_ = [("internal", ctypes.c_char * 128)]
+
+    torch.cuda.set_device(0)
+    uid = UniqueId()
+    assert rccl.ncclGetUniqueId(ctypes.byref(uid)) == 0
+    comm = ctypes.c_void_p()
+    rccl.ncclCommInitRank.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_int, UniqueId, ctypes.c_int]
+    assert rccl.ncclCommInitRank(ctypes.byref(comm), 1, uid, 0) == 0
+    try:
+        rec_len = _lib.ITAL_REC_HEADER + 32 + 64 + 4
+        rec = torch.arange(rec_len, dtype=torch.float64, device="cuda:0") * 0.5
+        out = torch.zeros((1, rec_len), dtype=torch.float64, device="cuda:0")
+        _lib.check(lib.ital_select_exchange(rec.data_ptr(), out.data_ptr(), rec_len, comm,
+                                            torch.cuda.current_stream().cuda_stream))
+        torch.cuda.synchronize()
+        assert torch.equal(out[0], rec)
+        assert lib.ital_select_exchange(rec.data_ptr(), out.data_ptr(), rec_len, None,
+                                        torch.cuda.current_stream().cuda_stream) != 0     # no communicator: refused
+    finally:
+        rccl.ncclCommDestroy.argtypes = [ctypes.c_void_p]
+        rccl.ncclCommDestroy(comm)
