@@ -285,9 +285,12 @@ class ITAL(ActiveRetrievalBase):
                                                 gp.rank, 0, _ptr(gp.mu), _ptr(gp.s2), _ptr(gp.Xd), _ptr(gp.xnorm), gp.ldx,
                                                 _ptr(gp.V), gp.ldv, gp.m, gp.cap, _ptr(b["C"]), gp.ldv, t - 1, b["kmax"],
                                                 _ptr(gp.status), _ptr(b["work"]), _ptr(b["rec"]), st))
-                    ev0 = self._mark()
-                    recs = sharding.gather_records(b["rec"], b["rec_all"], gp.group) if gp.collective else b["rec"]
-                    self._mark("exchange", t, gp.world, ev0)
+                    if gp.collective:
+                        ev0 = self._mark()
+                        recs = sharding.gather_records(b["rec"], b["rec_all"], gp.group)
+                        self._mark("exchange", t, gp.world, ev0)
+                    else:
+                        recs = b["rec"]
                     check(lib.ital_select_resolve(_ptr(recs), gp.world, b["rec_len"], gp.rank, 0, t - 1, b["batch"],
                                                   _ptr(alive), _ptr(b["ret"]), st))
                 if t < k:
