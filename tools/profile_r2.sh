@@ -26,7 +26,7 @@ passes() {   # name, program and arguments...
 for w in $WHICH; do
   case $w in
     headline) passes headline python3 $ROOT/bench.py --steps 6 --warmup 1 --no-cpu-baseline --no-scaling-workload
-              tail -1 $OUT/headline_stats.log > $OUT/r2_headline_bench_under_rocprof.json ;;
+              grep '^{"metric"' $OUT/headline_stats.log > $OUT/r2_headline_bench_under_rocprof.json ;;
     general)  passes general python3 $ROOT/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-scaling-workload --label-prob 0.5 --mistake-prob 0.25 ;;
     mcmi)     passes mcmi python3 $ROOT/tools/mcmi_bench.py ;;
     c5share)  rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/c5share_stats -o stats -- python3 $ROOT/tools/scale_probe.py 125000 512 16 1 > $OUT/r2_c5share_probe.log 2>&1
