@@ -235,12 +235,14 @@ class OracleITAL(OracleLearnerBase):
         return prob_rel(np.array([rel[i] for i in ret]), mean, cov, self.clip_cov)
 
     # ---- MI (ital.py:183-275)
-    def mutual_information(self, ret, mean, cov, rel_it=None):
+    def mutual_information(self, ret, mean, cov, rel_it=None, patterns=None):
+        """`patterns`: explicit sign patterns instead of the ones rel_iter would enumerate / sample (tests: the Monte-Carlo
+        estimate for a GIVEN sample, independent of LAPACK's sign conventions in multivariate_normal)."""
         ret = [int(i) for i in ret]
         if rel_it is not None:
             return self._mi_sub(ret, rel_it, mean, cov)
         mi = 0.0
-        it, mc = self._rel_iter(len(ret), mean, cov)
+        it, mc = self._rel_iter(len(ret), mean, cov) if patterns is None else (patterns, len(patterns))
         for reli in it:
             rel = {ret[i]: r for i, r in enumerate(reli)}
             pr = prob_rel(reli, mean, cov, self.clip_cov)
@@ -353,7 +355,7 @@ class _Appended:
         self.covs = self.L.gp.predict_cov_batch(self.ext, out)
         self.cov_base = self.L.gp.predict_stored(self.ext, cov_mode="full")[1]
 
-    def score(self, i):
+    def score(self, i, patterns=None):
         L = self.L
         if L._ce_subset is not None:
             if i in self.pos:
@@ -362,7 +364,7 @@ class _Appended:
                 ret, rel_it, cov = self.ext + [i], self.ret_pos + [len(self.ext)], self.covs[self.cov_pos[i]]
             return L.mutual_information(ret, L.rel_mean[ret], cov, rel_it=rel_it)
         ids = self.ret + [i]
-        return L.mutual_information(ids, L.rel_mean[ids], self.covs[i])
+        return L.mutual_information(ids, L.rel_mean[ids], self.covs[i], patterns=patterns)
 
     def append(self, i):
         self.ret.append(i)

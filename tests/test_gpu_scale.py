@@ -49,7 +49,7 @@ def _oracle_scores(job):
     consumed = 0
     if job["seed"] is not None:
         np.random.seed(job["seed"])
-    for t, i, rng_state, skip in job["tasks"]:
+    for t, i, rng_state, skip, given in job["tasks"]:
         while t_now < t:
             state.append(int(job["picks"][t_now - 1]))
             t_now += 1
@@ -64,14 +64,21 @@ def _oracle_scores(job):
         omvn.rng_set_state(rng_state)
         before = omvn.rng_draws()
         val = state.score(int(i))
+        drawn = omvn.rng_draws() - before
         if skip is not None:
             consumed += job["normals_per_cand"][t]
-        out.append((t, int(i), float(val), omvn.rng_draws() - before))
+        val_given = None
+        if given is not None:
+            # the same estimate for the sign patterns the device learner sampled (bit t-1-v = variable v relevant)
+            pats = [tuple(bool((int(w) >> (t - 1 - v)) & 1) for v in range(t)) for w in given]
+            omvn.rng_set_state(rng_state)
+            val_given = float(state.score(int(i), patterns=pats))
+        out.append((t, int(i), float(val), drawn, val_given))
     return out
 
 
 def _check_against_sub_oracle(X, ls, L, picks, cand0, scores, samples, kw, stream0, draws_per_cand, seed=None,
-                              normals_per_cand=None, workers=8, rtol=1e-8, allow_mismatch=0):
+                              normals_per_cand=None, workers=8, rtol=1e-8, patterns=None, allow_resampled=0.0):
     """samples: {t: list positions in the ORIGINAL candidate list (live at step t)}.  draws_per_cand(t): uniforms of the
     mvndst stream one candidate consumes at step t.  normals_per_cand(t): standard normals of numpy's generator per
     candidate (Monte-Carlo pattern sampling; 0 where the step enumerates)."""
@@ -99,7 +106,8 @@ def _check_against_sub_oracle(X, ls, L, picks, cand0, scores, samples, kw, strea
             rank = p - int(np.searchsorted(dead, p))
             st = stream.peek(rank * dpc)
             skip = normals_before_step + rank * npc if normals_per_cand else None
-            tasks.append((t, sub[int(cand0[p])], tuple(int(v) for v in st), skip, p))
+            given = None if patterns is None else [int(w) for w in patterns[t - 1][p]]
+            tasks.append((t, sub[int(cand0[p])], tuple(int(v) for v in st), skip, given, p))
         stream.advance(n_alive * dpc)
         normals_before_step += n_alive * npc
     # cut the task list into contiguous slices of about equal cost (each worker walks numpy's stream forward once); a
@@ -114,19 +122,24 @@ def _check_against_sub_oracle(X, ls, L, picks, cand0, scores, samples, kw, strea
     for a, b in zip(cuts[:-1], cuts[1:]):
         if b > a:
             jobs.append(dict(root=ROOT, Xs=Xs, ls=ls, kw=kw, labelled=[(sub[int(i)], y) for i, y in labelled],
-                             picks=[sub[int(p)] for p in picks], tasks=[tk[:4] for tk in tasks[a:b]], seed=seed,
+                             picks=[sub[int(p)] for p in picks], tasks=[tk[:5] for tk in tasks[a:b]], seed=seed,
                              normals_per_cand={t: (normals_per_cand(t) if normals_per_cand else 0) for t in range(1, k + 1)}))
     with ProcessPoolExecutor(max_workers=len(jobs), mp_context=mp.get_context("spawn")) as pool:
         results = [r for part in pool.map(_oracle_scores, jobs) for r in part]
     assert len(results) == len(tasks)
     bad = []
-    for (t, si, val, drawn), tk in zip(results, tasks):
-        p = tk[4]
+    for (t, si, val, drawn, val_given), tk in zip(results, tasks):
+        p = tk[5]
         mine = scores[t - 1][p]
         assert drawn == draws_per_cand(t), (t, p, drawn)      # the oracle consumed what the offsets assume
+        if val_given is not None:
+            # strict: the estimate for the patterns the device learner sampled
+            assert np.isclose(mine, val_given, rtol=rtol, atol=1e-12), (t, p, mine, val_given)
         if not np.isclose(mine, val, rtol=rtol, atol=1e-12):
             bad.append((t, p, mine, val))
-    assert len(bad) <= allow_mismatch, bad[:5]
+    # `bad`: candidates whose patterns the oracle's own multivariate_normal sampled differently (LAPACK's sign conventions,
+    # DESIGN.md) -- never tolerated where the patterns are enumerated
+    assert len(bad) <= allow_resampled * len(tasks), bad[:5]
     return len(tasks), bad
 
 
@@ -250,10 +263,14 @@ def test_c5_share_125000x512_k16_monte_carlo(dev):
     checked = {1: 48, 2: 48, 3: 32, 5: 24, 8: 16, 12: 8, 16: 8}
     samples = _sample_positions(np.random.default_rng(8), n_cand, pick_pos, k, lambda t: checked.get(t, 0))
     samples = {t: ps for t, ps in samples.items() if t in checked}
-    # the reference maps its normals through an SVD of the candidate's covariance: LAPACK's sign of a singular vector can
-    # flip under a last-bit difference of that matrix -- such a candidate receives other, equally valid sign
-    # patterns.  Rare (one candidate in ~150 problems of the fuzz tool); one of the ~190 checked here may be hit.
+    # The reference maps its normals through an SVD of the candidate's covariance, and LAPACK's sign of a singular vector
+    # can flip under a last-bit difference of that matrix (~0.6 % of the candidates at t >= 7): such a candidate
+    # receives other, equally valid sign patterns.  Hence two checks: STRICT -- for the patterns the device learner sampled
+    # (L.last_patterns) the oracle's estimate equals the device's for every checked candidate; LOOSE -- the oracle's own
+    # sampling (numpy's generator walked to the candidate's normals) reproduces those patterns for at least 95 % of them.
     ntask, bad = _check_against_sub_oracle(X, ls, L, picks, cand0, scores, samples, dict(monte_carlo_num_rel=mc), stream0,
-                                           draws, seed=11, normals_per_cand=normals, workers=8, allow_mismatch=1)
-    print("C5' share: fetch_unlabelled(16) on 125000 x 512, monte_carlo_num_rel=1: %.1f s, %d oracle evaluations, "
-          "%d sign-flip mismatches" % (dt, ntask, len(bad)))
+                                           draws, seed=11, normals_per_cand=normals, workers=8,
+                                           patterns=[np.asarray(a) for a in L.last_patterns], allow_resampled=0.05)
+    print("C5' share: fetch_unlabelled(16) on 125000 x 512, monte_carlo_num_rel=1: %.1f s, %d oracle evaluations "
+          "(all equal for the device's patterns), %d candidates re-sampled differently by the oracle's LAPACK"
+          % (dt, ntask, len(bad)))

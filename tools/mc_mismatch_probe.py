@@ -37,7 +37,8 @@ if __name__ == "__main__":
     normals = lambda t: npat(t) * t if L._mc_plan(t, 0)[0] else 0
     samples = tgs._sample_positions(np.random.default_rng(8), len(cand0), pick_pos, k, lambda t: per)
     ntask, bad = tgs._check_against_sub_oracle(X, ls, L, picks, cand0, scores, samples, dict(monte_carlo_num_rel=mc), stream0,
-                                               draws, seed=11, normals_per_cand=normals, workers=12, allow_mismatch=10 ** 9)
+                                               draws, seed=11, normals_per_cand=normals, workers=12,
+                                               patterns=[np.asarray(a) for a in L.last_patterns], allow_resampled=1.0)
     print("checked", ntask, "mismatches", len(bad))
     by_t = {}
     for t, p, mine, val in bad:
