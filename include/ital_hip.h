@@ -273,11 +273,6 @@ typedef struct ital_gscore_desc {
                                ([n_cand]; with clip_cov the count depends on the data) and scores nothing */
     double* mi;             /* [n_cand] out */
     int* status;
-    double* work;           /* workspace in device memory (work_doubles doubles; ital_amd reuses the lattice scorer's): with
-                               room for at least one candidate's prepared calls -- calls x (2 + n(n+1)/2 + n + 16(n-1)) doubles,
-                               n = nE + 1 -- the step runs as three kernels (prepare, lattice sums, combine) over slabs of
-                               candidates; otherwise (and with clip_cov) as one kernel that does everything per candidate */
-    int64_t work_doubles;
     unsigned long long* pair_count; /* non-NULL: += the (Phi, Phi^-1) pairs of the lattice sums that were evaluated
                                (16 P(n-1) points x (n-1) pairs per evaluated call; instrumentation for the roofline) */
 } ital_gscore_desc;

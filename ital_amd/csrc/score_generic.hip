@@ -43,8 +43,9 @@
 #ifndef ITAL_GEN_NOINLINE
 #define ITAL_GEN_NOINLINE __attribute__((noinline))   // keeps the preparation's registers out of the evaluation loop's budget
 #endif
-#ifndef ITAL_GEN_PIPELINE
-#define ITAL_GEN_PIPELINE 1   // prepare / lattice-sum / combine as three kernels (0: the monolithic kernel for everything)
+#ifndef ITAL_GEN_HOTK
+#define ITAL_GEN_HOTK 1   // exp / log coefficients of the compile-time-dimension evaluator as vector-register operands (HotK:
+                          // 197 -> 20 spilled VGPRs, 385 -> 193 spilled SGPRs in the t = 4 instantiation; noisy-user step 61.8 -> 59.1 ms)
 #endif
 #ifndef ITAL_GEN_EARLY
 #define ITAL_GEN_EARLY 1   // decide saturated calls from the standardised limits, before COVSRT
@@ -661,7 +662,13 @@ __device__ double qmc_eval_fixed(const double* __restrict__ slab, unsigned infi,
 #pragma unroll
         for (int j = 0; j < i; j++) cf[i * (i - 1) / 2 + j] = uniform_f64(slab[pidx(i, j)]);
     }
+#if ITAL_GEN_HOTK
+    HotK kk;
+    kk.load();
+    const double acc = qmc_lane_sum<T, HotK>(lat, cf, lm, infi, tailq, lane, kk);
+#else
     const double acc = qmc_lane_sum<T>(lat, cf, lm, infi, tailq, lane);
+#endif
     return wave_sum(acc) / (16.0 * PRIME);
 }
 
@@ -919,229 +926,6 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(ITAL_GEN_WA
     if (lane == 0 && d.pair_count) atomicAdd(d.pair_count, pairs);
 }
 
-// ------------------------------------------------------------------------------------------------ three-kernel pipeline
-// The monolithic kernel above prepares, evaluates and accumulates inside one wave per candidate: its register allocation
-// is the union of three very different phases (1.1 KB of scratch per lane, 26 GB of spill traffic per launch at the
-// noisy-user benchmark size, half of the vector issue slots idle).  Everything except clip_cov runs through three kernels
-// instead, the prepared calls travelling through a workspace in HBM:
-//   gen_prep_kernel     wave per candidate, lane per call   decode + closed-form update + early verdict + COVSRT + lattice
-//   gen_main_kernel     wave per (candidate, call)          the lattice sums of the calls that need one (FP64-VALU bound)
-//   gen_combine_kernel  thread per candidate                the terms in the reference's order -> mi
-// meta[call] = (flags | n << 8 | infi << 16 | closes << 40, value): value is written by the preparation (closed forms,
-// saturated calls) or by the lattice-sum kernel.
-struct GPipe {
-    int64_t slab_lo, slab_n;   // candidate positions [slab_lo, slab_lo + slab_n) of this launch
-    int total;                 // calls per candidate
-    int R;                     // doubles per record: packed factor + limits (the evaluator's slab), then the lattices
-    int lat;                   // offset of the lattices inside a record
-    double* meta;              // [slab_n][total][2]
-    double* recs;              // [slab_n][total][R]
-};
-
-__device__ __forceinline__ long long pack_meta(const Prep& pp) {
-    return (long long)(pp.flags & 0xff) | ((long long)(pp.n & 0xff) << 8) | ((long long)(pp.infi & 0xffffffu) << 16) |
-           ((long long)(pp.closes & 0xffffffu) << 40);
-}
-
-__global__ __launch_bounds__(128) void gen_prep_kernel(GArgs a, GPipe g) {
-    extern __shared__ double lds_all[];
-    const ital_gscore_desc& d = a.d;
-    const int lane = threadIdx.x & 63;
-    const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int64_t i = (int64_t)blockIdx.x * 2 + wid;
-    if (i >= g.slab_n) return;
-    const int64_t p = g.slab_lo + i;
-    if (!d.alive[p]) return;
-    double* W = lds_all + (size_t)wid * a.wave_doubles;
-    double* muU = W;
-    const int ldS = a.ldS;
-    double* SigU = muU + ldS;
-    int* usort = reinterpret_cast<int*>(SigU + ldS * ldS);
-    int* ipos = usort + GN;
-    double* slabs = SigU + ldS * ldS + (GN + GR + 1) / 2;
-
-    const int row = d.cand[p];
-    const int64_t gi = d.row_offset + row;
-    const int nE = d.nE;
-    const bool subset = d.subset_mode != 0;
-    int epos = -1;
-    for (int e = 0; e < nE; e++)
-        if (d.E_idx[e] == gi) epos = e;
-    if (!subset) epos = -1;
-    const int nU = epos >= 0 ? nE : nE + 1;
-    const int cpos = epos >= 0 ? epos : nE;
-    const int nr = d.n_picks + 1;
-    // joint mean / covariance of U = E (+ candidate) in the wave's LDS area
-    for (int idx = lane; idx < nU * nU; idx += 64) {
-        const int r = idx / nU, c = idx - r * nU;
-        double v;
-        if (r < nE && c < nE) v = d.E_sig[r * d.ldE + c];
-        else if (r == c) v = d.s2[row];                         // not clamped (gp.py:254)
-        else v = d.C[(int64_t)(r < c ? r : c) * d.ldc + row];
-        SigU[r * ldS + c] = v;
-    }
-    for (int e = lane; e < nU; e += 64) muU[e] = e < nE ? d.E_mu[e] : d.mu[row];
-    if (lane == 0) {
-        if (epos >= 0) {
-            for (int sidx = 0; sidx < nE; sidx++) usort[sidx] = d.E_sort[sidx];
-        } else {
-            int rank = 0;
-            for (int e = 0; e < nE; e++) rank += (d.E_idx[e] < gi) ? 1 : 0;
-            for (int sidx = 0; sidx < nU; sidx++)
-                usort[sidx] = sidx < rank ? d.E_sort[sidx] : (sidx == rank ? nE : d.E_sort[sidx - 1]);
-        }
-        for (int v = 0; v < nr; v++) ipos[v] = v < d.n_picks ? d.pick_pos[v] : cpos;
-    }
-    // stream position of this candidate in the reference's serial order
-    MrgState rng = {d.seed[0], d.seed[1], d.seed[2], d.seed[3], d.seed[4], d.seed[5]};
-    {
-        const int64_t gpos = d.gpos ? d.gpos[p] : d.pos_offset + p;
-        int64_t before = gpos, n_in = 0;
-        for (int q = 0; q < d.n_dead; q++) before -= (d.dead_pos[q] < gpos) ? 1 : 0;
-        for (int q = 0; q < d.n_in; q++) n_in += (d.in_pos[q] < gpos) ? 1 : 0;
-        uint64_t off = (uint64_t)(before - n_in) * (uint64_t)d.draws_out + (uint64_t)n_in * (uint64_t)d.draws_in;
-        if (d.draw_off) off = (uint64_t)d.draw_off[p];
-        for (int bit = 0; off != 0; bit++, off >>= 1)
-            if (off & 1) mrg_apply(rng, d.jump1 + bit * 18);
-    }
-    wave_sync();
-    const int npat = d.mc_rel > 0 ? d.mc_rel : (1 << nr);
-    const int npre = subset ? 2 : 1;
-    const bool entropy = d.fb_mode == 3;
-    const int nfb = entropy ? 0 : (d.fb_mode == 0 ? 1 : (d.mc_fb > 0 ? d.mc_fb : (d.fb_mode == 1 ? (1 << nr) : pow3(nr) - 1)));
-    const int cpp = npre + nfb;
-    const int total = npat * cpp;
-    const bool clamp_prior = !subset && nr == 1;
-    double* meta = g.meta + (size_t)i * total * 2;
-    double* recs = g.recs + (size_t)i * total * g.R;
-    for (int chunk0 = 0; chunk0 < total; chunk0 += a.chunk) {
-        Prep pp;
-        pp.n = 0; pp.infi = 0; pp.flags = 16; pp.value = 0; pp.closes = 0; pp.ng = 0; pp.gdraws = 0;
-        const int call = chunk0 + lane;
-        const bool mine = lane < a.chunk && call < total;
-        double* slab = slabs + (size_t)lane * a.stride;
-        if (mine) {
-            const CallInfo ci = decode_call(d, p, call, cpp, npre, nr, npat);
-            if (ci.kind != K_SKIP)
-                pp = prepare_call<false>(d, ci, nU, nr, ldS, muU, SigU, usort, ipos, clamp_prior, slab, slab + a.slab, nullptr);
-        }
-        // every dimension >= 3 call (evaluated or saturated) takes 8*(2*NDIM-1) uniforms from MVNUNI: lane l jumps ahead by
-        // what the calls before it in this chunk consume, the wave's base state by the chunk's total
-        const bool draws_any = pp.n >= 3 && !(pp.flags & (1 | 16));
-        const int my_draws = draws_any ? 8 * (2 * (pp.n - 1) - 1) : 0;
-        int incl = my_draws;
-#pragma unroll
-        for (int off = 1; off < 64; off <<= 1) {
-            const int o = __shfl_up(incl, off, 64);
-            if (lane >= off) incl += o;
-        }
-        const int total_draws = __builtin_amdgcn_readlane(incl, 63);
-        if (mine) {
-            if (draws_any && !(pp.flags & 6)) {
-                double* rec = recs + (size_t)call * g.R;
-                const int ns = pp.n * (pp.n + 1) / 2 + pp.n;
-                for (int q = 0; q < ns; q++) rec[q] = slab[q];
-                make_lattice(d, rng, (unsigned)(incl - my_draws), pp.n, rec + g.lat);
-            }
-            double value = pp.value;
-            if (!(pp.flags & 1) && (pp.flags & 6)) value = (pp.flags & 2) ? 1.0 : 0.0;
-            meta[2 * call] = __longlong_as_double(pack_meta(pp));
-            meta[2 * call + 1] = value;
-        }
-        unsigned adv = (unsigned)total_draws;
-        for (int bit = 0; adv != 0; bit++, adv >>= 1)
-            if (adv & 1u) mrg_apply(rng, d.jump1 + bit * 18);
-        wave_sync();
-    }
-}
-
-template <int NMAX, int NH, int TFIX>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(ITAL_GEN_WAVES(TFIX), ITAL_GEN_WAVES(TFIX)))) void gen_main_kernel(
-    const uint8_t* __restrict__ alive, GPipe g, unsigned long long* pair_count) {
-    extern __shared__ double lds_all[];
-    const int lane = threadIdx.x & 63;
-    const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int64_t item = (int64_t)blockIdx.x * 4 + wid;
-    const int64_t i = item / g.total;
-    if (i >= g.slab_n) return;
-    if (!alive[g.slab_lo + i]) return;
-    double* meta = g.meta + item * 2;
-    const long long m = __double_as_longlong(uniform_f64(meta[0]));
-    const int fl = (int)(m & 0xff);
-    if (fl & (1 | 2 | 4 | 16)) return;              // closed form, saturated or skipped: nothing to integrate
-    const int n = (int)((m >> 8) & 0xff);
-    const unsigned infi = (unsigned)((m >> 16) & 0xffffffu), closes = (unsigned)((m >> 40) & 0xffffffu);
-    double* rec = lds_all + (size_t)wid * (g.R + 256);
-    double* tailq = rec + g.R;
-    const double* src = g.recs + item * g.R;
-    const int ns = n * (n + 1) / 2 + n;
-    for (int q = lane; q < ns; q += 64) rec[q] = src[q];
-    for (int q = lane; q < 16 * (n - 1); q += 64) rec[g.lat + q] = src[g.lat + q];
-    wave_sync();
-    double value;
-    if (TFIX > 0 && n == TFIX && closes == (1u << (TFIX > 0 ? TFIX : 1)) - 1u)
-        value = qmc_eval_fixed<(TFIX > 0 ? TFIX : 3)>(rec, infi, rec + g.lat, lane, tailq);
-    else
-        value = qmc_eval<NMAX, NH>(n, rec, infi, closes, rec + g.lat, lane, tailq);
-    if (lane == 0) {
-        meta[1] = value;
-        if (pair_count) atomicAdd(pair_count, 16ull * P_TAB[(n - 1 < 10 ? n - 1 : 10) - 1] * (n - 1));
-    }
-}
-
-__global__ __launch_bounds__(64) void gen_combine_kernel(GArgs a, GPipe g) {
-    const ital_gscore_desc& d = a.d;
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= g.slab_n) return;
-    const int64_t p = g.slab_lo + i;
-    if (!d.alive[p]) return;
-    const bool subset = d.subset_mode != 0;
-    const int nr = d.n_picks + 1;
-    const int npat = d.mc_rel > 0 ? d.mc_rel : (1 << nr);
-    const int npre = subset ? 2 : 1;
-    const bool entropy = d.fb_mode == 3;
-    const int nfb = entropy ? 0 : (d.fb_mode == 0 ? 1 : (d.mc_fb > 0 ? d.mc_fb : (d.fb_mode == 1 ? (1 << nr) : pow3(nr) - 1)));
-    const int cpp = npre + nfb;
-    const int total = npat * cpp;
-    const double* meta = g.meta + (size_t)i * total * 2;
-    double mi = 0.0, pr_cur = 0.0, logpr_cur = 0.0;
-    for (int call = 0; call < total; call++) {
-        const int fl = (int)(__double_as_longlong(meta[2 * call]) & 0xff);
-        if (fl & 16) continue;   // skipped all-zero feedback sample
-        const double value = meta[2 * call + 1];
-        const CallInfo ci = decode_call(d, p, call, cpp, npre, nr, npat);
-        if (entropy) {
-            if (nr == 1) {
-                if (ci.pat == 0) {
-                    const double q = fmax(1e-8, fmin(1.0 - 1e-8, value));
-                    mi = q * log(q) + (1.0 - q) * log(1.0 - q);
-                }
-            } else if (value > 1e-12) {
-                mi += value * log(value);
-            }
-        } else if (ci.kind == K_PRIOR) {
-            pr_cur = value;
-            logpr_cur = log(value + d.eps);
-        } else if (ci.kind == K_PRIOR_SUB) {
-            pr_cur = value;
-        } else if (ci.kind == K_PRIOR_FULL) {
-            logpr_cur = log(value + d.eps);
-        } else {
-            double cur = (log(value + d.eps) - logpr_cur) * ci.weight;
-            if (!subset && d.label_mode == 1) {
-                if (cur > mi) mi = cur;
-            } else if (!subset && d.label_mode == 2) {
-                if (mi == 0 || cur < mi) mi = cur;
-            } else {
-                mi += d.mc_rel > 0 ? cur : cur * pr_cur;   // sampled patterns are not weighted (ital.py:216-218)
-            }
-        }
-    }
-    if (d.mc_rel > 0) mi /= d.mc_rel;   // ital.py:221-222
-    if (entropy) mi = -mi;
-    d.mi[p] = mi;
-}
-
 }  // namespace ital
 
 using namespace ital;
@@ -1193,65 +977,6 @@ extern "C" int ital_score_generic(const ital_gscore_desc* d, hipStream_t stream)
     const int64_t blocks = (d->n_cand + 1) / 2;
     // plain mode (no subset): every call of dimension >= 3 has dimension n_picks + 1 -> compile-time evaluator
     const int tfix = (!d->subset_mode && nUmax >= 3 && nUmax <= 6) ? nUmax : 0;
-    // ---- three-kernel pipeline (everything but clip_cov and its counting pass), candidates in slabs of the workspace
-    {
-        double npat = d->mc_rel > 0 ? (double)d->mc_rel : pow(2.0, nr);
-        double nfb = d->fb_mode == 3 ? 0.0 : d->fb_mode == 0 ? 1.0 : (d->mc_fb > 0 ? (double)d->mc_fb : (d->fb_mode == 1 ? pow(2.0, nr) : pow(3.0, nr) - 1));
-        const int64_t total = (int64_t)(npat * ((d->subset_mode ? 2 : 1) + nfb));
-        GPipe g;
-        g.total = (int)total;
-        g.lat = nUmax * (nUmax + 1) / 2 + nUmax;
-        g.R = g.lat + 16 * (nUmax - 1 > 0 ? nUmax - 1 : 0);
-        const int64_t per_cand = total * (2 + (int64_t)g.R);
-        if (!clip && !d->draw_count && d->work && d->work_doubles >= per_cand && ITAL_GEN_PIPELINE) {
-            int64_t S = d->work_doubles / per_cand;
-            if (S > d->n_cand) S = d->n_cand;
-            while (S * total > (int64_t)1 << 31) S >>= 1;     // grid size of the lattice-sum launch
-            GArgs ap = a;
-            int stride_p = (slab + fs_doubles(nr)) | 1;
-            int chunk_p = 64;
-            while (chunk_p > 4 && chunk_p * stride_p > 6144) chunk_p >>= 1;   // <= 48 KB of call slabs per wave
-            ap.chunk = chunk_p;
-            ap.stride = stride_p;
-            ap.master = 0;
-            ap.wave_doubles = fixed + chunk_p * stride_p;
-            const size_t lds_p = (size_t)2 * ap.wave_doubles * sizeof(double);
-            const size_t lds_m = (size_t)4 * (g.R + 256) * sizeof(double);
-            static bool prep_attr = false;
-            if (!prep_attr) {
-                if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gen_prep_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                        160 * 1024) != hipSuccess)
-                    return ital_fail(-12, "ital_score_generic: cannot raise the dynamic LDS limit");
-                prep_attr = true;
-            }
-            if (lds_p > 160 * 1024) return ital_fail(-12, "ital_score_generic: LDS budget exceeded");
-            for (int64_t lo = 0; lo < d->n_cand; lo += S) {
-                g.slab_lo = lo;
-                g.slab_n = d->n_cand - lo < S ? d->n_cand - lo : S;
-                g.meta = d->work;
-                g.recs = d->work + g.slab_n * total * 2;
-                hipLaunchKernelGGL(gen_prep_kernel, dim3((unsigned)((g.slab_n + 1) / 2)), dim3(128), lds_p, stream, ap, g);
-                const unsigned mb = (unsigned)((g.slab_n * total + 3) / 4);
-#define ITAL_GEN_MAIN(NMAX_, NH_, TFIX_) \
-    hipLaunchKernelGGL((gen_main_kernel<NMAX_, NH_, TFIX_>), dim3(mb), dim3(256), lds_m, stream, d->alive, g, d->pair_count)
-                switch (tfix) {
-                    case 3: ITAL_GEN_MAIN(6, 2, 3); break;
-                    case 4: ITAL_GEN_MAIN(6, 2, 4); break;
-                    case 5: ITAL_GEN_MAIN(6, 2, 5); break;
-                    case 6: ITAL_GEN_MAIN(6, 2, 6); break;
-                    default:
-                        if (nUmax <= 6) ITAL_GEN_MAIN(6, 2, 0);
-                        else if (nUmax <= 12) ITAL_GEN_MAIN(12, ITAL_GEN_NH12, 0);
-                        else ITAL_GEN_MAIN(ITAL_GENERIC_MAX_DIM, 1, 0);
-                }
-#undef ITAL_GEN_MAIN
-                hipLaunchKernelGGL(gen_combine_kernel, dim3((unsigned)((g.slab_n + 63) / 64)), dim3(64), 0, stream, ap, g);
-                int rc = ital_check_launch("ital_score_generic(pipeline)");
-                if (rc) return rc;
-            }
-            return 0;
-        }
-    }
 #define ITAL_GEN_LAUNCH(NMAX_, NH_, TFIX_, CLIP_)                                                                             \
     do {                                                                                                               \
         static bool attr_done = false;                                                                                 \

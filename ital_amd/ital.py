@@ -444,15 +444,6 @@ class ITAL(ActiveRetrievalBase):
                 desc.draws_out, desc.draws_in = draws_out, draws_in
                 desc.mi, desc.status = _ptr(mi), _ptr(gp.status)
                 desc.pair_count = _ptr(self.pair_counter)
-                if not clip_count and not (self._clip_active() and nE + 1 > 5):
-                    # workspace of the three-kernel pipeline: the prepared calls of a slab of candidates
-                    n_u = nE + 1
-                    per_cand = npat * ((2 if subset_mode else 1) + nfb) * (2 + n_u * (n_u + 1) // 2 + n_u + 16 * max(n_u - 1, 0))
-                    want = min(per_cand * max(n_loc, 1), max(self.qmc_work_bytes // 8, per_cand))
-                    w = b.get("qmc_work")
-                    if w is None or w.numel() < want:
-                        b["qmc_work"] = w = torch.empty(want, dtype=torch.float64, device=dev)
-                    desc.work, desc.work_doubles = _ptr(w), w.numel()
                 total_draws = None
                 if mc is not None:
                     rel_arr, fb_arr, draws_pp = mc          # per list position (dead positions hold zeros)
