@@ -165,6 +165,8 @@ def other_workloads(X, rel, device):
         for _ in range(warm):                             # warm-up rounds (the second one still loads code: lazily
             ret = learner.fetch_unlabelled(k)             # initialised torch kernels of the update path, 12-50 ms once)
             learner.update({int(i): float(rel[i]) for i in ret})
+        if getattr(learner, "pair_counter", None) is not None:
+            learner.pair_counter.zero_()                  # count the timed rounds only
         learner.profile = []
         learner.event_pool = [torch.cuda.Event(enable_timing=True) for _ in range(32 * k * rounds)]
         torch.cuda.synchronize()
