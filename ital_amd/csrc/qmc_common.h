@@ -110,7 +110,7 @@ __device__ __forceinline__ double eval_chains(const double (&xx)[NCB][(T - 1 > 0
 // Sum over this lane's share of the 16 P lattice points of one orthant call of compile-time dimension T (8 randomly
 // shifted Korobov lattices of P points, each point with its antithetic partner).  lat: [8][NDIM] permuted generators, then
 // [8][NDIM] shifts; cf / lm / infi as eval_chains.  The caller adds the lanes up and divides by 16 P.
-template <int T, class K = LitK>
+template <int T, class K = LitK, int NH_ = ITAL_QMC_NH>
 __device__ __forceinline__ double qmc_lane_sum(const double* __restrict__ lat,
                                                const double (&cf)[(T * (T - 1) / 2 > 0 ? T * (T - 1) / 2 : 1)],
                                                const double (&lm)[T], unsigned infi_c, double* __restrict__ tailq, int lane,
@@ -121,7 +121,7 @@ __device__ __forceinline__ double qmc_lane_sum(const double* __restrict__ lat,
     // chains of a call rarely fill whole rounds of 64 NC chains (t = 4: 1168 = 4.56 x 256): the last round runs
     // with just the chains it needs (3 per lane instead of 4 at t = 4: 19 chain slots per lane instead of 20),
     // whole items first, the two chains of the left-over items on neighbouring lanes.
-    constexpr int NH = ITAL_QMC_NH, NC = 2 * NH;
+    constexpr int NH = NH_, NC = 2 * NH;
     constexpr int NITEM = 8 * PRIME, FULL = (2 * NITEM) / (64 * NC), REST = 2 * NITEM - FULL * 64 * NC;
     constexpr int NCL = ITAL_QMC_TRIM_LAST ? (REST + 63) / 64 : (REST > 0 ? NC : 0);
     // (a last round that needs all NC chains anyway is simply one more trip of this loop: one copy of the code)

@@ -26,6 +26,9 @@
 #ifndef ITAL_QMC_HOTK
 #define ITAL_QMC_HOTK 1   // exp / log coefficients of the lattice loop as vector-register operands (device_math.h HotK)
 #endif
+#ifndef ITAL_QMC_MAIN_NH
+#define ITAL_QMC_MAIN_NH(T) ((T) == 3 ? 3 : 2)
+#endif
 #ifndef ITAL_QMC_WAVES
 #define ITAL_QMC_WAVES(T) ((T) <= 4 ? 3 : 2)   // waves per SIMD the register allocation aims at (measured)
 #endif
@@ -171,7 +174,11 @@ struct Qmc {
     static constexpr int SLAB_RAW = NCOV + 2 * T + NDIM;      // prep scratch per thread: packed factor, limits, expected values, generators
     static constexpr int SLAB = SLAB_RAW | 1;                 // odd stride: conflict-free per-thread slabs
     static constexpr int PREP_THREADS = T <= 6 ? 256 : 128;
-    static constexpr int TAILQ = 128 * ITAL_QMC_NH;           // compaction queue of the Phi^-1 tail branch (in place)
+    // lattice items per lane and round of the lattice-sum kernel (each with its antithetic partner): three at t = 3, where
+    // six chains still fit 168 registers (t = 3 launch 0.533 -> 0.505 ms: the tail branch of Phi^-1 then runs on 90 %
+    // full waves instead of 60 %); at t = 4 six chains spill at three waves per SIMD (4.3 ms) and lose at two (2.41 ms)
+    static constexpr int NH = ITAL_QMC_MAIN_NH(T);
+    static constexpr int TAILQ = 128 * NH;                    // compaction queue of the Phi^-1 tail branch (in place)
     static constexpr int WAVE_DOUBLES = LAT + TAILQ;
     static constexpr int64_t CAND_DOUBLES = (int64_t)NPAT * (REC + 1) + 3;   // records, terms, 6 ints of generator state
 };
@@ -460,9 +467,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(ITAL_QMC_WA
 #if ITAL_QMC_HOTK
         HotK kk;
         kk.load();
-        const double acc = qmc_lane_sum<T, HotK>(lat, cf, lm, infi, tailq, lane, kk);
+        const double acc = qmc_lane_sum<T, HotK, Q::NH>(lat, cf, lm, infi, tailq, lane, kk);
 #else
-        const double acc = qmc_lane_sum<T>(lat, cf, lm, infi, tailq, lane);
+        const double acc = qmc_lane_sum<T, LitK, Q::NH>(lat, cf, lm, infi, tailq, lane);
 #endif
         pr = wave_sum(acc) / (16.0 * Q::PRIME);
     }
