@@ -48,8 +48,7 @@ VALU_PER_PAIR_CHAIN = 47 + 0.85 * 45 + 0.15 * 121      # vector instructions of 
 FLOP_PER_MCMI_TERM = 53 + 2 * 44 + 6
 # committed counter summaries (rocprofv3 --pmc passes of this very command, tools/profile_gpu.sh + tools/pmc_summary.py):
 # HBM traffic and instruction counts per launch are read from these files and the file is named in the output
-PMC_FILES = {"headline": "profiles/r2_pmc_summary.csv", "general": "profiles/r2_general_pmc_summary.csv",
-             "mcmi": "profiles/r2_mcmi_pmc_summary.csv"}
+PMC_FILES = {"headline": "profiles/r2_pmc_summary.csv", "general": "profiles/r2_general_pmc_summary.csv"}
 CALIBRATION_FILE = "profiles/r2_oracle_calibration.json"
 
 
@@ -221,8 +220,9 @@ def other_workloads(X, rel, device):
         roofs["cov_block_kernel"] = dict({"bound": "mfma", "achieved": ach, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                                           "frac": ach / FP64_MFMA_PEAK_TFLOPS, "avg_launch_ms": sec * 1e3,
                                           "note": "1000 x 1000 block: 0.55 GFLOP per launch, launch-latency bound at the "
-                                                  "reference's subsample; 42 TFLOP/s at 9273^2 (profiles/r1_mcmi_*)"},
-                                         **pmc_fields("mcmi", "ital::cov_block_kernel", sec))
+                                                  "reference's subsample; 42 TFLOP/s at 9273^2 (profiles/r1_mcmi_*, "
+                                                  "profiles/r2_mcmi_pmc_summary.csv: launches of both sizes averaged)",
+                                          "traffic": None})
     ms = prof.get(("mcmi_score", BATCH), [])
     if ms:
         sec = float(np.mean([d for d, _ in ms]))
@@ -231,8 +231,9 @@ def other_workloads(X, rel, device):
         ach = terms * FLOP_PER_MCMI_TERM / sec / 1e12
         roofs["mcmi_score_kernel<%d>" % BATCH] = dict({"bound": "fp64-valu", "achieved": ach, "peak": FP64_VALU_PEAK_TFLOPS,
                                                        "unit": "TFLOP/s", "frac": ach / FP64_VALU_PEAK_TFLOPS,
-                                                       "avg_launch_ms": sec * 1e3, "terms_per_s": terms / sec},
-                                                      **pmc_fields("mcmi", "void ital::mcmi_score_kernel<%d>" % BATCH, sec))
+                                                       "avg_launch_ms": sec * 1e3, "terms_per_s": terms / sec, "traffic": None,
+                                                       "note": "counters: profiles/r2_mcmi_pmc_summary.csv (tools/mcmi_bench.py, "
+                                                               "launches of 1000 and 9273 candidates averaged)"})
     out["mcmi_min_subsample1000_k4"] = dict(r, roofline=roofs, config="MCMI_min, subsample 1000 (reference configs/usps.conf)")
     return out
 
