@@ -273,6 +273,13 @@ typedef struct ital_gscore_desc {
                                ([n_cand]; with clip_cov the count depends on the data) and scores nothing */
     double* mi;             /* [n_cand] out */
     int* status;
+    double* work;           /* workspace in device memory (work_doubles doubles; ital_amd reuses the lattice scorer's).  Without a
+                               subset and clip_cov, for 3 .. 6 variables, and with room for two buffers of at least one
+                               candidate's prepared calls each -- calls x (2.5 + n(n+1)/2 + n + 16(n-1)) doubles, n = nE + 1 -- the
+                               step runs as three kernels (prepare / lattice sums / combine) over slabs of candidates, the
+                               preparation of a slab under the lattice sums of the one before (two internal streams, joined
+                               with `stream` on both sides); otherwise as one kernel that does everything per candidate */
+    int64_t work_doubles;
     unsigned long long* pair_count; /* non-NULL: += the (Phi, Phi^-1) pairs of the lattice sums that were evaluated
                                (16 P(n-1) points x (n-1) pairs per evaluated call; instrumentation for the roofline) */
 } ital_gscore_desc;

@@ -44,7 +44,7 @@ class ItalGscoreDesc(ctypes.Structure):
                 ("draws_out", c_int64), ("draws_in", c_int64), ("n_in", c_int), ("in_pos", c_void_p),
                 ("n_dead", c_int), ("dead_pos", c_void_p), ("mc_rel", c_int), ("rel_samples", c_void_p),
                 ("mc_fb", c_int), ("fb_samples", c_void_p), ("draw_off", c_void_p), ("draw_count", c_void_p), ("mi", c_void_p),
-                ("status", c_void_p), ("pair_count", c_void_p)]
+                ("status", c_void_p), ("work", c_void_p), ("work_doubles", c_int64), ("pair_count", c_void_p)]
 
 
 class ItalMcmiDesc(ctypes.Structure):

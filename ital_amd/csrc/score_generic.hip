@@ -47,6 +47,9 @@
 #define ITAL_GEN_HOTK 1   // exp / log coefficients of the compile-time-dimension evaluator as vector-register operands (HotK:
                           // 197 -> 20 spilled VGPRs, 385 -> 193 spilled SGPRs in the t = 4 instantiation; noisy-user step 61.8 -> 59.1 ms)
 #endif
+#ifndef ITAL_GEN_PIPELINE
+#define ITAL_GEN_PIPELINE 1   // plain mode, 3 .. 6 variables: prepare / lattice sums / combine as three kernels on two streams
+#endif
 #ifndef ITAL_GEN_EARLY
 #define ITAL_GEN_EARLY 1   // decide saturated calls from the standardised limits, before COVSRT
 #endif
@@ -926,11 +929,291 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(ITAL_GEN_WA
     if (lane == 0 && d.pair_count) atomicAdd(d.pair_count, pairs);
 }
 
+// ------------------------------------------------------------------------------------------------ three-kernel pipeline
+// Plain mode with a compile-time evaluator (no subset, no clip_cov, 3 .. 6 variables: the noisy user models, the entropy
+// baseline, the first Monte-Carlo steps).  The monolithic kernel above prepares, evaluates and accumulates inside one wave
+// per candidate; at the noisy-user benchmark size it fills half of the vector issue slots (59 ms per t = 4 launch for 33 ms
+// of lattice sums at the perfect-user kernel's rate).  Here the step is three kernels over slabs of candidates, the prepared
+// calls travelling through a workspace in HBM:
+//   gen_prep_kernel     wave per candidate, lane per call   decode + closed-form update + early verdict + COVSRT + lattices;
+//                                                           calls that need a lattice sum are appended to the slab's list
+//   gen_main_kernel<T>  waves striding over that list       the lattice sums (FP64-VALU bound, the perfect-user evaluator)
+//   gen_combine_kernel  wave per candidate                  the terms in the reference's order -> mi
+// The preparation is bound by the latency of its LDS-resident per-call matrices, the lattice sums by vector issue: the two
+// run on two streams, the preparation of slab s + 1 under the lattice sums of slab s (double-buffered workspace).
+// meta[call] = (flags | n << 8 | infi << 16 | closes << 40, value): value is written by the preparation (closed forms,
+// saturated calls) or by the lattice-sum kernel.
+struct GPipe {
+    int64_t slab_lo, slab_n;   // candidate positions [slab_lo, slab_lo + slab_n) of this launch
+    int total;                 // calls per candidate
+    int R;                     // doubles per record: packed factor + limits (the evaluator's slab), then the lattices
+    int lat;                   // offset of the lattices inside a record
+    double* meta;              // [slab_n][total][2]
+    double* recs;              // [slab_n][total][R]
+    unsigned int* list;        // [slab_n * total] indices (candidate of the slab * total + call) of the calls to integrate
+    unsigned int* count;       // entries of the list
+};
+
+__device__ __forceinline__ long long pack_meta(const Prep& pp) {
+    return (long long)(pp.flags & 0xff) | ((long long)(pp.n & 0xff) << 8) | ((long long)(pp.infi & 0xffffffu) << 16) |
+           ((long long)(pp.closes & 0xffffffu) << 40);
+}
+
+// The 8 lattices of a call with the generator vector in a scratch area `gen` (LDS, n - 1 doubles), streamed out to `L`
+// (write-only: straight into the call's record in HBM).
+__device__ ITAL_GEN_NOINLINE void make_lattice_stream(const ital_gscore_desc& d, const MrgState& base, unsigned before, int n,
+                                                      double* gen, double* __restrict__ L) {
+    MrgState sti = base;
+    for (int bit = 0; before != 0; bit++, before >>= 1)
+        if (before & 1u) mrg_apply(sti, d.jump1 + bit * 18);
+    MrgStateF st = mrg_to_f(sti);
+    const int ndim = n - 1;
+    for (int j = 0; j < ndim; j++) gen[j] = d.vk[n * GN + j];
+    for (int sft = 0; sft < 8; sft++) {
+        for (int j = 1; j <= ndim - 1; j++) {
+            const double u = mrg_next_f(st);
+            const int jp = (int)(j + u * (ndim + 1 - j));
+            const double xt = gen[j - 1];
+            gen[j - 1] = gen[jp - 1];
+            gen[jp - 1] = xt;
+        }
+        for (int j = 0; j < ndim; j++) L[sft * ndim + j] = gen[j];
+        for (int j = 0; j < ndim; j++) L[8 * ndim + sft * ndim + j] = mrg_next_f(st);
+    }
+}
+
+__global__ __launch_bounds__(128) void gen_prep_kernel(GArgs a, GPipe g) {
+    extern __shared__ double lds_all[];
+    const ital_gscore_desc& d = a.d;
+    const int lane = threadIdx.x & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int64_t i = (int64_t)blockIdx.x * 2 + wid;
+    if (i >= g.slab_n) return;
+    const int64_t p = g.slab_lo + i;
+    if (!d.alive[p]) return;
+    double* W = lds_all + (size_t)wid * a.wave_doubles;
+    double* muU = W;
+    const int ldS = a.ldS;
+    double* SigU = muU + ldS;
+    int* usort = reinterpret_cast<int*>(SigU + ldS * ldS);
+    int* ipos = usort + GN;
+    double* slabs = SigU + ldS * ldS + (GN + GR + 1) / 2;
+
+    const int row = d.cand[p];
+    const int64_t gi = d.row_offset + row;
+    const int nE = d.nE;
+    const int nU = nE + 1;            // plain mode: U = batch so far + candidate
+    const int nr = d.n_picks + 1;
+    for (int idx = lane; idx < nU * nU; idx += 64) {
+        const int r = idx / nU, c = idx - r * nU;
+        double v;
+        if (r < nE && c < nE) v = d.E_sig[r * d.ldE + c];
+        else if (r == c) v = d.s2[row];                         // not clamped (gp.py:254)
+        else v = d.C[(int64_t)(r < c ? r : c) * d.ldc + row];
+        SigU[r * ldS + c] = v;
+    }
+    for (int e = lane; e < nU; e += 64) muU[e] = e < nE ? d.E_mu[e] : d.mu[row];
+    if (lane == 0) {
+        int rank = 0;
+        for (int e = 0; e < nE; e++) rank += (d.E_idx[e] < gi) ? 1 : 0;
+        for (int sidx = 0; sidx < nU; sidx++)
+            usort[sidx] = sidx < rank ? d.E_sort[sidx] : (sidx == rank ? nE : d.E_sort[sidx - 1]);
+        for (int v = 0; v < nr; v++) ipos[v] = v < d.n_picks ? d.pick_pos[v] : nE;
+    }
+    // stream position of this candidate in the reference's serial order
+    MrgState rng = {d.seed[0], d.seed[1], d.seed[2], d.seed[3], d.seed[4], d.seed[5]};
+    {
+        const int64_t gpos = d.gpos ? d.gpos[p] : d.pos_offset + p;
+        int64_t before = gpos;
+        for (int q = 0; q < d.n_dead; q++) before -= (d.dead_pos[q] < gpos) ? 1 : 0;
+        uint64_t off = (uint64_t)before * (uint64_t)d.draws_out;
+        if (d.draw_off) off = (uint64_t)d.draw_off[p];
+        for (int bit = 0; off != 0; bit++, off >>= 1)
+            if (off & 1) mrg_apply(rng, d.jump1 + bit * 18);
+    }
+    wave_sync();
+    const int npat = d.mc_rel > 0 ? d.mc_rel : (1 << nr);
+    const bool entropy = d.fb_mode == 3;
+    const int nfb = entropy ? 0 : (d.fb_mode == 0 ? 1 : (d.mc_fb > 0 ? d.mc_fb : (d.fb_mode == 1 ? (1 << nr) : pow3(nr) - 1)));
+    const int cpp = 1 + nfb;
+    const int total = npat * cpp;
+    const bool clamp_prior = nr == 1;
+    double* meta = g.meta + (size_t)i * total * 2;
+    double* recs = g.recs + (size_t)i * total * g.R;
+    for (int chunk0 = 0; chunk0 < total; chunk0 += a.chunk) {
+        Prep pp;
+        pp.n = 0; pp.infi = 0; pp.flags = 16; pp.value = 0; pp.closes = 0; pp.ng = 0; pp.gdraws = 0;
+        const int call = chunk0 + lane;
+        const bool mine = lane < a.chunk && call < total;
+        double* slab = slabs + (size_t)lane * a.stride;
+        if (mine) {
+            const CallInfo ci = decode_call(d, p, call, cpp, 1, nr, npat);
+            if (ci.kind != K_SKIP)
+                pp = prepare_call<false>(d, ci, nU, nr, ldS, muU, SigU, usort, ipos, clamp_prior, slab, slab + a.slab, nullptr);
+        }
+        // every dimension >= 3 call (evaluated or saturated) takes 8*(2*NDIM-1) uniforms from MVNUNI: lane l jumps ahead by
+        // what the calls before it in this chunk consume, the wave's base state by the chunk's total
+        const bool draws_any = pp.n >= 3 && !(pp.flags & (1 | 16));
+        const bool integrate = draws_any && !(pp.flags & 6);
+        const int my_draws = draws_any ? 8 * (2 * (pp.n - 1) - 1) : 0;
+        int incl = my_draws;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const int o = __shfl_up(incl, off, 64);
+            if (lane >= off) incl += o;
+        }
+        const int total_draws = __builtin_amdgcn_readlane(incl, 63);
+        // the calls of this pass that need a lattice sum: one slot each in the slab's list (order is irrelevant)
+        const unsigned long long em = __ballot(integrate);
+        unsigned int lbase = 0;
+        if (lane == 0 && em) lbase = atomicAdd(g.count, (unsigned int)__popcll(em));
+        lbase = (unsigned int)__builtin_amdgcn_readfirstlane((int)lbase);
+        if (mine) {
+            if (integrate) {
+                double* rec = recs + (size_t)call * g.R;
+                const int ns = pp.n * (pp.n + 1) / 2 + pp.n;
+                for (int q = 0; q < ns; q++) rec[q] = slab[q];
+                make_lattice_stream(d, rng, (unsigned)(incl - my_draws), pp.n, slab, rec + g.lat);   // the slab is free now
+                g.list[lbase + (unsigned int)__popcll(em & ((1ull << lane) - 1ull))] = (unsigned int)(i * total + call);
+            }
+            double value = pp.value;
+            if (!(pp.flags & 1) && (pp.flags & 6)) value = (pp.flags & 2) ? 1.0 : 0.0;
+            meta[2 * call] = __longlong_as_double(pack_meta(pp));
+            meta[2 * call + 1] = value;
+        }
+        unsigned adv = (unsigned)total_draws;
+        for (int bit = 0; adv != 0; bit++, adv >>= 1)
+            if (adv & 1u) mrg_apply(rng, d.jump1 + bit * 18);
+        wave_sync();
+    }
+}
+
+// Waves stride over the list of calls to integrate (a fixed grid: the length of the list is only known on the device).
+template <int T>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) void gen_main_kernel(GPipe g, unsigned long long* pair_count) {
+    extern __shared__ double lds_all[];
+    const int lane = threadIdx.x & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    double* rec = lds_all + (size_t)wid * (g.R + 256);
+    double* tailq = rec + g.R;
+    const unsigned int count = *g.count;
+    const unsigned int nwaves = gridDim.x * 4;
+    unsigned long long pairs = 0;
+    for (unsigned int e = blockIdx.x * 4 + wid; e < count; e += nwaves) {
+        const unsigned int item = g.list[e];
+        double* meta = g.meta + (size_t)item * 2;
+        const long long m = __double_as_longlong(uniform_f64(meta[0]));
+        const int n = (int)((m >> 8) & 0xff);
+        const unsigned infi = (unsigned)((m >> 16) & 0xffffffu), closes = (unsigned)((m >> 40) & 0xffffffu);
+        const double* src = g.recs + (size_t)item * g.R;
+        const int ns = n * (n + 1) / 2 + n;
+        for (int q = lane; q < ns; q += 64) rec[q] = src[q];
+        for (int q = lane; q < 16 * (n - 1); q += 64) rec[g.lat + q] = src[g.lat + q];
+        wave_sync();
+        double value;
+        if (n == T && closes == (1u << T) - 1u)
+            value = qmc_eval_fixed<T>(rec, infi, rec + g.lat, lane, tailq);
+        else
+            value = qmc_eval<6, 2>(n, rec, infi, closes, rec + g.lat, lane, tailq);   // linearly dependent variables
+        if (lane == 0) meta[1] = value;
+        pairs += 16ull * P_TAB[(n - 1 < 10 ? n - 1 : 10) - 1] * (n - 1);
+        wave_sync();
+    }
+    if (lane == 0 && pair_count && pairs) atomicAdd(pair_count, pairs);
+}
+
+// Wave per candidate: the lanes form the terms of 64 calls at a time, lane 0's order-preserving fold adds them up exactly
+// as the reference's loop does (ital.py:207-222).
+__global__ __launch_bounds__(256) void gen_combine_kernel(GArgs a, GPipe g) {
+    const ital_gscore_desc& d = a.d;
+    const int lane = threadIdx.x & 63;
+    const int64_t i = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (i >= g.slab_n) return;
+    const int64_t p = g.slab_lo + i;
+    if (!d.alive[p]) return;
+    const int nr = d.n_picks + 1;
+    const int npat = d.mc_rel > 0 ? d.mc_rel : (1 << nr);
+    const bool entropy = d.fb_mode == 3;
+    const int nfb = entropy ? 0 : (d.fb_mode == 0 ? 1 : (d.mc_fb > 0 ? d.mc_fb : (d.fb_mode == 1 ? (1 << nr) : pow3(nr) - 1)));
+    const int cpp = 1 + nfb;
+    const int total = npat * cpp;
+    const double* meta = g.meta + (size_t)i * total * 2;
+    double mi = 0.0;
+    for (int c0 = 0; c0 < total; c0 += 64) {
+        const int call = c0 + lane;
+        // kind of term this lane contributes: 0 none, 1 updated-call term (mean / sampled), 2 entropy term, 3 single entropy
+        int kind = 0;
+        double term = 0.0;
+        if (call < total) {
+            const int fl = (int)(__double_as_longlong(meta[2 * call]) & 0xff);
+            if (!(fl & 16)) {
+                const double value = meta[2 * call + 1];
+                const CallInfo ci = decode_call(d, p, call, cpp, 1, nr, npat);
+                if (entropy) {
+                    if (nr == 1) {
+                        if (ci.pat == 0) {
+                            const double q = fmax(1e-8, fmin(1.0 - 1e-8, value));
+                            term = q * log(q) + (1.0 - q) * log(1.0 - q);
+                            kind = 3;
+                        }
+                    } else if (value > 1e-12) {
+                        term = value * log(value);
+                        kind = 2;
+                    }
+                } else if (ci.kind == K_UPDATED) {
+                    const double pr = meta[2 * (call / cpp) * cpp + 1];       // the pattern's prior probability
+                    const double cur = (log(value + d.eps) - log(pr + d.eps)) * ci.weight;
+                    term = (d.label_mode != 0 || d.mc_rel > 0) ? cur : cur * pr;   // sampled patterns are not weighted
+                    kind = 1;
+                }
+            }
+        }
+        for (int l = 0; l < 64 && c0 + l < total; l++) {
+            const int k_l = __builtin_amdgcn_readlane(kind, l);
+            if (k_l == 0) continue;
+            const double t_l = readlane_f64(term, l);
+            if (k_l == 3) mi = t_l;
+            else if (k_l == 2) mi += t_l;
+            else if (d.label_mode == 1) { if (t_l > mi) mi = t_l; }
+            else if (d.label_mode == 2) { if (mi == 0 || t_l < mi) mi = t_l; }
+            else mi += t_l;
+        }
+    }
+    if (d.mc_rel > 0) mi /= d.mc_rel;   // ital.py:221-222
+    if (entropy) mi = -mi;
+    if (lane == 0) d.mi[p] = mi;
+}
+
 }  // namespace ital
 
 using namespace ital;
 
 static int fs_doubles(int nr) { return nr * nr + 2 * nr; }
+
+// Streams and events of the pipeline (one set per device of the process, created on first use).
+struct PipeStreams {
+    hipStream_t prep, main;
+    hipEvent_t start, prep_done[2], main_done[2];
+};
+
+static PipeStreams* pipe_streams() {
+    static PipeStreams sets[16];
+    static bool made[16] = {};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return nullptr;
+    if (!made[dev]) {
+        PipeStreams& p = sets[dev];
+        bool ok = hipStreamCreateWithFlags(&p.prep, hipStreamNonBlocking) == hipSuccess &&
+                  hipStreamCreateWithFlags(&p.main, hipStreamNonBlocking) == hipSuccess &&
+                  hipEventCreateWithFlags(&p.start, hipEventDisableTiming) == hipSuccess;
+        for (int q = 0; q < 2 && ok; q++)
+            ok = hipEventCreateWithFlags(&p.prep_done[q], hipEventDisableTiming) == hipSuccess &&
+                 hipEventCreateWithFlags(&p.main_done[q], hipEventDisableTiming) == hipSuccess;
+        if (!ok) return nullptr;
+        made[dev] = true;
+    }
+    return &sets[dev];
+}
 
 extern "C" int ital_score_generic(const ital_gscore_desc* d, hipStream_t stream) {
     if (!d) return ital_fail(-22, "ital_score_generic: null descriptor");
@@ -977,6 +1260,69 @@ extern "C" int ital_score_generic(const ital_gscore_desc* d, hipStream_t stream)
     const int64_t blocks = (d->n_cand + 1) / 2;
     // plain mode (no subset): every call of dimension >= 3 has dimension n_picks + 1 -> compile-time evaluator
     const int tfix = (!d->subset_mode && nUmax >= 3 && nUmax <= 6) ? nUmax : 0;
+    // ---- three-kernel pipeline: plain mode with a compile-time evaluator, slabs of candidates through the workspace
+    {
+        double npat = d->mc_rel > 0 ? (double)d->mc_rel : pow(2.0, nr);
+        double nfb = d->fb_mode == 3 ? 0.0 : d->fb_mode == 0 ? 1.0 : (d->mc_fb > 0 ? (double)d->mc_fb : (d->fb_mode == 1 ? pow(2.0, nr) : pow(3.0, nr) - 1));
+        const int64_t total = (int64_t)(npat * (1 + nfb));
+        GPipe g;
+        g.total = (int)total;
+        g.lat = nUmax * (nUmax + 1) / 2 + nUmax;
+        g.R = g.lat + 16 * (nUmax - 1);
+        const int64_t per_cand = total * (2 + (int64_t)g.R) + (total + 1) / 2;      // meta, records, list entries
+        const int64_t half = d->work_doubles / 2 - 1;                                // two buffers, a counter each
+        if (ITAL_GEN_PIPELINE && tfix != 0 && !clip && !d->draw_count && d->work && half >= per_cand) {
+            PipeStreams* ps = pipe_streams();
+            if (!ps) return ital_fail(-12, "ital_score_generic: cannot create the pipeline's streams");
+            int64_t S = half / per_cand;
+            if (S > d->n_cand) S = d->n_cand;
+            while (S * total > (int64_t)1 << 31) S >>= 1;     // 32-bit list entries
+            GArgs ap = a;
+            int stride_p = (slab + fs_doubles(nr)) | 1;
+            int chunk_p = 64;
+            while (chunk_p > 4 && chunk_p * stride_p > 6144) chunk_p >>= 1;   // <= 48 KB of call slabs per wave
+            ap.chunk = chunk_p;
+            ap.stride = stride_p;
+            ap.master = 0;
+            ap.wave_doubles = fixed + chunk_p * stride_p;
+            const size_t lds_p = (size_t)2 * ap.wave_doubles * sizeof(double);
+            const size_t lds_m = (size_t)4 * (g.R + 256) * sizeof(double);
+            if (lds_p > 64 * 1024) return ital_fail(-12, "ital_score_generic: LDS budget exceeded");
+            if (hipEventRecord(ps->start, stream) != hipSuccess || hipStreamWaitEvent(ps->prep, ps->start, 0) != hipSuccess ||
+                hipStreamWaitEvent(ps->main, ps->start, 0) != hipSuccess)
+                return ital_fail(-5, "ital_score_generic: stream synchronisation failed");
+            int nslab = 0;
+            for (int64_t lo = 0; lo < d->n_cand; lo += S, nslab++) {
+                const int buf = nslab & 1;
+                double* base = d->work + (size_t)buf * (half + 1);
+                g.slab_lo = lo;
+                g.slab_n = d->n_cand - lo < S ? d->n_cand - lo : S;
+                g.count = reinterpret_cast<unsigned int*>(base);
+                g.meta = base + 1;
+                g.recs = g.meta + g.slab_n * total * 2;
+                g.list = reinterpret_cast<unsigned int*>(g.recs + g.slab_n * total * g.R);
+                if (nslab >= 2) (void)hipStreamWaitEvent(ps->prep, ps->main_done[buf], 0);   // the buffer is free again
+                (void)hipMemsetAsync(g.count, 0, sizeof(unsigned int), ps->prep);
+                hipLaunchKernelGGL(gen_prep_kernel, dim3((unsigned)((g.slab_n + 1) / 2)), dim3(128), lds_p, ps->prep, ap, g);
+                (void)hipEventRecord(ps->prep_done[buf], ps->prep);
+                (void)hipStreamWaitEvent(ps->main, ps->prep_done[buf], 0);
+                const unsigned mb = 768;     // 3 workgroups of 4 waves per CU; the waves stride over the slab's list
+                switch (tfix) {
+                    case 3: hipLaunchKernelGGL(gen_main_kernel<3>, dim3(mb), dim3(256), lds_m, ps->main, g, d->pair_count); break;
+                    case 4: hipLaunchKernelGGL(gen_main_kernel<4>, dim3(mb), dim3(256), lds_m, ps->main, g, d->pair_count); break;
+                    case 5: hipLaunchKernelGGL(gen_main_kernel<5>, dim3(mb), dim3(256), lds_m, ps->main, g, d->pair_count); break;
+                    default: hipLaunchKernelGGL(gen_main_kernel<6>, dim3(mb), dim3(256), lds_m, ps->main, g, d->pair_count); break;
+                }
+                hipLaunchKernelGGL(gen_combine_kernel, dim3((unsigned)((g.slab_n + 3) / 4)), dim3(256), 0, ps->main, ap, g);
+                (void)hipEventRecord(ps->main_done[buf], ps->main);
+                int rc = ital_check_launch("ital_score_generic(pipeline)");
+                if (rc) return rc;
+            }
+            (void)hipStreamWaitEvent(stream, ps->main_done[0], 0);
+            if (nslab >= 2) (void)hipStreamWaitEvent(stream, ps->main_done[1], 0);
+            return 0;
+        }
+    }
 #define ITAL_GEN_LAUNCH(NMAX_, NH_, TFIX_, CLIP_)                                                                             \
     do {                                                                                                               \
         static bool attr_done = false;                                                                                 \

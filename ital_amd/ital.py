@@ -444,6 +444,16 @@ class ITAL(ActiveRetrievalBase):
                 desc.draws_out, desc.draws_in = draws_out, draws_in
                 desc.mi, desc.status = _ptr(mi), _ptr(gp.status)
                 desc.pair_count = _ptr(self.pair_counter)
+                if not subset_mode and not self._clip_active() and 3 <= nE + 1 <= 6:
+                    # workspace of the three-kernel pipeline: two buffers of prepared calls (slabs of candidates)
+                    n_u = nE + 1
+                    calls = npat * (1 + nfb)
+                    per_cand = calls * (3 + n_u * (n_u + 1) // 2 + n_u + 16 * (n_u - 1))
+                    want = min(2 * per_cand * max(n_loc, 1) + 4, max(self.qmc_work_bytes // 8, 2 * per_cand + 4))
+                    w = b.get("qmc_work")
+                    if w is None or w.numel() < want:
+                        b["qmc_work"] = w = torch.empty(want, dtype=torch.float64, device=dev)
+                    desc.work, desc.work_doubles = _ptr(w), w.numel()
                 total_draws = None
                 if mc is not None:
                     rel_arr, fb_arr, draws_pp = mc          # per list position (dead positions hold zeros)

@@ -157,7 +157,7 @@ def test_ctypes_structs_have_the_layout_of_the_header(tmp_path):
     probes = {"ital_batch": (_lib.ItalBatch, ["kmax", "bidx", "VB"]),
               "ital_score_desc": (_lib.ItalScoreDesc, ["t", "gpos", "batch", "label_mode", "seed", "jumppat", "status", "work", "work_doubles", "ev_stop"]),
               "ital_gscore_desc": (_lib.ItalGscoreDesc, ["n_cand", "gpos", "nE", "ldE", "pick_pos", "label_prob", "clip_cov", "seed",
-                                                         "draws_in", "dead_pos", "fb_samples", "draw_count", "status", "pair_count"]),
+                                                         "draws_in", "dead_pos", "fb_samples", "draw_count", "status", "work_doubles", "pair_count"]),
               "ital_mcmi_desc": (_lib.ItalMcmiDesc, ["t", "alive", "ld_cov", "batch", "ce"])}
     lines = []
     for name, (_, fields) in probes.items():
