@@ -1280,14 +1280,21 @@ extern "C" int ital_score_generic(const ital_gscore_desc* d, hipStream_t stream)
             GArgs ap = a;
             int stride_p = (slab + fs_doubles(nr)) | 1;
             int chunk_p = 64;
-            while (chunk_p > 4 && chunk_p * stride_p > 6144) chunk_p >>= 1;   // <= 48 KB of call slabs per wave
+            while (chunk_p > 4 && chunk_p * stride_p > 4096) chunk_p >>= 1;   // <= 32 KB of call slabs per wave
             ap.chunk = chunk_p;
             ap.stride = stride_p;
             ap.master = 0;
             ap.wave_doubles = fixed + chunk_p * stride_p;
             const size_t lds_p = (size_t)2 * ap.wave_doubles * sizeof(double);
             const size_t lds_m = (size_t)4 * (g.R + 256) * sizeof(double);
-            if (lds_p > 64 * 1024) return ital_fail(-12, "ital_score_generic: LDS budget exceeded");
+            static bool prep_attr = false;
+            if (!prep_attr) {
+                if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gen_prep_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                        160 * 1024) != hipSuccess)
+                    return ital_fail(-12, "ital_score_generic: cannot raise the dynamic LDS limit");
+                prep_attr = true;
+            }
+            if (lds_p > 160 * 1024) return ital_fail(-12, "ital_score_generic: LDS budget exceeded");
             if (hipEventRecord(ps->start, stream) != hipSuccess || hipStreamWaitEvent(ps->prep, ps->start, 0) != hipSuccess ||
                 hipStreamWaitEvent(ps->main, ps->start, 0) != hipSuccess)
                 return ital_fail(-5, "ital_score_generic: stream synchronisation failed");
