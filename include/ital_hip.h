@@ -274,7 +274,7 @@ typedef struct ital_gscore_desc {
     double* mi;             /* [n_cand] out */
     int* status;
     double* work;           /* workspace in device memory (work_doubles doubles; ital_amd reuses the lattice scorer's).  Without a
-                               subset and clip_cov, for 3 .. 6 variables, and with room for two buffers of at least one
+                               subset and clip_cov, for 3 .. 16 variables, and with room for two buffers of at least one
                                candidate's prepared calls each -- calls x (2.5 + n(n+1)/2 + n + 16(n-1)) doubles, n = nE + 1 -- the
                                step runs as three kernels (prepare / lattice sums / combine) over slabs of candidates, the
                                preparation of a slab under the lattice sums of the one before (two internal streams, joined

@@ -188,4 +188,83 @@ __device__ __forceinline__ double qmc_lane_sum(const double* __restrict__ lat,
     return acc;
 }
 
+// The same lattice sum for larger compile-time dimensions (T = 7 .. 16: the Monte-Carlo pattern switch keeps batches of
+// up to 16 feasible): the factor (T(T-1)/2 wave-uniform values, 120 at T = 16) no longer fits registers and is read from
+// LDS at use (`slab`: packed lower triangle with diagonal, then the limits -- the evaluator's record), the lattice
+// coordinates are formed per stage instead of up front; the conditioned values y (2 NH chains x T-1) stay in registers
+// because every index is a compile-time constant.
+template <int T, int NCB>
+__device__ __forceinline__ double eval_chains_big(const int (&kk)[(NCB + 1) / 2], const int (&so)[(NCB + 1) / 2],
+                                                  const bool (&okh)[(NCB + 1) / 2], const double* __restrict__ lat,
+                                                  const double* __restrict__ slab, unsigned infi_c, double* tailq, int lane) {
+    constexpr int NDIM = T - 1, NCOV = T * (T + 1) / 2;
+    double yy[NCB][NDIM], ff[NCB];
+#pragma unroll
+    for (int c = 0; c < NCB; c++) ff[c] = okh[c >> 1] ? 1.0 : 0.0;
+#pragma unroll
+    for (int i = 0; i < T; i++) {
+        const bool lower = (infi_c >> i) & 1u;
+        __asm__ volatile("" ::: "memory");   // keeps this row's factor loads here: hoisted out of the lattice loop they
+                                             // would occupy T(T+1)/2 register pairs
+        const double lmi = slab[NCOV + i];
+        double sc[NCB];
+#pragma unroll
+        for (int c = 0; c < NCB; c++) sc[c] = 0;
+#pragma unroll
+        for (int j = 0; j < i; j++) {
+            const double cij = slab[i * (i + 1) / 2 + j];
+#pragma unroll
+            for (int c = 0; c < NCB; c++) sc[c] = fma(cij, yy[c][j], sc[c]);
+        }
+        double pin[NCB];
+#pragma unroll
+        for (int c = 0; c < NCB; c++) {
+            const double ph = mvn_phi(lmi - sc[c]);
+            const double d = lower ? ph : 0.0;
+            const double w = lower ? 1.0 - ph : ph;
+            ff[c] *= w;
+            if (i < T - 1) {
+                const int h = c >> 1;
+                const double v = kk[h] * lat[so[h] + i] + lat[8 * NDIM + so[h] + i];
+                const double fr = v - floor(v);
+                const double x0 = fabs(2 * fr - 1);
+                pin[c] = fma((c & 1) ? 1 - x0 : x0, w, d);
+            }
+        }
+        if (i < T - 1) {
+            double out[NCB];
+            phinv_wave<NCB>(pin, out, tailq, lane);
+#pragma unroll
+            for (int c = 0; c < NCB; c++) yy[c][i] = out[c];
+        }
+    }
+    double acc = 0.0;
+#pragma unroll
+    for (int c = 0; c < NCB; c++) acc += ff[c];
+    return acc;
+}
+
+template <int T, int NH>
+__device__ __forceinline__ double qmc_lane_sum_big(const double* __restrict__ lat, const double* __restrict__ slab,
+                                                   unsigned infi_c, double* __restrict__ tailq, int lane) {
+    constexpr int NDIM = T - 1, PRIME = P_TAB[(NDIM < 10 ? NDIM : 10) - 1];
+    constexpr int NC = 2 * NH, NITEM = 8 * PRIME;
+    double acc = 0.0;
+    for (int base = 0; base < NITEM; base += 64 * NH) {
+        int kk[NH], so[NH];
+        bool okh[NH];
+#pragma unroll
+        for (int h = 0; h < NH; h++) {
+            const int item = base + 64 * h + lane;
+            okh[h] = item < NITEM;
+            const int it = okh[h] ? item : 0;
+            const int sft = it / PRIME;
+            kk[h] = it - sft * PRIME + 1;
+            so[h] = sft * NDIM;
+        }
+        acc += eval_chains_big<T, NC>(kk, so, okh, lat, slab, infi_c, tailq, lane);
+    }
+    return acc;
+}
+
 }  // namespace ital

@@ -47,8 +47,21 @@
 #define ITAL_GEN_HOTK 1   // exp / log coefficients of the compile-time-dimension evaluator as vector-register operands (HotK:
                           // 197 -> 20 spilled VGPRs, 385 -> 193 spilled SGPRs in the t = 4 instantiation; noisy-user step 61.8 -> 59.1 ms)
 #endif
+#ifndef ITAL_GEN_BIG_NH
+#define ITAL_GEN_BIG_NH 1      // lattice items per lane and round of the compile-time evaluator for 7 .. 16 variables
+#endif
+#ifndef ITAL_GEN_MAIN_WAVES
+#define ITAL_GEN_MAIN_WAVES(T) ((T) > 0 && (T) < 10 ? 3 : 2)   // measured: from 10 variables on three waves per SIMD spill
+                                                               // (C5' share 65 s against 22 s)
+#endif
+#ifndef ITAL_GEN_TFIX_MAX
+#define ITAL_GEN_TFIX_MAX 16   // largest dimension the pipeline takes (plain mode)
+#endif
+#ifndef ITAL_GEN_PREP_SPLIT
+#define ITAL_GEN_PREP_SPLIT 4   // preparation waves per candidate in the pipeline
+#endif
 #ifndef ITAL_GEN_PIPELINE
-#define ITAL_GEN_PIPELINE 1   // plain mode, 3 .. 6 variables: prepare / lattice sums / combine as three kernels on two streams
+#define ITAL_GEN_PIPELINE 1   // plain mode, 3 .. 16 variables: prepare / lattice sums / combine as three kernels on streams of their own
 #endif
 #ifndef ITAL_GEN_EARLY
 #define ITAL_GEN_EARLY 1   // decide saturated calls from the standardised limits, before COVSRT
@@ -654,8 +667,8 @@ __device__ double qmc_eval(int n, const double* __restrict__ slab, unsigned infi
 // variable): the evaluator of the perfect-user fast path (score.hip) -- factor and limits as wave-uniform scalars, fully
 // unrolled, 2 lattice items x antithetic partner per lane.
 template <int T>
-__device__ double qmc_eval_fixed(const double* __restrict__ slab, unsigned infi, const double* __restrict__ lat, int lane,
-                                 double* __restrict__ tailq) {
+__device__ __forceinline__ double qmc_eval_fixed_inl(const double* __restrict__ slab, unsigned infi,
+                                                     const double* __restrict__ lat, int lane, double* __restrict__ tailq) {
     constexpr int NDIM = T - 1, NCOV = T * (T + 1) / 2, NCOR = T * (T - 1) / 2;
     constexpr int PRIME = P_TAB[(NDIM < 10 ? NDIM : 10) - 1];
     double cf[NCOR > 0 ? NCOR : 1], lm[T];
@@ -673,6 +686,12 @@ __device__ double qmc_eval_fixed(const double* __restrict__ slab, unsigned infi,
     const double acc = qmc_lane_sum<T>(lat, cf, lm, infi, tailq, lane);
 #endif
     return wave_sum(acc) / (16.0 * PRIME);
+}
+
+template <int T>
+__device__ double qmc_eval_fixed(const double* __restrict__ slab, unsigned infi, const double* __restrict__ lat, int lane,
+                                 double* __restrict__ tailq) {
+    return qmc_eval_fixed_inl<T>(slab, infi, lat, lane, tailq);
 }
 
 __device__ __forceinline__ void wave_sync() {
@@ -930,8 +949,8 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(ITAL_GEN_WA
 }
 
 // ------------------------------------------------------------------------------------------------ three-kernel pipeline
-// Plain mode with a compile-time evaluator (no subset, no clip_cov, 3 .. 6 variables: the noisy user models, the entropy
-// baseline, the first Monte-Carlo steps).  The monolithic kernel above prepares, evaluates and accumulates inside one wave
+// Plain mode with a compile-time evaluator (no subset, no clip_cov, 3 .. 16 variables: the noisy user models, the entropy
+// baseline, the Monte-Carlo pattern switch up to batches of 16).  The monolithic kernel above prepares, evaluates and accumulates inside one wave
 // per candidate; at the noisy-user benchmark size it fills half of the vector issue slots (59 ms per t = 4 launch for 33 ms
 // of lattice sums at the perfect-user kernel's rate).  Here the step is three kernels over slabs of candidates, the prepared
 // calls travelling through a workspace in HBM:
@@ -940,7 +959,8 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(ITAL_GEN_WA
 //   gen_main_kernel<T>  waves striding over that list       the lattice sums (FP64-VALU bound, the perfect-user evaluator)
 //   gen_combine_kernel  wave per candidate                  the terms in the reference's order -> mi
 // The preparation is bound by the latency of its LDS-resident per-call matrices, the lattice sums by vector issue: the two
-// run on two streams, the preparation of slab s + 1 under the lattice sums of slab s (double-buffered workspace).
+// run on streams of their own, the preparation of slab s + 1 and the combine of slab s - 1 under the lattice sums of slab s
+// (double-buffered workspace).
 // meta[call] = (flags | n << 8 | infi << 16 | closes << 40, value): value is written by the preparation (closed forms,
 // saturated calls) or by the lattice-sum kernel.
 struct GPipe {
@@ -950,8 +970,11 @@ struct GPipe {
     int lat;                   // offset of the lattices inside a record
     double* meta;              // [slab_n][total][2]
     double* recs;              // [slab_n][total][R]
-    unsigned int* list;        // [slab_n * total] indices (candidate of the slab * total + call) of the calls to integrate
-    unsigned int* count;       // entries of the list
+    unsigned int* list;        // [slab_n * total] indices (candidate of the slab * total + call) of the calls to integrate:
+                               // regular ones from the front, the ones with linearly dependent variables from the back
+    unsigned int* count;       // [2] entries from the front / from the back
+    int nsplit;                // waves a candidate's calls are spread over in the preparation (1 when the stream offsets of the
+                               // calls depend on the data: skipped all-zero feedback samples)
 };
 
 __device__ __forceinline__ long long pack_meta(const Prep& pp) {
@@ -987,7 +1010,9 @@ __global__ __launch_bounds__(128) void gen_prep_kernel(GArgs a, GPipe g) {
     const ital_gscore_desc& d = a.d;
     const int lane = threadIdx.x & 63;
     const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int64_t i = (int64_t)blockIdx.x * 2 + wid;
+    const int64_t item = (int64_t)blockIdx.x * 2 + wid;
+    const int64_t i = item / g.nsplit;
+    const int part = (int)(item - i * g.nsplit);
     if (i >= g.slab_n) return;
     const int64_t p = g.slab_lo + i;
     if (!d.alive[p]) return;
@@ -1020,7 +1045,16 @@ __global__ __launch_bounds__(128) void gen_prep_kernel(GArgs a, GPipe g) {
             usort[sidx] = sidx < rank ? d.E_sort[sidx] : (sidx == rank ? nE : d.E_sort[sidx - 1]);
         for (int v = 0; v < nr; v++) ipos[v] = v < d.n_picks ? d.pick_pos[v] : nE;
     }
-    // stream position of this candidate in the reference's serial order
+    const int npat = d.mc_rel > 0 ? d.mc_rel : (1 << nr);
+    const bool entropy = d.fb_mode == 3;
+    const int nfb = entropy ? 0 : (d.fb_mode == 0 ? 1 : (d.mc_fb > 0 ? d.mc_fb : (d.fb_mode == 1 ? (1 << nr) : pow3(nr) - 1)));
+    const int cpp = 1 + nfb;
+    const int total = npat * cpp;
+    // this wave's share of the candidate's calls: whole passes of a.chunk calls
+    const int npass = (total + a.chunk - 1) / a.chunk;
+    const int pass_lo = (int)((int64_t)npass * part / g.nsplit), pass_hi = (int)((int64_t)npass * (part + 1) / g.nsplit);
+    // stream position of this candidate in the reference's serial order, then of the share's first call (with more than one
+    // share every call draws the same 8 (2 (nU - 1) - 1) uniforms: no skipped samples)
     MrgState rng = {d.seed[0], d.seed[1], d.seed[2], d.seed[3], d.seed[4], d.seed[5]};
     {
         const int64_t gpos = d.gpos ? d.gpos[p] : d.pos_offset + p;
@@ -1028,19 +1062,15 @@ __global__ __launch_bounds__(128) void gen_prep_kernel(GArgs a, GPipe g) {
         for (int q = 0; q < d.n_dead; q++) before -= (d.dead_pos[q] < gpos) ? 1 : 0;
         uint64_t off = (uint64_t)before * (uint64_t)d.draws_out;
         if (d.draw_off) off = (uint64_t)d.draw_off[p];
+        off += (uint64_t)pass_lo * (uint64_t)a.chunk * (uint64_t)(nU >= 3 ? 8 * (2 * (nU - 1) - 1) : 0);
         for (int bit = 0; off != 0; bit++, off >>= 1)
             if (off & 1) mrg_apply(rng, d.jump1 + bit * 18);
     }
     wave_sync();
-    const int npat = d.mc_rel > 0 ? d.mc_rel : (1 << nr);
-    const bool entropy = d.fb_mode == 3;
-    const int nfb = entropy ? 0 : (d.fb_mode == 0 ? 1 : (d.mc_fb > 0 ? d.mc_fb : (d.fb_mode == 1 ? (1 << nr) : pow3(nr) - 1)));
-    const int cpp = 1 + nfb;
-    const int total = npat * cpp;
     const bool clamp_prior = nr == 1;
     double* meta = g.meta + (size_t)i * total * 2;
     double* recs = g.recs + (size_t)i * total * g.R;
-    for (int chunk0 = 0; chunk0 < total; chunk0 += a.chunk) {
+    for (int chunk0 = pass_lo * a.chunk; chunk0 < pass_hi * a.chunk && chunk0 < total; chunk0 += a.chunk) {
         Prep pp;
         pp.n = 0; pp.infi = 0; pp.flags = 16; pp.value = 0; pp.closes = 0; pp.ng = 0; pp.gdraws = 0;
         const int call = chunk0 + lane;
@@ -1063,18 +1093,24 @@ __global__ __launch_bounds__(128) void gen_prep_kernel(GArgs a, GPipe g) {
             if (lane >= off) incl += o;
         }
         const int total_draws = __builtin_amdgcn_readlane(incl, 63);
-        // the calls of this pass that need a lattice sum: one slot each in the slab's list (order is irrelevant)
-        const unsigned long long em = __ballot(integrate);
-        unsigned int lbase = 0;
+        // the calls of this pass that need a lattice sum: one slot each in the slab's list (order is irrelevant); the rare
+        // ones with linearly dependent variables (MVNDFN's grouped limits: the runtime evaluator) fill it from the back
+        const bool regular = integrate && pp.closes == (1u << pp.n) - 1u;
+        const unsigned long long em = __ballot(regular), cm = __ballot(integrate && !regular);
+        unsigned int lbase = 0, cbase = 0;
         if (lane == 0 && em) lbase = atomicAdd(g.count, (unsigned int)__popcll(em));
+        if (lane == 0 && cm) cbase = atomicAdd(g.count + 1, (unsigned int)__popcll(cm));
         lbase = (unsigned int)__builtin_amdgcn_readfirstlane((int)lbase);
+        cbase = (unsigned int)__builtin_amdgcn_readfirstlane((int)cbase);
         if (mine) {
             if (integrate) {
                 double* rec = recs + (size_t)call * g.R;
                 const int ns = pp.n * (pp.n + 1) / 2 + pp.n;
                 for (int q = 0; q < ns; q++) rec[q] = slab[q];
                 make_lattice_stream(d, rng, (unsigned)(incl - my_draws), pp.n, slab, rec + g.lat);   // the slab is free now
-                g.list[lbase + (unsigned int)__popcll(em & ((1ull << lane) - 1ull))] = (unsigned int)(i * total + call);
+                const unsigned int id = (unsigned int)(i * total + call);
+                if (regular) g.list[lbase + (unsigned int)__popcll(em & ((1ull << lane) - 1ull))] = id;
+                else g.list[(unsigned int)(g.slab_n * total) - 1u - cbase - (unsigned int)__popcll(cm & ((1ull << lane) - 1ull))] = id;
             }
             double value = pp.value;
             if (!(pp.flags & 1) && (pp.flags & 6)) value = (pp.flags & 2) ? 1.0 : 0.0;
@@ -1089,32 +1125,38 @@ __global__ __launch_bounds__(128) void gen_prep_kernel(GArgs a, GPipe g) {
 }
 
 // Waves stride over the list of calls to integrate (a fixed grid: the length of the list is only known on the device).
+// T > 0: the regular calls (T variables, every row closes its own group) with the compile-time evaluator; T == 0: the calls
+// with linearly dependent variables, from the back of the list, with the runtime one.
 template <int T>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) void gen_main_kernel(GPipe g, unsigned long long* pair_count) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(ITAL_GEN_MAIN_WAVES(T), ITAL_GEN_MAIN_WAVES(T)))) void gen_main_kernel(
+    GPipe g, unsigned long long* pair_count) {
     extern __shared__ double lds_all[];
     const int lane = threadIdx.x & 63;
     const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     double* rec = lds_all + (size_t)wid * (g.R + 256);
     double* tailq = rec + g.R;
-    const unsigned int count = *g.count;
+    const unsigned int count = g.count[T > 0 ? 0 : 1];
+    const unsigned int last = (unsigned int)(g.slab_n * g.total) - 1u;
     const unsigned int nwaves = gridDim.x * 4;
     unsigned long long pairs = 0;
     for (unsigned int e = blockIdx.x * 4 + wid; e < count; e += nwaves) {
-        const unsigned int item = g.list[e];
+        const unsigned int item = g.list[T > 0 ? e : last - e];
         double* meta = g.meta + (size_t)item * 2;
         const long long m = __double_as_longlong(uniform_f64(meta[0]));
         const int n = (int)((m >> 8) & 0xff);
-        const unsigned infi = (unsigned)((m >> 16) & 0xffffffu), closes = (unsigned)((m >> 40) & 0xffffffu);
+        const unsigned infi = (unsigned)((m >> 16) & 0xffffffu);
         const double* src = g.recs + (size_t)item * g.R;
         const int ns = n * (n + 1) / 2 + n;
         for (int q = lane; q < ns; q += 64) rec[q] = src[q];
         for (int q = lane; q < 16 * (n - 1); q += 64) rec[g.lat + q] = src[g.lat + q];
         wave_sync();
         double value;
-        if (n == T && closes == (1u << T) - 1u)
-            value = qmc_eval_fixed<T>(rec, infi, rec + g.lat, lane, tailq);
-        else
-            value = qmc_eval<6, 2>(n, rec, infi, closes, rec + g.lat, lane, tailq);   // linearly dependent variables
+        if (T >= 7) {
+            constexpr int TB = T >= 7 ? T : 7, NDIMB = TB - 1;
+            value = wave_sum(qmc_lane_sum_big<TB, ITAL_GEN_BIG_NH>(rec + g.lat, rec, infi, tailq, lane)) /
+                    (16.0 * P_TAB[(NDIMB < 10 ? NDIMB : 10) - 1]);
+        } else if (T > 0) value = qmc_eval_fixed_inl<(T > 0 && T < 7 ? T : 3)>(rec, infi, rec + g.lat, lane, tailq);
+        else value = qmc_eval<ITAL_GENERIC_MAX_DIM, 1>(n, rec, infi, (unsigned)((m >> 40) & 0xffffffu), rec + g.lat, lane, tailq);
         if (lane == 0) meta[1] = value;
         pairs += 16ull * P_TAB[(n - 1 < 10 ? n - 1 : 10) - 1] * (n - 1);
         wave_sync();
@@ -1192,8 +1234,8 @@ static int fs_doubles(int nr) { return nr * nr + 2 * nr; }
 
 // Streams and events of the pipeline (one set per device of the process, created on first use).
 struct PipeStreams {
-    hipStream_t prep, main;
-    hipEvent_t start, prep_done[2], main_done[2];
+    hipStream_t prep, main, comb;
+    hipEvent_t start, prep_done[2], main_done[2], comb_done[2];
 };
 
 static PipeStreams* pipe_streams() {
@@ -1205,10 +1247,12 @@ static PipeStreams* pipe_streams() {
         PipeStreams& p = sets[dev];
         bool ok = hipStreamCreateWithFlags(&p.prep, hipStreamNonBlocking) == hipSuccess &&
                   hipStreamCreateWithFlags(&p.main, hipStreamNonBlocking) == hipSuccess &&
+                  hipStreamCreateWithFlags(&p.comb, hipStreamNonBlocking) == hipSuccess &&
                   hipEventCreateWithFlags(&p.start, hipEventDisableTiming) == hipSuccess;
         for (int q = 0; q < 2 && ok; q++)
             ok = hipEventCreateWithFlags(&p.prep_done[q], hipEventDisableTiming) == hipSuccess &&
-                 hipEventCreateWithFlags(&p.main_done[q], hipEventDisableTiming) == hipSuccess;
+                 hipEventCreateWithFlags(&p.main_done[q], hipEventDisableTiming) == hipSuccess &&
+                 hipEventCreateWithFlags(&p.comb_done[q], hipEventDisableTiming) == hipSuccess;
         if (!ok) return nullptr;
         made[dev] = true;
     }
@@ -1271,7 +1315,8 @@ extern "C" int ital_score_generic(const ital_gscore_desc* d, hipStream_t stream)
         g.R = g.lat + 16 * (nUmax - 1);
         const int64_t per_cand = total * (2 + (int64_t)g.R) + (total + 1) / 2;      // meta, records, list entries
         const int64_t half = d->work_doubles / 2 - 1;                                // two buffers, a counter each
-        if (ITAL_GEN_PIPELINE && tfix != 0 && !clip && !d->draw_count && d->work && half >= per_cand) {
+        const int tfix_p = (!d->subset_mode && nUmax >= 3 && nUmax <= ITAL_GEN_TFIX_MAX) ? nUmax : 0;
+        if (ITAL_GEN_PIPELINE && tfix_p != 0 && !clip && !d->draw_count && d->work && half >= per_cand) {
             PipeStreams* ps = pipe_streams();
             if (!ps) return ital_fail(-12, "ital_score_generic: cannot create the pipeline's streams");
             int64_t S = half / per_cand;
@@ -1287,6 +1332,9 @@ extern "C" int ital_score_generic(const ital_gscore_desc* d, hipStream_t stream)
             ap.wave_doubles = fixed + chunk_p * stride_p;
             const size_t lds_p = (size_t)2 * ap.wave_doubles * sizeof(double);
             const size_t lds_m = (size_t)4 * (g.R + 256) * sizeof(double);
+            // a slab is a few hundred candidates: one wave each would leave most of the chip idle during the preparation
+            const int npass = (int)((total + chunk_p - 1) / chunk_p);
+            g.nsplit = d->mc_fb > 0 ? 1 : (npass < ITAL_GEN_PREP_SPLIT ? (npass < 1 ? 1 : npass) : ITAL_GEN_PREP_SPLIT);
             static bool prep_attr = false;
             if (!prep_attr) {
                 if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gen_prep_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -1296,7 +1344,7 @@ extern "C" int ital_score_generic(const ital_gscore_desc* d, hipStream_t stream)
             }
             if (lds_p > 160 * 1024) return ital_fail(-12, "ital_score_generic: LDS budget exceeded");
             if (hipEventRecord(ps->start, stream) != hipSuccess || hipStreamWaitEvent(ps->prep, ps->start, 0) != hipSuccess ||
-                hipStreamWaitEvent(ps->main, ps->start, 0) != hipSuccess)
+                hipStreamWaitEvent(ps->main, ps->start, 0) != hipSuccess || hipStreamWaitEvent(ps->comb, ps->start, 0) != hipSuccess)
                 return ital_fail(-5, "ital_score_generic: stream synchronisation failed");
             int nslab = 0;
             for (int64_t lo = 0; lo < d->n_cand; lo += S, nslab++) {
@@ -1308,25 +1356,29 @@ extern "C" int ital_score_generic(const ital_gscore_desc* d, hipStream_t stream)
                 g.meta = base + 1;
                 g.recs = g.meta + g.slab_n * total * 2;
                 g.list = reinterpret_cast<unsigned int*>(g.recs + g.slab_n * total * g.R);
-                if (nslab >= 2) (void)hipStreamWaitEvent(ps->prep, ps->main_done[buf], 0);   // the buffer is free again
-                (void)hipMemsetAsync(g.count, 0, sizeof(unsigned int), ps->prep);
-                hipLaunchKernelGGL(gen_prep_kernel, dim3((unsigned)((g.slab_n + 1) / 2)), dim3(128), lds_p, ps->prep, ap, g);
+                if (nslab >= 2) (void)hipStreamWaitEvent(ps->prep, ps->comb_done[buf], 0);   // the buffer is free again
+                (void)hipMemsetAsync(g.count, 0, 2 * sizeof(unsigned int), ps->prep);
+                hipLaunchKernelGGL(gen_prep_kernel, dim3((unsigned)((g.slab_n * g.nsplit + 1) / 2)), dim3(128), lds_p, ps->prep, ap, g);
                 (void)hipEventRecord(ps->prep_done[buf], ps->prep);
                 (void)hipStreamWaitEvent(ps->main, ps->prep_done[buf], 0);
                 const unsigned mb = 768;     // 3 workgroups of 4 waves per CU; the waves stride over the slab's list
-                switch (tfix) {
-                    case 3: hipLaunchKernelGGL(gen_main_kernel<3>, dim3(mb), dim3(256), lds_m, ps->main, g, d->pair_count); break;
-                    case 4: hipLaunchKernelGGL(gen_main_kernel<4>, dim3(mb), dim3(256), lds_m, ps->main, g, d->pair_count); break;
-                    case 5: hipLaunchKernelGGL(gen_main_kernel<5>, dim3(mb), dim3(256), lds_m, ps->main, g, d->pair_count); break;
-                    default: hipLaunchKernelGGL(gen_main_kernel<6>, dim3(mb), dim3(256), lds_m, ps->main, g, d->pair_count); break;
+#define ITAL_GEN_MAIN(T_) case T_: hipLaunchKernelGGL(gen_main_kernel<T_>, dim3(mb), dim3(256), lds_m, ps->main, g, d->pair_count); break;
+                switch (tfix_p) {
+                    ITAL_GEN_MAIN(3) ITAL_GEN_MAIN(4) ITAL_GEN_MAIN(5) ITAL_GEN_MAIN(6) ITAL_GEN_MAIN(7) ITAL_GEN_MAIN(8)
+                    ITAL_GEN_MAIN(9) ITAL_GEN_MAIN(10) ITAL_GEN_MAIN(11) ITAL_GEN_MAIN(12) ITAL_GEN_MAIN(13) ITAL_GEN_MAIN(14)
+                    ITAL_GEN_MAIN(15) ITAL_GEN_MAIN(16)
                 }
-                hipLaunchKernelGGL(gen_combine_kernel, dim3((unsigned)((g.slab_n + 3) / 4)), dim3(256), 0, ps->main, ap, g);
+#undef ITAL_GEN_MAIN
+                hipLaunchKernelGGL(gen_main_kernel<0>, dim3(64), dim3(256), lds_m, ps->main, g, d->pair_count);
                 (void)hipEventRecord(ps->main_done[buf], ps->main);
+                (void)hipStreamWaitEvent(ps->comb, ps->main_done[buf], 0);       // the slab's terms add up under the next slab's sums
+                hipLaunchKernelGGL(gen_combine_kernel, dim3((unsigned)((g.slab_n + 3) / 4)), dim3(256), 0, ps->comb, ap, g);
+                (void)hipEventRecord(ps->comb_done[buf], ps->comb);
                 int rc = ital_check_launch("ital_score_generic(pipeline)");
                 if (rc) return rc;
             }
-            (void)hipStreamWaitEvent(stream, ps->main_done[0], 0);
-            if (nslab >= 2) (void)hipStreamWaitEvent(stream, ps->main_done[1], 0);
+            (void)hipStreamWaitEvent(stream, ps->comb_done[0], 0);
+            if (nslab >= 2) (void)hipStreamWaitEvent(stream, ps->comb_done[1], 0);
             return 0;
         }
     }

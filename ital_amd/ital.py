@@ -444,7 +444,7 @@ class ITAL(ActiveRetrievalBase):
                 desc.draws_out, desc.draws_in = draws_out, draws_in
                 desc.mi, desc.status = _ptr(mi), _ptr(gp.status)
                 desc.pair_count = _ptr(self.pair_counter)
-                if not subset_mode and not self._clip_active() and 3 <= nE + 1 <= 6:
+                if not subset_mode and not self._clip_active() and 3 <= nE + 1 <= 16:
                     # workspace of the three-kernel pipeline: two buffers of prepared calls (slabs of candidates)
                     n_u = nE + 1
                     calls = npat * (1 + nfb)
