@@ -205,7 +205,8 @@ def other_workloads(X, rel, device):
                              "ital_gscore_desc.pair_count: 240 of the 1296 calls per candidate at t = 4); time = the whole "
                              "ital_score_generic step (preparation of all 1296 calls, lattice sums, combine; the preparation "
                              "runs under the lattice sums on a second stream); avg_launch_ms = one t = 4 step"},
-                    **pmc_fields("general", "void ital::gen_main_kernel<%d>" % BATCH, sec4))
+                    **dict(pmc_fields("general", "void ital::gen_main_kernel<%d>" % BATCH, sec4), valu_issue_frac=None,
+                           traffic_note="traffic: per launch of gen_main_kernel, one of the ~12 slab launches of a step"))
     out["ital_general_user_k4"] = dict(res, roofline=roof,
                                        config="label_prob 0.5, mistake_prob 0.25: 3^t - 1 feedback configurations per pattern")
     np.random.seed(0)
