@@ -43,6 +43,8 @@ class MCMI_min(ActiveRetrievalBase):
         self.last_scores = None
         self.profile = None
         self.event_pool = []
+        self._block_bufs = None
+        self._fetch_bufs = None
 
     def _mark(self, stage=None, t=0, size=0, start=None):
         if self.profile is None:
@@ -59,9 +61,18 @@ class MCMI_min(ActiveRetrievalBase):
         dev = gp.device
         nc = len(cand)
         ldc = _pad16(nc)
-        Xc = torch.zeros((nc, gp.ldx), dtype=torch.float64, device=dev)
-        Vc = torch.zeros((max(gp.m, 1), ldc), dtype=torch.float64, device=dev)
-        vec = torch.zeros((3, nc), dtype=torch.float64, device=dev)  # |x|^2, mean, variance
+        # block buffers are kept between fetches of the same shape (a round at the reference's subsample of 1000 is 0.2 ms of
+        # kernels: allocations and fills are most of its host time); the padding stays zero, the rest is overwritten
+        key = (nc, gp.ldx, gp.cap)
+        if self._block_bufs is None or self._block_bufs[0] != key:
+            self._block_bufs = (key, torch.zeros((nc, gp.ldx), dtype=torch.float64, device=dev),
+                                torch.zeros((gp.cap, ldc), dtype=torch.float64, device=dev),
+                                torch.zeros((3, nc), dtype=torch.float64, device=dev))
+        _, Xc, Vc, vec = self._block_bufs
+        if gp.collective:
+            Xc.zero_()
+            Vc.zero_()
+            vec.zero_()
         if not gp.collective:
             loc = torch.as_tensor(np.asarray(cand, dtype=np.int64) - gp.row0, dtype=torch.int64, device=dev)
             Xc.copy_(gp.Xd.index_select(0, loc))
@@ -86,19 +97,20 @@ class MCMI_min(ActiveRetrievalBase):
         gp = self.gp
         if gp.m == 0:
             raise RuntimeError("fetch_unlabelled() needs a fitted relevance model: call update() first or pass queries")
-        self.candidates = self.get_unseen()
-        if self.subsample and (self.subsample < len(self.candidates)):
-            # same call on the global numpy RNG as the reference (mcmi.py:61-63)
-            self.candidates = np.random.choice(self.candidates, self.subsample, replace=False).tolist()
-        if len(self.candidates) < k:
-            k = len(self.candidates)
+        cand = self._unseen_array()
+        if self.subsample and (self.subsample < len(cand)):
+            # same call on the global numpy RNG as the reference (mcmi.py:61-63; an array draws as a list does)
+            cand = np.random.choice(cand, self.subsample, replace=False)
+        if len(cand) < k:
+            k = len(cand)
         if k <= 0:
+            self.candidates = cand.tolist()
             return []
         if k > ITAL_MAX_T:
             raise NotImplementedError("batches larger than %d are not enumerated on the device" % ITAL_MAX_T)
         lib = _lib.lib()
         dev = gp.device
-        cand = np.asarray(self.candidates, dtype=np.int64)
+        cand = np.asarray(cand, dtype=np.int64)
         nc = len(cand)
         with torch.cuda.device(dev):
             st = _stream()
@@ -108,17 +120,22 @@ class MCMI_min(ActiveRetrievalBase):
             if max(n_i, 1) * ldc * 8 > self.max_cov_bytes:
                 raise MemoryError("MCMI_min: %d x %d covariance block; pass subsample= (reference configs use 1000)"
                                   % (n_i, nc))
-            b = make_batch_buffers(dev, k, gp.ldx, gp.cap, ldc, gp.world)
-            cov = torch.empty((max(n_i, 1), ldc), dtype=torch.float64, device=dev)
+            key = (k, gp.ldx, gp.cap, ldc, n_i, i0)
+            if self._fetch_bufs is None or self._fetch_bufs[0] != key:
+                self._fetch_bufs = (key, make_batch_buffers(dev, k, gp.ldx, gp.cap, ldc, gp.world),
+                                    torch.empty((max(n_i, 1), ldc), dtype=torch.float64, device=dev),
+                                    torch.arange(i0, max(i1, i0 + 1), dtype=torch.int32, device=dev),
+                                    torch.empty(max(n_i, 1), dtype=torch.uint8, device=dev),
+                                    torch.empty(max(n_i, 1), dtype=torch.float64, device=dev))
+            _, b, cov, pos_d, alive, ce = self._fetch_bufs
+            alive.fill_(1)
+            b["ret"][b["kmax"]:].zero_()       # the selection steps OR the status word into this slot
             ev0 = self._mark()
             if n_i:
                 check(lib.ital_cov_block(_ptr(Xc[i0:]), _ptr(xnc[i0:]), n_i, _ptr(Xc), _ptr(xnc), nc, gp.ldx,
                                          Vc.data_ptr() + 8 * i0, ldc, _ptr(Vc), ldc, gp.m, float(self.var),
                                          float(self.length_scale), _ptr(cov), ldc, st))
             self._mark("cov_block", 0, nc, ev0)
-            pos_d = torch.arange(i0, max(i1, i0 + 1), dtype=torch.int32, device=dev)
-            alive = torch.ones(max(n_i, 1), dtype=torch.uint8, device=dev)
-            ce = torch.zeros(max(n_i, 1), dtype=torch.float64, device=dev)
             self.last_scores = []
             for t in range(1, k + 1):
                 desc = ItalMcmiDesc()
@@ -152,10 +169,10 @@ class MCMI_min(ActiveRetrievalBase):
                                                   _ptr(b["XBn"][slot:]), 1, _ptr(b["VB"][slot]), gp.cap, _ptr(Vc), ldc,
                                                   gp.m, float(self.var), float(self.length_scale), _ptr(b["C"][slot]),
                                                   ldc, st))
-            picked = b["ret"][:k].cpu().tolist()  # block positions; the only synchronisation of the round
-        gp.check_status()
+            host = b["ret"].cpu().tolist()        # block positions + status word; the only synchronisation of the round
+        picked = host[:k]
+        gp.check_status(host[b["kmax"]])
         ret = [int(cand[p]) for p in picked]
         self._last_batch = (b, ret)
-        gone = set(picked)
-        self.candidates = [int(c) for p, c in enumerate(cand) if p not in gone]  # as `del self.candidates[min_ind]`
+        self.candidates = np.delete(cand, picked).tolist()   # as `del self.candidates[min_ind]` per pick (mcmi.py:79)
         return ret
