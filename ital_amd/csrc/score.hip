@@ -11,10 +11,12 @@
 //
 //   t = 1 : Phi closed form                     (one thread per candidate, HBM-bound)
 //   t = 2 : Genz bivariate closed form          (one lane per (candidate, pattern))
-//   t >= 3: Genz MVNDST randomised Korobov lattice (one wave per candidate, lattice points across the 64 lanes,
-//           COVSRT variable re-ordering per call by one lane each, FP64-VALU bound).  The lattice shifts replay
-//           MVNUNI's stream at the offset the reference's *serial* loop would reach for this (candidate, pattern,
-//           call): jump-ahead by 3x3 matrix powers, so the scores - and the argmax - match the reference's.
+//   t >= 3: Genz MVNDST randomised Korobov lattice as four kernels: generator state per candidate; one thread per
+//           (candidate, sign pattern) prepares the call (COVSRT variable re-ordering, the 8 shifted lattices) into a record;
+//           one wave per record sums the lattice, its points across the 64 lanes (FP64-VALU bound); one thread per
+//           candidate adds the terms up.  The lattice shifts replay MVNUNI's stream at the offset the reference's *serial*
+//           loop would reach for this (candidate, pattern, call): jump-ahead by 3x3 matrix powers, so the scores - and
+//           the argmax - match the reference's.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -54,7 +56,7 @@ struct ScoreArgs {
     // MVNUNI replay
     int seed[6];            // generator state at the first call of this greedy step
     const long long* jump;  // [48][18]: transition matrices for 2^b calls (of this step's dimension)
-    const long long* jumplane;  // [2^t][18]: transition matrices for 2r calls (the prior call of sign pattern r)
+    const long long* jumppat;   // [2^t][18]: transition matrices for 2r calls (the prior call of sign pattern r)
     const double* vk;       // [t-1] Korobov generators
     int* status;
 };
@@ -417,7 +419,7 @@ __global__ __launch_bounds__(Qmc<T>::PREP_THREADS) void qmc_prep_kernel(ScoreArg
         // from shift to shift), then NDIM shifts.  The prior call of pattern r is call 2r of the candidate.
         const int* sp = seeds + i * 6;
         MrgState sti = {sp[0], sp[1], sp[2], sp[3], sp[4], sp[5]};
-        mrg_apply(sti, a.jumplane + (int64_t)r * 18);   // row r: 2r calls
+        mrg_apply(sti, a.jumppat + (int64_t)r * 18);   // row r: 2r calls
         MrgStateF st = mrg_to_f(sti);
         for (int j = 0; j < Q::NDIM; j++) gen[j] = a.vk[j];
         double* L = rec + Q::R_LAT;
@@ -564,7 +566,7 @@ extern "C" int ital_score_step(const ital_score_desc* d, hipStream_t stream) {
     a.t = d->t; a.n_cand = d->n_cand; a.cand = d->cand; a.alive = d->alive; a.mu = d->mu; a.s2 = d->s2; a.C = d->C;
     a.ldc = d->ldc; a.row_offset = d->row_offset; a.pos_offset = d->pos_offset; a.gpos = d->gpos; a.b = d->batch;
     a.noise = d->noise; a.eps = d->eps; a.label_mode = d->label_mode; a.mi = d->mi; a.jump = d->jump;
-    a.jumplane = d->jumppat; a.vk = d->vk; a.status = d->status;
+    a.jumppat = d->jumppat; a.vk = d->vk; a.status = d->status;
     for (int i = 0; i < 6; i++) a.seed[i] = d->seed[i];
     if (d->t == 1) {
         hipLaunchKernelGGL(score_t1_kernel, dim3((unsigned)((d->n_cand + 255) / 256)), dim3(256), 0, stream, a);
