@@ -17,6 +17,10 @@
 #include "ital_hip.h"
 #include "ital_internal.h"
 
+#ifndef ITAL_MCMI_HOTK
+#define ITAL_MCMI_HOTK 1
+#endif
+
 namespace ital {
 
 typedef double d4 __attribute__((ext_vector_type(4)));
@@ -217,10 +221,11 @@ struct McmiArgs {
 // q log(q + eps) + (1 - q) log(1 - q + eps) with q = Phi(z).  Phi through Hart's rational (mvn_phi, ~1e-15 relative, a
 // third of the instructions of the erf/erfc library route behind scipy's ndtr) and the short logarithm of
 // device_math.h; agrees with the reference's value to ~1e-15, far inside the 1e-8 test tolerance.
-__device__ __forceinline__ double entropy_term(double z, double eps) {
-    const double q = mvn_phi(z);
+template <class K>
+__device__ __forceinline__ double entropy_term(double z, double eps, const K& kk) {
+    const double q = mvn_phi(z, kk);
     const double p = 1.0 - q;
-    return q * log_pos(q + eps) + p * log_pos(p + eps);
+    return q * log_pos(q + eps, kk) + p * log_pos(p + eps, kk);
 }
 
 // One workgroup per candidate i; the 256 threads stride over the candidates j.  Patterns are enumerated in
@@ -285,6 +290,12 @@ __global__ __launch_bounds__(256) void mcmi_score_kernel(McmiArgs a) {
         for (int q = 0; q < T; q++) W[p][q] = Wsh[p][q];
     }
     const double* Srow = a.S + li * a.lds_;
+#if ITAL_MCMI_HOTK
+    HotK kk;          // exp / log coefficients as vector-register operands (device_math.h)
+    kk.load();
+#else
+    const LitK kk;
+#endif
     double best = 0.0;
     for (int hi = 0; hi < NH; hi++) {
         double acc[NL];
@@ -327,7 +338,7 @@ __global__ __launch_bounds__(256) void mcmi_score_kernel(McmiArgs a) {
             if (sv > 0) {
                 const double inv_sd = 1.0 / sqrt(sv);
 #pragma unroll
-                for (int r = 0; r < NL; r++) acc[r] += entropy_term(-val[r] * inv_sd, a.eps);
+                for (int r = 0; r < NL; r++) acc[r] += entropy_term(-val[r] * inv_sd, a.eps, kk);
             } else {
                 // norm.cdf(0, mean, 0) is NaN (scipy scale check): the whole sum becomes NaN
 #pragma unroll
