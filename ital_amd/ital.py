@@ -63,6 +63,7 @@ class ITAL(ActiveRetrievalBase):
         self.qmc_work_bytes = int(os.environ.get("ITAL_QMC_WORK_BYTES", 1 << 30))   # cap of the lattice scorer's workspace
         self._last_batch = None  # (batch buffers, picks) of the last fast-path round: update() reuses the winners' rows
         self.pair_counter = None  # optional int64 device tensor [1]: the general scorer adds its evaluated (Phi, Phi^-1) pairs
+        self.generic_pipeline = True   # False: the general scorer always runs as its single kernel (cross-check in tests)
         self.event_pool = []     # pre-created timing events (bench.py)
         self.profile = None      # list to receive (stage, t, size, start_event, end_event) per launch (bench.py)
         self._fetch_bufs = None
@@ -444,7 +445,7 @@ class ITAL(ActiveRetrievalBase):
                 desc.draws_out, desc.draws_in = draws_out, draws_in
                 desc.mi, desc.status = _ptr(mi), _ptr(gp.status)
                 desc.pair_count = _ptr(self.pair_counter)
-                if not subset_mode and not self._clip_active() and 3 <= nE + 1 <= 16:
+                if self.generic_pipeline and not subset_mode and not self._clip_active() and 3 <= nE + 1 <= 16:
                     # workspace of the three-kernel pipeline: two buffers of prepared calls (slabs of candidates)
                     n_u = nE + 1
                     calls = npat * (1 + nfb)

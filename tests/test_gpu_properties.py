@@ -146,3 +146,53 @@ def test_one_million_candidates(dev):
         mi += pr * (np.log(pu + 1e-12) - np.log(pr + 1e-12))
     np.testing.assert_allclose(s0[sub], mi, rtol=1e-9, atol=1e-12)
     assert cand[int(np.argmax(np.where(np.isnan(s0), -np.inf, s0)))] == picks[0][0]
+
+
+@pytest.mark.parametrize("kw,n,k", [(dict(label_prob=0.6, mistake_prob=0.2), 300, 4), (dict(mistake_prob=0.15), 200, 5),
+                                    (dict(monte_carlo_num_rel=1), 400, 9), (dict(label_estimation="pessimistic", mistake_prob=0.1), 150, 3)])
+def test_general_scorer_pipeline_equals_its_single_kernel(dev, kw, n, k):
+    """Plain mode of ital_score_generic: three kernels on internal streams (prepare / lattice sums / combine, slabs of the
+    workspace) against the one kernel that does everything per candidate -- same calls, same stream offsets, same order of
+    the terms; up to 6 variables even the same evaluator (bit-identical scores), beyond that the compile-time evaluator
+    against the runtime one (last-bit differences)."""
+    from ital_amd import ITAL, mvn_stream
+    rng = np.random.default_rng(17)
+    X = rng.random((n, 9))
+    out = []
+    for pipeline, work_bytes in ((True, 1 << 30), (True, 1 << 21), (False, 1 << 30)):
+        mvn_stream.GLOBAL.reset()
+        np.random.seed(3)
+        L = ITAL(X, length_scale=0.9, device=dev, **kw)
+        L.generic_pipeline = pipeline
+        L.qmc_work_bytes = work_bytes                      # 2 MiB: many small slabs
+        L.keep_scores = True
+        L.update({1: 1, 2: -1})
+        ret = L.fetch_unlabelled(k)
+        out.append((ret, [s.cpu().numpy() for s in L.last_scores], mvn_stream.GLOBAL.draws))
+    for ret, scores, draws in out[1:]:
+        assert ret == out[0][0] and draws == out[0][2]
+    for a, b in zip(out[0][1], out[1][1]):                 # slab size does not matter
+        np.testing.assert_array_equal(a, b)
+    for t, (a, b) in enumerate(zip(out[0][1], out[2][1])):
+        live = np.isfinite(b)
+        if t + 1 <= 6:
+            np.testing.assert_array_equal(a[live], b[live])
+        else:
+            np.testing.assert_allclose(a[live], b[live], rtol=1e-12, atol=0)
+
+
+def test_sharded_rows_holder_equals_the_full_matrix(dev):
+    """sharding.ShardedRows (a rank passes only its own row block) against the full matrix, one rank."""
+    from ital_amd import ITAL, mvn_stream, sharding
+    rng = np.random.default_rng(23)
+    X = rng.random((500, 20))
+    res = []
+    for data in (X, sharding.ShardedRows(X, 500, 0)):
+        mvn_stream.GLOBAL.reset()
+        L = ITAL(data, length_scale=1.2, device=dev)
+        L.update({4: 1, 9: -1})
+        res.append((L.fetch_unlabelled(4), L.rel_mean.copy(), len(L.get_unseen())))
+    assert res[0][0] == res[1][0] and res[0][2] == res[1][2] == 498
+    np.testing.assert_array_equal(res[0][1], res[1][1])
+    with pytest.raises(ValueError):
+        ITAL(sharding.ShardedRows(X[:100], 500, 0), length_scale=1.2, device=dev)   # not this rank's block

@@ -174,3 +174,16 @@ def test_ctypes_structs_have_the_layout_of_the_header(tmp_path):
         assert int(got[name]) == ctypes.sizeof(cls), name
         for f in fields:
             assert int(got["%s.%s" % (name, f)]) == getattr(cls, f).offset, (name, f)
+
+
+def test_score_workspace_size():
+    """ital_score_workspace (host-only entry point): records of 2^t patterns, their terms and the generator state."""
+    from ital_amd import _lib
+    lib = _lib.load()
+    for t, lat in ((3, 32), (4, 48), (8, 112)):
+        ncor = t * (t - 1) // 2
+        per_cand = (1 << t) * (ncor + t + 1 + lat + 1) + 3
+        assert lib.ital_score_workspace(t, 1) == per_cand
+        assert lib.ital_score_workspace(t, 1000) == 1000 * per_cand
+    assert lib.ital_score_workspace(2, 10) == 0 and lib.ital_score_workspace(9, 10) == 0
+    assert lib.ital_topk_workspace() > 4096 * 8
