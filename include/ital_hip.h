@@ -60,6 +60,17 @@ int ital_chol_append(const double* XT, const double* XTn, int ldx, double* L, in
                      const double* ynew, int m, int c, double var, double length_scale, double noise, int* status,
                      hipStream_t stream);
 
+/* Stages the c <= 16 samples an update labels: XT_dst[j][:] = rows[slot[j]][:] (feature rows, e.g. out of the batch state
+ * XB of the last fetch), XTn_dst[j] = their squared norms, y_dst[j] = y[j]; the picks and labels travel by value.
+ * Replaces the row slicing of GaussianProcess.update, reference ital/gp.py:185-190 (K_all[ind] / X[ind]). */
+typedef struct ital_label_batch {
+    int c;
+    int slot[16];
+    double y[16];
+} ital_label_batch;
+int ital_stage_labelled(const double* rows, int ldx, ital_label_batch lb, double* XT_dst, double* XTn_dst, double* y_dst,
+                        hipStream_t stream);
+
 /* Appends the c whitened rows V[m..m+c-1][:] = L22^-1 (K[new,:] - L21 V) and refreshes the predictive mean
  * mu += V_new^T alpha_new and variance s2 -= colsum(V_new^2) of every row.  L21 = &L[m][0] (ld ldw),
  * L22 = &L[m][m] (ld ldw).  Replaces predict_stored after an update, reference ital/gp.py:203-232 as called from

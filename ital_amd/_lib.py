@@ -25,6 +25,10 @@ class ItalBatch(ctypes.Structure):
                 ("VB", c_void_p)]
 
 
+class ItalLabelBatch(ctypes.Structure):
+    _fields_ = [("c", c_int), ("slot", c_int * 16), ("y", c_double * 16)]
+
+
 class ItalScoreDesc(ctypes.Structure):
     _fields_ = [("t", c_int), ("n_cand", c_int64), ("cand", c_void_p), ("alive", c_void_p), ("mu", c_void_p),
                 ("s2", c_void_p), ("C", c_void_p), ("ldc", c_int64), ("row_offset", c_int64),
@@ -66,6 +70,7 @@ SIGNATURES = {
     "ital_whiten_append": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_void_p, c_void_p, c_int, c_void_p, c_int,
                                    c_void_p, c_void_p, c_void_p, c_int64, c_int, c_double, c_double, c_void_p,
                                    c_void_p, c_void_p]),
+    "ital_stage_labelled": (c_int, [c_void_p, c_int, ItalLabelBatch, c_void_p, c_void_p, c_void_p, c_void_p]),
     "ital_predict": (c_int, [c_void_p, c_int64, c_int, c_void_p, c_void_p, c_int, c_void_p, c_int, c_void_p,
                              c_double, c_double, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_void_p]),
     "ital_topk": (c_int, [c_void_p, c_int64, c_int64, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),

@@ -22,6 +22,7 @@
 #include <stdint.h>
 
 #include "device_math.h"
+#include "ital_hip.h"
 #include "ital_internal.h"
 
 namespace ital {
@@ -199,9 +200,37 @@ __global__ __launch_bounds__(256) void clamp0_kernel(int64_t nt, double* __restr
     if (i < nt) pvar[i] = fmax(0.0, pvar[i]);     // np.maximum(0, ...) of gp.py:290
 }
 
+// Stages the samples an update labels: feature rows picked out of a row matrix (the replicated batch state of the last
+// fetch) into the labelled-set rows XT[m .. m+c), their squared norms and the labels -- one launch, the picks and labels
+// travel as kernel arguments (no host-to-device copies, no gather / copy / norm launches of their own).
+__global__ __launch_bounds__(64) void stage_labelled_kernel(const double* __restrict__ rows, int ldx, ital_label_batch lb,
+                                                            double* __restrict__ XT_dst, double* __restrict__ XTn_dst,
+                                                            double* __restrict__ y_dst) {
+    const int j = blockIdx.x, lane = threadIdx.x;
+    if (j >= lb.c) return;
+    const double* src = rows + (int64_t)lb.slot[j] * ldx;
+    double* dst = XT_dst + (int64_t)j * ldx;
+    double acc = 0;
+    for (int k = lane; k < ldx; k += 64) {
+        const double v = src[k];
+        dst[k] = v;
+        acc += v * v;
+    }
+    acc = wave_sum(acc);
+    if (lane == 0) { XTn_dst[j] = acc; y_dst[j] = lb.y[j]; }
+}
+
 }  // namespace ital
 
 using namespace ital;
+
+extern "C" int ital_stage_labelled(const double* rows, int ldx, ital_label_batch lb, double* XT_dst, double* XTn_dst,
+                                   double* y_dst, hipStream_t stream) {
+    if (lb.c < 1 || lb.c > 16) return ital_fail(-22, "ital_stage_labelled: 1..16 samples per call");
+    if (ldx % 16 != 0) return ital_fail(-22, "ital_stage_labelled: ldx must be a multiple of 16");
+    hipLaunchKernelGGL(stage_labelled_kernel, dim3(lb.c), dim3(64), 0, stream, rows, ldx, lb, XT_dst, XTn_dst, y_dst);
+    return ital_check_launch("ital_stage_labelled");
+}
 
 extern "C" int ital_row_norms(const double* X, int64_t n, int ldx, double* xnorm, hipStream_t stream) {
     if (n <= 0) return 0;

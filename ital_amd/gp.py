@@ -193,11 +193,13 @@ class GaussianProcess(object):
         if len(ind) == 0:
             return self
         if row_cache is not None and all(i in row_cache[1] for i in ind):
-            slots = torch.as_tensor([row_cache[1][i] for i in ind], dtype=torch.int64, device=self.device)
-            rows = row_cache[0].index_select(0, slots)
+            if len(ind) <= 16:
+                self._append_staged(row_cache[0], [row_cache[1][i] for i in ind], y)
+            else:
+                slots = torch.as_tensor([row_cache[1][i] for i in ind], dtype=torch.int64, device=self.device)
+                self._append(row_cache[0].index_select(0, slots), y)
         else:
-            rows = self._gather_rows(ind)
-        self._append(rows, y)
+            self._append(self._gather_rows(ind), y)
         self.ind += ind
         self.y = y.copy() if self.y is None else np.concatenate((self.y, y))
         self._replicate_mean()
@@ -249,6 +251,32 @@ class GaussianProcess(object):
         if self.collective:
             sharding.all_reduce_sum(out, self.group)
         return out
+
+    def _append_staged(self, matrix, slots, y):
+        """_append for up to 16 samples whose feature rows are rows `slots` of a replicated device matrix (the batch state
+        of the last fetch): one staging launch instead of gather, copies, norms and a label upload."""
+        lib, st = self._lib, _stream()
+        c = len(slots)
+        if self.m + c > self.cap:
+            self._alloc(max(2 * self.cap, self.m + c))
+        if getattr(self, "_ybuf", None) is None:
+            self._ybuf = torch.empty(16, dtype=torch.float64, device=self.device)
+        lb = _lib.ItalLabelBatch()
+        lb.c = c
+        for j in range(c):
+            lb.slot[j] = int(slots[j])
+            lb.y[j] = float(y[j])
+        m = self.m
+        check(lib.ital_stage_labelled(_ptr(matrix), self.ldx, lb, _ptr(self.XT[m:]), _ptr(self.XTn[m:]), _ptr(self._ybuf), st))
+        check(lib.ital_chol_append(_ptr(self.XT), _ptr(self.XTn), self.ldx, _ptr(self.L), self.cap, _ptr(self.alpha),
+                                   _ptr(self._ybuf), m, c, float(self.var), float(self.length_scale), float(self.noise),
+                                   _ptr(self.status), st))
+        L21 = self.L[m:]
+        check(lib.ital_whiten_append(_ptr(self.Xd), _ptr(self.xnorm), self.n, self.ldx, _ptr(self.XT[m:m + c]),
+                                     _ptr(self.XTn[m:m + c]), c, _ptr(L21), self.cap, L21.data_ptr() + 8 * m,
+                                     _ptr(self.alpha[m:m + c]), _ptr(self.V), self.ldv, m, float(self.var),
+                                     float(self.length_scale), _ptr(self.mu), _ptr(self.s2), st))
+        self.m += c
 
     def _append(self, rows, y):
         lib, st = self._lib, _stream()

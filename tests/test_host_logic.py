@@ -155,6 +155,7 @@ def test_ctypes_structs_have_the_layout_of_the_header(tmp_path):
     from ital_amd import _lib
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     probes = {"ital_batch": (_lib.ItalBatch, ["kmax", "bidx", "VB"]),
+              "ital_label_batch": (_lib.ItalLabelBatch, ["c", "slot", "y"]),
               "ital_score_desc": (_lib.ItalScoreDesc, ["t", "gpos", "batch", "label_mode", "seed", "jumppat", "status", "work", "work_doubles", "ev_stop"]),
               "ital_gscore_desc": (_lib.ItalGscoreDesc, ["n_cand", "gpos", "nE", "ldE", "pick_pos", "label_prob", "clip_cov", "seed",
                                                          "draws_in", "dead_pos", "fb_samples", "draw_count", "status", "work_doubles", "pair_count"]),
