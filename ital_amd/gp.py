@@ -43,7 +43,7 @@ class GaussianProcess(object):
     """
 
     def __init__(self, data, length_scale, var=1.0, noise=1e-6, pdist=None, *, device=None, rank=0, world=1,
-                 group=None, capacity=64):
+                 group=None, capacity=None):
         if pdist is not None:
             raise NotImplementedError("pre-computed distances are a dense-kernel feature of the reference (gp.py:116-128)")
         if not torch.cuda.is_available():
@@ -83,6 +83,11 @@ class GaussianProcess(object):
             self.xnorm = torch.empty(max(self.n, 1), dtype=torch.float64, device=self.device)
             check(self._lib.ital_row_norms(_ptr(self.Xd), self.n, self.ldx, _ptr(self.xnorm), _stream()))
             self.status = torch.zeros(1, dtype=torch.int32, device=self.device)
+            if capacity is None:
+                # room for 256 labelled samples (a session of 60 rounds of 4) unless the whitened block V would take more
+                # than 2 GiB up front; growing later costs a reallocation and a copy of V and of the batch buffers (13 ms
+                # at 9298 rows: visible in a 3 ms round)
+                capacity = int(min(256, max(64, (2 << 30) // (8 * self.ldv))))
             self._alloc(capacity)
         self.reset()
 

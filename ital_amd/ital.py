@@ -203,18 +203,29 @@ class ITAL(ActiveRetrievalBase):
             raise ValueError("attempt to get argmax of an empty sequence")
         return self._select(k, candidates)
 
-    def _shard(self, candidates):
+    def _shard(self, candidates, b=None):
         """Candidate shard of this rank as device arrays: local rows, alive flags, explicit list positions (or None when
-        the local positions are one contiguous run of the list), and the list position of the first one."""
+        the local positions are one contiguous run of the list), and the list position of the first one.  `b`: batch
+        buffers whose cached alive-flag array is reused (the fetch prologue sits between two rounds with the GPU idle)."""
         gp = self.gp
         dev = gp.device
         cand = np.asarray(candidates, dtype=np.int64)
-        loc_rows, pos_offset, gpos = sharding.shard_candidates(cand, gp.row0, gp.row1)
+        if gp.world == 1:
+            loc_rows, pos_offset, gpos = cand, 0, None          # every candidate is local, in list order
+        else:
+            loc_rows, pos_offset, gpos = sharding.shard_candidates(cand, gp.row0, gp.row1)
         n_loc = len(loc_rows)
         cand_d = torch.from_numpy((loc_rows - gp.row0).astype(np.int32)).to(dev) if n_loc else \
             torch.zeros(1, dtype=torch.int32, device=dev)
         gpos_d = torch.from_numpy(gpos).to(dev) if gpos is not None else None
-        alive = torch.ones(max(n_loc, 1), dtype=torch.uint8, device=dev)
+        if b is not None:
+            if b.get("alive") is None or b["alive"].numel() < max(n_loc, 1):
+                b["alive"] = torch.empty(max(n_loc, 1), dtype=torch.uint8, device=dev)
+                b["mi"] = torch.empty(max(n_loc, 1), dtype=torch.float64, device=dev)
+            alive = b["alive"]
+            alive.fill_(1)
+        else:
+            alive = torch.ones(max(n_loc, 1), dtype=torch.uint8, device=dev)
         return cand, n_loc, pos_offset, cand_d, gpos_d, alive
 
     def _qmc_workspace(self, b, t, n_loc):
@@ -236,8 +247,8 @@ class ITAL(ActiveRetrievalBase):
             b = self._buffers(k)
             st = _stream()
             # ---- candidate shard of this rank (list positions keep their global numbering)
-            cand, n_loc, pos_offset, cand_d, gpos_d, alive = self._shard(candidates)
-            mi = torch.empty(max(n_loc, 1), dtype=torch.float64, device=dev)   # every live position is written by the scorer
+            cand, n_loc, pos_offset, cand_d, gpos_d, alive = self._shard(candidates, b)
+            mi = b["mi"]                                   # every live position is written by the scorer
             self.last_scores = []
             stream = mvn_stream.GLOBAL
             saved_stream = (stream.state, stream.draws)

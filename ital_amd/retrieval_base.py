@@ -12,6 +12,9 @@ from .gp import GaussianProcess
 
 class ActiveRetrievalBase(object):
 
+    #: initial capacity of the labelled set on the device (None: GaussianProcess picks it; it grows on demand)
+    gp_capacity = None
+
     def __init__(self, data=None, queries=[], length_scale=0.1, var=1.0, noise=1e-6, *, device=None, rank=0,
                  world=1, group=None):
         self.length_scale = length_scale
@@ -26,7 +29,7 @@ class ActiveRetrievalBase(object):
         self.queries = queries
         if self.data is not None:
             self.gp = GaussianProcess(self.data, self.length_scale, self.var, self.noise, device=self.device,
-                                      rank=self.rank, world=self.world, group=self.group)
+                                      rank=self.rank, world=self.world, group=self.group, capacity=self.gp_capacity)
             self.reset()
         else:
             self.gp = None

@@ -196,3 +196,29 @@ def test_sharded_rows_holder_equals_the_full_matrix(dev):
     np.testing.assert_array_equal(res[0][1], res[1][1])
     with pytest.raises(ValueError):
         ITAL(sharding.ShardedRows(X[:100], 500, 0), length_scale=1.2, device=dev)   # not this rank's block
+
+
+def test_labelled_set_capacity_growth_inside_a_session(dev):
+    """The labelled-set buffers (V, L, the batch buffers that depend on their leading dimension) grow on demand: a session
+    that starts with room for 16 labelled samples gives the picks and means of one that never has to grow."""
+    from ital_amd import ITAL, mvn_stream
+    rng = np.random.default_rng(31)
+    X = rng.random((400, 10))
+    rel = np.where(X[:, 0] > 0.5, 1.0, -1.0)
+    res = []
+    for cap in (16, None):
+        mvn_stream.GLOBAL.reset()
+        ITAL.gp_capacity = cap
+        try:
+            L = ITAL(X, length_scale=1.0, device=dev)
+        finally:
+            ITAL.gp_capacity = None
+        L.update({0: 1})
+        picks = []
+        for _ in range(7):                                  # 1 + 7 x 4 = 29 labelled samples: crosses 16
+            ret = L.fetch_unlabelled(4)
+            picks.append(ret)
+            L.update({i: float(rel[i]) for i in ret})
+        res.append((picks, L.rel_mean.copy(), L.gp.cap))
+    assert res[0][0] == res[1][0] and res[0][2] >= 32 and res[1][2] >= 64
+    np.testing.assert_allclose(res[0][1], res[1][1], rtol=0, atol=1e-12)
