@@ -146,6 +146,15 @@ class ITAL(ActiveRetrievalBase):
             self.profile.append((stage, t, size, start, ev))
         return ev
 
+    def _event(self):
+        """A timing event for the library to record (handle must exist: pool events are recorded once when the pool is
+        made; a fresh one is recorded here)."""
+        if self.event_pool:
+            return self.event_pool.pop()
+        ev = torch.cuda.Event(enable_timing=True)
+        ev.record()
+        return ev
+
     def _buffers(self, kmax):
         gp = self.gp
         b = self._fetch_bufs
@@ -277,14 +286,17 @@ class ITAL(ActiveRetrievalBase):
                     work = self._qmc_workspace(b, t, n_loc)
                     desc.work, desc.work_doubles = _ptr(work), work.numel()
                     if self.profile is not None:
-                        # the lattice-sum kernel alone, bracketed by events the library records on the launch stream
-                        # (an event has to be recorded once before its handle exists)
-                        k0, k1 = self._mark(), self._mark()
+                        # the lattice-sum kernel alone, bracketed by events the library records on the launch stream (an
+                        # event has to be recorded once before its handle exists: the pool's events are, see bench.py).
+                        # Every record is a barrier packet in the queue (~4 us of idle GPU in a 3 ms round), so the step
+                        # as a whole is only bracketed where no kernel-level pair exists
+                        k0, k1 = self._event(), self._event()
                         desc.ev_start, desc.ev_stop = k0.cuda_event, k1.cuda_event
                         self.profile.append(("qmc_main", t, n_alive, k0, k1))
-                ev0 = self._mark()
+                ev0 = self._mark() if t < 3 else None
                 check(lib.ital_score_step(ctypes.byref(desc), st))
-                self._mark("score", t, n_alive, ev0)
+                if t < 3:
+                    self._mark("score", t, n_alive, ev0)
                 if self.keep_scores:
                     self.last_scores.append(mi.clone())
                 if not gp.collective and n_loc <= _FUSED_SELECT_MAX:
@@ -307,12 +319,13 @@ class ITAL(ActiveRetrievalBase):
                                                   _ptr(alive), _ptr(b["ret"]), st))
                 if t < k:
                     slot = t - 1
-                    ev0 = self._mark()
+                    ev0 = self._mark() if t == 1 else None           # one sample of the streaming kernel per round
                     check(lib.ital_cross_cov_cols(_ptr(gp.Xd), _ptr(gp.xnorm), gp.n, gp.ldx, _ptr(b["XB"][slot]),
                                                   _ptr(b["XBn"][slot:]), 1, _ptr(b["VB"][slot]), gp.cap, _ptr(gp.V),
                                                   gp.ldv, gp.m, float(self.var), float(self.length_scale),
                                                   _ptr(b["C"][slot]), gp.ldv, st))
-                    self._mark("cross_cov", t, gp.m, ev0)
+                    if t == 1:
+                        self._mark("cross_cov", t, gp.m, ev0)
                 # the reference's serial loop has now consumed this many uniforms of mvndst's stream
                 stream.advance(n_alive * (2 << t) * mvn_stream.draws_per_call(t))
                 n_alive -= 1
