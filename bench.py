@@ -321,7 +321,7 @@ def scaling_workload(device, rank, world, group, rounds=3):
         prof.setdefault((name, t), []).append(e0.elapsed_time(e1))
     ex = [v for key, vs in prof.items() if key[0] == "exchange" for v in vs]
     backend = None
-    if world > 1:
+    if group is not None:
         import torch.distributed as dist
         backend = dist.get_backend(group)
     mem = torch.cuda.max_memory_allocated(device) / 2 ** 30
