@@ -83,6 +83,7 @@ class GaussianProcess(object):
             self.xnorm = torch.empty(max(self.n, 1), dtype=torch.float64, device=self.device)
             check(self._lib.ital_row_norms(_ptr(self.Xd), self.n, self.ldx, _ptr(self.xnorm), _stream()))
             self.status = torch.zeros(1, dtype=torch.int32, device=self.device)
+            self._gather_bufs = {}
             if capacity is None:
                 # room for 256 labelled samples (a session of 60 rounds of 4) unless the whitened block V would take more
                 # than 2 GiB up front; growing later costs a reallocation and a copy of V and of the batch buffers (13 ms
@@ -321,17 +322,25 @@ class GaussianProcess(object):
         """Local shard vector -> full-length numpy array (all ranks; a collective when the rows are sharded)."""
         return self._full_device(t).cpu().numpy()
 
-    def _full_device(self, t):
+    def _full_device(self, t, keep=None):
         """Local shard vector -> full-length device vector, replicated on every rank (one all-gather of equal-sized,
-        padded shards when the rows are sharded)."""
+        padded shards when the rows are sharded).  `keep`: name under which the send / receive buffers are kept between
+        calls (the means are replicated after every update: no allocation, and no copy at all when the shards are equal)."""
         loc = t[: self.n]
         if not self.collective:
             return loc
         pad = (self.n_total + self.world - 1) // self.world
-        send = torch.zeros(pad, dtype=loc.dtype, device=self.device)
+        bufs = self._gather_bufs.get(keep) if keep else None
+        if bufs is None:
+            bufs = (torch.zeros(pad, dtype=loc.dtype, device=self.device),
+                    torch.empty((self.world, pad), dtype=loc.dtype, device=self.device))
+            if keep:
+                self._gather_bufs[keep] = bufs
+        send, recv = bufs
         send[: self.n] = loc
-        recv = torch.empty((self.world, pad), dtype=loc.dtype, device=self.device)
         sharding.gather_records(send, recv, self.group)
+        if pad * self.world == self.n_total:
+            return recv.view(-1)
         parts = []
         for r in range(self.world):
             a, b = sharding.row_range(self.n_total, self.world, r)
@@ -343,7 +352,7 @@ class GaussianProcess(object):
         rank (asynchronous, on the stream).  What reads them later -- `rel_mean`, top_results(), the candidate restriction
         of `top_candidates` -- is then a local operation: reading an attribute on one rank only cannot dead-lock the
         others (the reference refreshes `rel_mean` inside update() too, retrieval_base.py:58,120)."""
-        self.mu_all = self._full_device(self.mu)
+        self.mu_all = self._full_device(self.mu, keep="mu")
         self._mean_host = None
 
     def mean_host(self):
