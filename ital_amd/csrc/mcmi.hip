@@ -17,6 +17,12 @@
 #include "ital_hip.h"
 #include "ital_internal.h"
 
+#ifndef ITAL_COV_LDS
+#define ITAL_COV_LDS 1     // covariance blocks of at least 256 x 256: the LDS-staged kernel
+#endif
+#ifndef ITAL_COV_LDS_MIN_TILES
+#define ITAL_COV_LDS_MIN_TILES 1024   // four waves of workgroups over the 256 CUs x 2; below (3000^2: 576 tiles) the register-tiled kernel wins
+#endif
 #ifndef ITAL_MCMI_HOTK
 #define ITAL_MCMI_HOTK 1
 #endif
@@ -194,6 +200,164 @@ __global__ __launch_bounds__(256) void cov_block_kernel(CovArgs a) {
                 const int64_t i = i0 + 16 * p + kg + 4 * reg;
                 if (col == 0 && i < a.na) a.out[(int64_t)blockIdx.x * a.ldo + i] = v;
             }
+    }
+}
+
+// The same block with the operands staged through LDS: a workgroup owns a 128 x 128 tile of the output, its four waves a
+// 64 x 64 quarter each (16 MFMA tiles: 64 accumulator registers per lane), and every 16-wide feature step is fetched from
+// global memory ONCE per workgroup -- 128 rows of A and of B, 16 KB each, transposed into LDS ([feature][row], padded row
+// stride) -- instead of once per wave: 16 flops per byte from L2 / HBM against 5.3 of the register-tiled kernel above,
+// which reads every operand four times per workgroup.  The global loads of step s + 1 are issued before the 64 MFMAs of
+// step s and written to the other LDS buffer after them (register + LDS double buffer, one barrier per step).
+constexpr int CB_T = 128;              // tile edge
+constexpr int CB_KS = 16;              // features per stage
+constexpr int CB_LD = CB_T + 4;        // padded row stride of a staged tile (doubles)
+
+template <bool ROWSUM>
+__global__ __launch_bounds__(256, 2) void cov_block_lds_kernel(CovArgs a) {
+    __shared__ double lds[2][2][CB_KS][CB_LD];     // [buffer][A / B][feature][row]
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int col = lane & 15, kg = lane >> 4;
+    const int wy = wave >> 1, wx = wave & 1;       // quarter of the tile this wave owns
+    const int64_t ntile = (a.nb + CB_T - 1) / CB_T;
+    int64_t jt = blockIdx.x;
+    const int64_t i0 = (int64_t)blockIdx.y * CB_T;
+    // staging role of this thread: feature pair sk, sk + 1 of the rows srow + 8 u (u = 0..3) of the tile.  Eight lanes
+    // read the 128 contiguous bytes of a row's 16 features (8 cache lines per load instruction of a wave); lanes 0-31
+    // hold four feature pairs x eight rows, which land in 64 distinct LDS banks when written transposed.
+    const int sk = 2 * ((lane & 3) + 4 * (lane >> 5)), srow = 32 * wave + ((lane >> 2) & 7);
+    // rows past the end of a block are clamped to its last row: what they produce is never stored or summed
+    const double* a_base = a.Xa + i0 * a.ldx + sk;
+    int a_off[4];
+#pragma unroll
+    for (int u = 0; u < 4; u++) a_off[u] = (int)(min((int64_t)(srow + 8 * u), a.na - 1 - i0) * a.ldx);
+    double rs[4][4];
+#pragma unroll
+    for (int p = 0; p < 4; p++)
+#pragma unroll
+        for (int reg = 0; reg < 4; reg++) rs[p][reg] = 0.0;
+    do {
+        const int64_t j0 = jt * CB_T;
+        const double* b_base = a.Xb + j0 * a.ldx + sk;
+        int b_off[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) b_off[u] = (int)(min((int64_t)(srow + 8 * u), a.nb - 1 - j0) * a.ldx);
+        d4 acc[4][4];
+#pragma unroll
+        for (int p = 0; p < 4; p++)
+#pragma unroll
+            for (int q = 0; q < 4; q++) acc[p][q] = (d4){0, 0, 0, 0};
+        double2 ra[4], rb[4];
+        auto fetch = [&](int k0) {
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                ra[u] = *reinterpret_cast<const double2*>(a_base + a_off[u] + k0);
+                rb[u] = *reinterpret_cast<const double2*>(b_base + b_off[u] + k0);
+            }
+        };
+        auto stage = [&](int buf) {
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                lds[buf][0][sk][srow + 8 * u] = ra[u].x;
+                lds[buf][0][sk + 1][srow + 8 * u] = ra[u].y;
+                lds[buf][1][sk][srow + 8 * u] = rb[u].x;
+                lds[buf][1][sk + 1][srow + 8 * u] = rb[u].y;
+            }
+        };
+        fetch(0);
+        __syncthreads();                 // the previous column tile's readers are done with the buffers
+        stage(0);
+        __syncthreads();
+        const int nstep = a.ldx / CB_KS;
+        for (int s_ = 0; s_ < nstep; s_++) {
+            const int buf = s_ & 1;
+            if (s_ + 1 < nstep) fetch((s_ + 1) * CB_KS);
+#pragma unroll
+            for (int j = 0; j < 4; j++) {            // four MFMA k-slices of the 16 staged features: feature 4 kg + j
+                double av[4], bv[4];
+#pragma unroll
+                for (int p = 0; p < 4; p++) av[p] = lds[buf][0][4 * kg + j][64 * wy + 16 * p + col];
+#pragma unroll
+                for (int q = 0; q < 4; q++) bv[q] = lds[buf][1][4 * kg + j][64 * wx + 16 * q + col];
+#pragma unroll
+                for (int p = 0; p < 4; p++)
+#pragma unroll
+                    for (int q = 0; q < 4; q++) acc[p][q] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[p], bv[q], acc[p][q], 0, 0, 0);
+            }
+            if (s_ + 1 < nstep) stage(buf ^ 1);
+            __syncthreads();
+        }
+        // dot products -> kernel values in place (D layout: reg -> row (i) = kg + 4*reg, column (j) = col); the norms of
+        // rows past the end are those of the last row (clamped like the rows themselves)
+        const int64_t iw = i0 + 64 * wy, jw = j0 + 64 * wx;
+        double ani[4][4];
+#pragma unroll
+        for (int p = 0; p < 4; p++)
+#pragma unroll
+            for (int reg = 0; reg < 4; reg++) ani[p][reg] = a.an[min(iw + 16 * p + kg + 4 * reg, a.na - 1)];
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const double bnj = a.bn[min(jw + 16 * q + col, a.nb - 1)];
+#pragma unroll
+            for (int p = 0; p < 4; p++)
+#pragma unroll
+                for (int reg = 0; reg < 4; reg++)     // the expression of cov_block_kernel, term for term
+                    acc[p][q][reg] = a.var * exp((ani[p][reg] + bnj - 2 * acc[p][q][reg]) / a.s);
+        }
+        // the whitened part is subtracted by the matrix cores into the same accumulators: acc += (-Va)^T Vb
+        for (int r0 = 0; r0 < a.m; r0 += 4) {
+            const int r = r0 + kg;
+            const bool r_ok = r < a.m;
+            double av[4], bv[4];
+#pragma unroll
+            for (int p = 0; p < 4; p++) {
+                const int64_t i = iw + 16 * p + col;
+                av[p] = (r_ok && i < a.na) ? -a.Va[(int64_t)r * a.ldva + i] : 0.0;
+            }
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                const int64_t j = jw + 16 * q + col;
+                bv[q] = (r_ok && j < a.nb) ? a.Vb[(int64_t)r * a.ldvb + j] : 0.0;
+            }
+#pragma unroll
+            for (int p = 0; p < 4; p++)
+#pragma unroll
+                for (int q = 0; q < 4; q++) acc[p][q] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[p], bv[q], acc[p][q], 0, 0, 0);
+        }
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const int64_t j = jw + 16 * q + col;
+#pragma unroll
+            for (int p = 0; p < 4; p++)
+#pragma unroll
+                for (int reg = 0; reg < 4; reg++) {
+                    const int64_t i = iw + 16 * p + kg + 4 * reg;
+                    if (ROWSUM) rs[p][reg] += j < a.nb ? fabs(acc[p][q][reg]) : 0.0;
+                    else if (i < a.na && j < a.nb) a.out[i * a.ldo + j] = acc[p][q][reg];
+                }
+        }
+        jt += gridDim.x;
+    } while (ROWSUM && jt < ntile);
+    if (ROWSUM) {
+        // the two waves that share a row quarter (wx = 0, 1) add their sums through LDS, in a fixed order
+        __syncthreads();
+        double* red = &lds[0][0][0][0];       // [2 (wy)][2 (wx)][64 rows]
+#pragma unroll
+        for (int p = 0; p < 4; p++)
+#pragma unroll
+            for (int reg = 0; reg < 4; reg++) {
+                double v = rs[p][reg];
+#pragma unroll
+                for (int off = 1; off < 16; off <<= 1) v += __shfl_xor(v, off, 64);
+                if (col == 0) red[(wy * 2 + wx) * 64 + 16 * p + kg + 4 * reg] = v;
+            }
+        __syncthreads();
+        if (tid < CB_T) {
+            const int64_t i = i0 + tid;
+            const int y = tid >> 6, r = tid & 63;
+            if (i < a.na) a.out[(int64_t)blockIdx.x * a.ldo + i] = red[(y * 2 + 0) * 64 + r] + red[(y * 2 + 1) * 64 + r];
+        }
     }
 }
 
@@ -382,6 +546,14 @@ extern "C" int ital_cov_block(const double* Xa, const double* an, int64_t na, co
     const int64_t gx = (nb + 16 * COV_MJ - 1) / (16 * COV_MJ), gy = (na + 64 * COV_MI - 1) / (64 * COV_MI);
     if (gy > 65535) return ital_fail(-22, "ital_cov_block: too many rows per call");
     CovArgs a = {Xa, an, na, Xb, bn, nb, ldx, Va, ldva, Vb, ldvb, m, var, -2.0 * length_scale * length_scale, out, ldo};
+    if (ITAL_COV_LDS && ((na + CB_T - 1) / CB_T) * ((nb + CB_T - 1) / CB_T) >= ITAL_COV_LDS_MIN_TILES) {
+        // large blocks: operands staged through LDS, 128 x 128 tiles
+        const int64_t lx = (nb + CB_T - 1) / CB_T, ly = (na + CB_T - 1) / CB_T;
+        if (ly > 65535) return ital_fail(-22, "ital_cov_block: too many rows per call");
+        // (a grid dealt to the XCDs in 8 x 8-tile patches for L2 reuse was measured: 2-9 % slower than this plain sweep)
+        hipLaunchKernelGGL(cov_block_lds_kernel<false>, dim3((unsigned)lx, (unsigned)ly), dim3(256), 0, stream, a);
+        return ital_check_launch("ital_cov_block(lds)");
+    }
     hipLaunchKernelGGL(cov_block_kernel<false>, dim3((unsigned)gx, (unsigned)gy), dim3(256), 0, stream, a);
     return ital_check_launch("ital_cov_block");
 }
@@ -399,7 +571,9 @@ extern "C" int ital_cov_abs_rowsum(const double* Xa, const double* an, int64_t n
     if (ldx % 16 != 0) return ital_fail(-22, "ital_cov_abs_rowsum: ldx must be a multiple of 16");
     if (m < 0 || (m > 0 && (!Va || !Vb))) return ital_fail(-22, "ital_cov_abs_rowsum: whitened blocks missing");
     if (!work || work_len < na) return ital_fail(-22, "ital_cov_abs_rowsum: work area smaller than na doubles");
-    const int64_t ntile = (nb + 16 * COV_MJ - 1) / (16 * COV_MJ), gy = (na + 64 * COV_MI - 1) / (64 * COV_MI);
+    const bool staged = ITAL_COV_LDS && ((na + CB_T - 1) / CB_T) * ((nb + CB_T - 1) / CB_T) >= ITAL_COV_LDS_MIN_TILES;
+    const int64_t ntile = staged ? (nb + CB_T - 1) / CB_T : (nb + 16 * COV_MJ - 1) / (16 * COV_MJ);
+    const int64_t gy = staged ? (na + CB_T - 1) / CB_T : (na + 64 * COV_MI - 1) / (64 * COV_MI);
     if (gy > 65535) return ital_fail(-22, "ital_cov_abs_rowsum: too many rows per call");
     // column splits: enough workgroups to fill the 256 CUs several times over, as many as the work area holds
     int64_t nsplit = (4096 + gy - 1) / gy;
@@ -407,7 +581,8 @@ extern "C" int ital_cov_abs_rowsum(const double* Xa, const double* an, int64_t n
     if (nsplit > work_len / na) nsplit = work_len / na;
     if (nsplit > 65535) nsplit = 65535;
     CovArgs a = {Xa, an, na, Xb, bn, nb, ldx, Va, ldva, Vb, ldvb, m, var, -2.0 * length_scale * length_scale, work, na};
-    hipLaunchKernelGGL(cov_block_kernel<true>, dim3((unsigned)nsplit, (unsigned)gy), dim3(256), 0, stream, a);
+    if (staged) hipLaunchKernelGGL(cov_block_lds_kernel<true>, dim3((unsigned)nsplit, (unsigned)gy), dim3(256), 0, stream, a);
+    else hipLaunchKernelGGL(cov_block_kernel<true>, dim3((unsigned)nsplit, (unsigned)gy), dim3(256), 0, stream, a);
     hipLaunchKernelGGL(rowsum_reduce_kernel, dim3((unsigned)((na + 255) / 256)), dim3(256), 0, stream, work, na, (int)nsplit, na,
                        accumulate, out);
     return ital_check_launch("ital_cov_abs_rowsum");

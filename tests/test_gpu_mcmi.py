@@ -57,6 +57,44 @@ def test_cov_block_vs_oracle(dev):
     assert np.all(got[:, len(b):] == -7.0)          # padding columns untouched
 
 
+def test_cov_block_lds_tiles_vs_oracle(dev):
+    """A block of more than 1024 tiles of 128 x 128 takes the LDS-staged kernel: ragged edges in both directions, checked
+    against the oracle's full predictive covariance, and bit for bit against the register-tiled kernel on a sub-block
+    small enough to be routed to it (same expression, same accumulation order over the features)."""
+    from ital_amd import GaussianProcess
+    from ital_amd import _lib
+    from ital_amd.gp import _ptr, _stream
+    from oracle.gp import OracleGP
+    rng = np.random.default_rng(12)
+    n, d = 4300, 21
+    X = rng.random((n, d))
+    ls = float(np.sqrt(d / 12.0))
+    gp = GaussianProcess(X, ls, var=1.2, device=dev)
+    ref = OracleGP(X, ls, var=1.2)
+    idx = rng.choice(n, 7, replace=False).tolist()
+    y = np.where(rng.random(7) > 0.5, 1.0, -1.0)
+    gp.update(idx, y)
+    ref.update(idx, y)
+    a0, a1, b0, b1 = 0, 4210, 70, 4300            # 33 x 34 tiles
+    Xa, Xb = gp.Xd[a0:a1].contiguous(), gp.Xd[b0:b1].contiguous()
+    Va, Vb = gp.V[: gp.m, a0:a1].contiguous(), gp.V[: gp.m, b0:b1].contiguous()
+    na, nb = gp.xnorm[a0:a1].contiguous(), gp.xnorm[b0:b1].contiguous()
+    ldo = b1 - b0 + 6
+    out = torch.full((a1 - a0, ldo), -7.0, dtype=torch.float64, device=dev)
+    lib = _lib.lib()
+    _lib.check(lib.ital_cov_block(_ptr(Xa), _ptr(na), a1 - a0, _ptr(Xb), _ptr(nb), b1 - b0, gp.ldx, _ptr(Va), a1 - a0,
+                                  _ptr(Vb), b1 - b0, gp.m, 1.2, ls, _ptr(out), ldo, _stream()))
+    got = out.cpu().numpy()
+    want = ref.predict_stored(np.arange(n), cov_mode="full")[1][a0:a1, b0:b1]
+    np.testing.assert_allclose(got[:, : b1 - b0], want, rtol=0, atol=2e-9)
+    assert np.all(got[:, b1 - b0:] == -7.0)         # padding columns untouched
+    sub = torch.empty((300, 500), dtype=torch.float64, device=dev)
+    _lib.check(lib.ital_cov_block(_ptr(Xa[3900:]), _ptr(na[3900:]), 300, _ptr(Xb[3700:]), _ptr(nb[3700:]), 500, gp.ldx,
+                                  _ptr(Va[:, 3900:]), a1 - a0, _ptr(Vb[:, 3700:]), b1 - b0, gp.m, 1.2, ls, _ptr(sub), 500,
+                                  _stream()))
+    assert torch.equal(sub, out[3900:4200, 3700:4200])
+
+
 @pytest.mark.parametrize("name", ["usps500_mcmi", "synth300_mcmi"])
 def test_golden_mcmi(dev, golden_dir, name):
     from ital_amd import MCMI_min
