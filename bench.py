@@ -364,6 +364,8 @@ def main():
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch with torch.distributed.run --nproc-per-node %d for --gpus %d" % (args.gpus, args.gpus))
+    if os.environ.get("ITAL_BENCH_ONE_DEVICE"):
+        local_rank = 0      # debugging aid for a 1-GPU box: all ranks on cuda:0 (use with ITAL_BENCH_BACKEND=gloo)
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     group = None
@@ -373,7 +375,11 @@ def main():
         os.environ.setdefault("MASTER_PORT", "29533")
         if args.force_collectives:
             os.environ["ITAL_FORCE_COLLECTIVES"] = "1"
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        backend = os.environ.get("ITAL_BENCH_BACKEND", "nccl")      # "nccl" is RCCL; gloo only to rehearse N > 1 on one GPU
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
         group = dist.group.WORLD
 
     from ital_amd import ITAL, mvn_stream
