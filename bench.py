@@ -225,8 +225,9 @@ def other_workloads(X, rel, device):
         roofs["cov_block_kernel"] = dict({"bound": "mfma", "achieved": ach, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                                           "frac": ach / FP64_MFMA_PEAK_TFLOPS, "avg_launch_ms": sec * 1e3,
                                           "note": "1000 x 1000 block: 0.55 GFLOP per launch, launch-latency bound at the "
-                                                  "reference's subsample; 42 TFLOP/s at 9273^2 (profiles/r1_mcmi_*, "
-                                                  "profiles/r2_mcmi_pmc_summary.csv: launches of both sizes averaged)",
+                                                  "reference's subsample; blocks of >= 1024 tiles of 128^2 take the LDS-staged "
+                                                  "kernel: 45 TFLOP/s at 9273^2 x 256, 60 at 20000^2 x 512 "
+                                                  "(tools/cov_bench.py, DESIGN.md section 3)",
                                           "traffic": None})
     ms = prof.get(("mcmi_score", BATCH), [])
     if ms:

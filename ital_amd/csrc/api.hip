@@ -20,5 +20,18 @@ int ital_check_launch(const char* who) {
     return -5;
 }
 
+int ital_raise_lds_limit(const void* kernel, int bytes, ItalLdsFlags& flags, const char* who) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return ital_fail(-5, "cannot tell the current device");
+    if (flags.done[dev]) return 0;
+    if (hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes) != hipSuccess) {
+        snprintf(g_err, sizeof(g_err), "%s: cannot raise the dynamic LDS limit to %d bytes", who, bytes);
+        (void)hipGetLastError();
+        return -12;
+    }
+    flags.done[dev] = true;
+    return 0;
+}
+
 extern "C" const char* ital_last_error(void) { return g_err; }
 extern "C" const char* ital_version(void) { return "ital_hip 0.1 (gfx950)"; }

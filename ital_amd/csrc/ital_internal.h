@@ -6,3 +6,8 @@
 int ital_fail(int code, const char* msg);
 // hipGetLastError() after a launch; 0 or a recorded failure.
 int ital_check_launch(const char* who);
+
+// Raises a kernel's dynamic-LDS limit once per device (the attribute belongs to the function on ONE device; a process that
+// drives several GPUs must set it on each).  `done`: the caller's static per-device flags.  0 or a recorded failure.
+struct ItalLdsFlags { bool done[16] = {}; };
+int ital_raise_lds_limit(const void* kernel, int bytes, ItalLdsFlags& flags, const char* who);

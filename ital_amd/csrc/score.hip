@@ -506,12 +506,11 @@ static int launch_qmc(const ScoreArgs& a, double* work, int64_t work_doubles, hi
     if (slab > a.n_cand) slab = a.n_cand;
     const size_t lds_main = (size_t)4 * Q::WAVE_DOUBLES * sizeof(double);
     const size_t lds_prep = (size_t)Q::PREP_THREADS * Q::SLAB * sizeof(double);
-    static bool attr_done = false;
-    if (!attr_done && lds_prep > 48 * 1024) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&qmc_prep_kernel<T>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_prep);
-        if (e != hipSuccess) return ital_fail(-12, "ital_score_step: cannot raise the dynamic LDS limit");
-        attr_done = true;
+    static ItalLdsFlags lds_flags;
+    if (lds_prep > 48 * 1024) {
+        const int rc = ital_raise_lds_limit(reinterpret_cast<const void*>(&qmc_prep_kernel<T>), (int)lds_prep, lds_flags,
+                                            "ital_score_step");
+        if (rc) return rc;
     }
     double* recs = work;
     double* terms = recs + slab * Q::NPAT * Q::REC;

@@ -1335,13 +1335,10 @@ extern "C" int ital_score_generic(const ital_gscore_desc* d, hipStream_t stream)
             // a slab is a few hundred candidates: one wave each would leave most of the chip idle during the preparation
             const int npass = (int)((total + chunk_p - 1) / chunk_p);
             g.nsplit = d->mc_fb > 0 ? 1 : (npass < ITAL_GEN_PREP_SPLIT ? (npass < 1 ? 1 : npass) : ITAL_GEN_PREP_SPLIT);
-            static bool prep_attr = false;
-            if (!prep_attr) {
-                if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gen_prep_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                        160 * 1024) != hipSuccess)
-                    return ital_fail(-12, "ital_score_generic: cannot raise the dynamic LDS limit");
-                prep_attr = true;
-            }
+            static ItalLdsFlags prep_flags;
+            if (const int rc = ital_raise_lds_limit(reinterpret_cast<const void*>(&gen_prep_kernel), 160 * 1024, prep_flags,
+                                                    "ital_score_generic"))
+                return rc;
             if (lds_p > 160 * 1024) return ital_fail(-12, "ital_score_generic: LDS budget exceeded");
             if (hipEventRecord(ps->start, stream) != hipSuccess || hipStreamWaitEvent(ps->prep, ps->start, 0) != hipSuccess ||
                 hipStreamWaitEvent(ps->main, ps->start, 0) != hipSuccess || hipStreamWaitEvent(ps->comb, ps->start, 0) != hipSuccess)
@@ -1384,13 +1381,10 @@ extern "C" int ital_score_generic(const ital_gscore_desc* d, hipStream_t stream)
     }
 #define ITAL_GEN_LAUNCH(NMAX_, NH_, TFIX_, CLIP_)                                                                             \
     do {                                                                                                               \
-        static bool attr_done = false;                                                                                 \
-        if (!attr_done) {                                                                                              \
-            if (hipFuncSetAttribute(reinterpret_cast<const void*>(&score_generic_kernel<NMAX_, NH_, TFIX_, CLIP_>),            \
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)             \
-                return ital_fail(-12, "ital_score_generic: cannot raise the dynamic LDS limit");                        \
-            attr_done = true;                                                                                          \
-        }                                                                                                              \
+        static ItalLdsFlags lds_flags;                                                                                 \
+        if (const int rc = ital_raise_lds_limit(reinterpret_cast<const void*>(&score_generic_kernel<NMAX_, NH_, TFIX_, CLIP_>), \
+                                                160 * 1024, lds_flags, "ital_score_generic"))                          \
+            return rc;                                                                                                 \
         hipLaunchKernelGGL((score_generic_kernel<NMAX_, NH_, TFIX_, CLIP_>), dim3((unsigned)blocks), dim3(128), lds, stream, a); \
     } while (0)
     if (clip) {     // grouped probabilities: the instantiations that carry the group passes

@@ -174,14 +174,10 @@ extern "C" int ital_topk(const double* v, int64_t n, int64_t index_offset, int k
         hipLaunchKernelGGL(topk_pick_kernel, dim3(1), dim3(256), 0, stream, w, pass);
     }
     hipLaunchKernelGGL(topk_collect_kernel, dim3(blocks), dim3(256), 0, stream, v, n, index_offset, w, out_vals, out_idx);
-    static bool attr_done = false;
+    static ItalLdsFlags lds_flags;
     const size_t lds = (size_t)TOPK_MAX * 16;
-    if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&topk_finish_kernel),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return ital_fail(-12, "ital_topk: cannot raise the dynamic LDS limit");
-        attr_done = true;
-    }
+    if (const int rc = ital_raise_lds_limit(reinterpret_cast<const void*>(&topk_finish_kernel), (int)lds, lds_flags, "ital_topk"))
+        return rc;
     hipLaunchKernelGGL(topk_finish_kernel, dim3(1), dim3(1024), lds, stream, v, n, index_offset, w, k, out_vals, out_idx);
     return ital_check_launch("ital_topk");
 }
