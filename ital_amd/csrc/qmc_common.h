@@ -194,13 +194,13 @@ __device__ __forceinline__ double qmc_lane_sum(const double* __restrict__ lat,
 // coordinates are formed per stage instead of up front; the conditioned values y (2 NH chains x T-1) stay in registers
 // because every index is a compile-time constant.
 template <int T, int NCB>
-__device__ __forceinline__ double eval_chains_big(const int (&kk)[(NCB + 1) / 2], const int (&so)[(NCB + 1) / 2],
-                                                  const bool (&okh)[(NCB + 1) / 2], const double* __restrict__ lat,
+__device__ __forceinline__ double eval_chains_big(const int (&kk)[NCB], const int (&so)[NCB], const bool (&anti)[NCB],
+                                                  const bool (&ok)[NCB], const double* __restrict__ lat,
                                                   const double* __restrict__ slab, unsigned infi_c, double* tailq, int lane) {
     constexpr int NDIM = T - 1, NCOV = T * (T + 1) / 2;
     double yy[NCB][NDIM], ff[NCB];
 #pragma unroll
-    for (int c = 0; c < NCB; c++) ff[c] = okh[c >> 1] ? 1.0 : 0.0;
+    for (int c = 0; c < NCB; c++) ff[c] = ok[c] ? 1.0 : 0.0;
 #pragma unroll
     for (int i = 0; i < T; i++) {
         const bool lower = (infi_c >> i) & 1u;
@@ -224,11 +224,10 @@ __device__ __forceinline__ double eval_chains_big(const int (&kk)[(NCB + 1) / 2]
             const double w = lower ? 1.0 - ph : ph;
             ff[c] *= w;
             if (i < T - 1) {
-                const int h = c >> 1;
-                const double v = kk[h] * lat[so[h] + i] + lat[8 * NDIM + so[h] + i];
+                const double v = kk[c] * lat[so[c] + i] + lat[8 * NDIM + so[c] + i];
                 const double fr = v - floor(v);
                 const double x0 = fabs(2 * fr - 1);
-                pin[c] = fma((c & 1) ? 1 - x0 : x0, w, d);
+                pin[c] = fma(anti[c] ? 1 - x0 : x0, w, d);
             }
         }
         if (i < T - 1) {
@@ -244,25 +243,29 @@ __device__ __forceinline__ double eval_chains_big(const int (&kk)[(NCB + 1) / 2]
     return acc;
 }
 
-template <int T, int NH>
+// NCB chains per lane and round: whole lattice items (a point and its antithetic partner on the same lane) first; with an
+// odd NCB the last chain of lanes 2i and 2i + 1 is the point and the partner of one more item (32 NCB items per round).
+template <int T, int NCB>
 __device__ __forceinline__ double qmc_lane_sum_big(const double* __restrict__ lat, const double* __restrict__ slab,
                                                    unsigned infi_c, double* __restrict__ tailq, int lane) {
     constexpr int NDIM = T - 1, PRIME = P_TAB[(NDIM < 10 ? NDIM : 10) - 1];
-    constexpr int NC = 2 * NH, NITEM = 8 * PRIME;
+    constexpr int NITEM = 8 * PRIME, PER_ROUND = 32 * NCB;
     double acc = 0.0;
-    for (int base = 0; base < NITEM; base += 64 * NH) {
-        int kk[NH], so[NH];
-        bool okh[NH];
+    for (int base = 0; base < NITEM; base += PER_ROUND) {
+        int kk[NCB], so[NCB];
+        bool anti[NCB], ok[NCB];
 #pragma unroll
-        for (int h = 0; h < NH; h++) {
-            const int item = base + 64 * h + lane;
-            okh[h] = item < NITEM;
-            const int it = okh[h] ? item : 0;
+        for (int c = 0; c < NCB; c++) {
+            const bool paired = c < 2 * (NCB / 2);
+            const int item = paired ? base + 64 * (c >> 1) + lane : base + 64 * (NCB / 2) + (lane >> 1);
+            anti[c] = paired ? (c & 1) : (lane & 1);
+            ok[c] = item < NITEM;
+            const int it = ok[c] ? item : 0;
             const int sft = it / PRIME;
-            kk[h] = it - sft * PRIME + 1;
-            so[h] = sft * NDIM;
+            kk[c] = it - sft * PRIME + 1;
+            so[c] = sft * NDIM;
         }
-        acc += eval_chains_big<T, NC>(kk, so, okh, lat, slab, infi_c, tailq, lane);
+        acc += eval_chains_big<T, NCB>(kk, so, anti, ok, lat, slab, infi_c, tailq, lane);
     }
     return acc;
 }

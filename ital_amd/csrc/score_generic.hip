@@ -47,8 +47,11 @@
 #define ITAL_GEN_HOTK 1   // exp / log coefficients of the compile-time-dimension evaluator as vector-register operands (HotK:
                           // 197 -> 20 spilled VGPRs, 385 -> 193 spilled SGPRs in the t = 4 instantiation; noisy-user step 61.8 -> 59.1 ms)
 #endif
-#ifndef ITAL_GEN_BIG_NH
-#define ITAL_GEN_BIG_NH 1      // lattice items per lane and round of the compile-time evaluator for 7 .. 16 variables
+#ifndef ITAL_GEN_BIG_NCB
+// chains per lane and round of the compile-time evaluator for 7 .. 16 variables: three where two waves per SIMD leave room
+// for them (the tail branch of Phi^-1 then runs on fuller waves: -6 % at 10-12 variables, -1 % at 14; at 15 and 16 the
+// 63-76 spilled registers cost more than that, +3 % / +20 %); two at 7-9, where three waves per SIMD are worth more
+#define ITAL_GEN_BIG_NCB(T) ((T) >= 10 && (T) <= 14 ? 3 : 2)
 #endif
 #ifndef ITAL_GEN_MAIN_WAVES
 #define ITAL_GEN_MAIN_WAVES(T) ((T) > 0 && (T) < 10 ? 3 : 2)   // measured: from 10 variables on three waves per SIMD spill
@@ -1153,7 +1156,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(ITAL_GEN_MA
         double value;
         if (T >= 7) {
             constexpr int TB = T >= 7 ? T : 7, NDIMB = TB - 1;
-            value = wave_sum(qmc_lane_sum_big<TB, ITAL_GEN_BIG_NH>(rec + g.lat, rec, infi, tailq, lane)) /
+            value = wave_sum(qmc_lane_sum_big<TB, ITAL_GEN_BIG_NCB(TB)>(rec + g.lat, rec, infi, tailq, lane)) /
                     (16.0 * P_TAB[(NDIMB < 10 ? NDIMB : 10) - 1]);
         } else if (T > 0) value = qmc_eval_fixed_inl<(T > 0 && T < 7 ? T : 3)>(rec, infi, rec + g.lat, lane, tailq);
         else value = qmc_eval<ITAL_GENERIC_MAX_DIM, 1>(n, rec, infi, (unsigned)((m >> 40) & 0xffffffu), rec + g.lat, lane, tailq);

@@ -149,7 +149,8 @@ def test_one_million_candidates(dev):
 
 
 @pytest.mark.parametrize("kw,n,k", [(dict(label_prob=0.6, mistake_prob=0.2), 300, 4), (dict(mistake_prob=0.15), 200, 5),
-                                    (dict(monte_carlo_num_rel=1), 400, 9), (dict(label_estimation="pessimistic", mistake_prob=0.1), 150, 3)])
+                                    (dict(monte_carlo_num_rel=1), 400, 9), (dict(label_estimation="pessimistic", mistake_prob=0.1), 150, 3),
+                                    (dict(monte_carlo_num_rel=1), 250, 15)])    # 10-14 variables: three chains per lane
 def test_general_scorer_pipeline_equals_its_single_kernel(dev, kw, n, k):
     """Plain mode of ital_score_generic: three kernels on internal streams (prepare / lattice sums / combine, slabs of the
     workspace) against the one kernel that does everything per candidate -- same calls, same stream offsets, same order of
