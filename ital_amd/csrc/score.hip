@@ -29,7 +29,7 @@
 #define ITAL_QMC_HOTK 1   // exp / log coefficients of the lattice loop as vector-register operands (device_math.h HotK)
 #endif
 #ifndef ITAL_QMC_MAIN_NH
-#define ITAL_QMC_MAIN_NH(T) ((T) == 3 ? 3 : 2)
+#define ITAL_QMC_MAIN_NH(T) ((T) == 4 ? 2 : 3)   // t = 4 at three waves per SIMD has no room for six chains; 25 000 x 512, k = 8: 1.90 -> 1.84 s
 #endif
 #ifndef ITAL_QMC_WAVES
 #define ITAL_QMC_WAVES(T) ((T) <= 4 ? 3 : 2)   // waves per SIMD the register allocation aims at (measured)

@@ -48,14 +48,18 @@
                           // 197 -> 20 spilled VGPRs, 385 -> 193 spilled SGPRs in the t = 4 instantiation; noisy-user step 61.8 -> 59.1 ms)
 #endif
 #ifndef ITAL_GEN_BIG_NCB
-// chains per lane and round of the compile-time evaluator for 7 .. 16 variables: three where two waves per SIMD leave room
-// for them (the tail branch of Phi^-1 then runs on fuller waves: -6 % at 10-12 variables, -1 % at 14; at 15 and 16 the
-// 63-76 spilled registers cost more than that, +3 % / +20 %); two at 7-9, where three waves per SIMD are worth more
-#define ITAL_GEN_BIG_NCB(T) ((T) >= 10 && (T) <= 14 ? 3 : 2)
+// chains per lane and round of the compile-time evaluator for 7 .. 16 variables, at two waves per SIMD: as many as the
+// 256 registers hold without spilling much -- the tail branch of Phi^-1 then runs on fuller waves.  Measured per step
+// (40 000 x 512, monte_carlo_num_rel = 1): 7 variables 57 -> 44 ms, 8: 122 -> 78, 9: 235 -> 160 (these ran two chains at
+// three waves per SIMD before), 10: 318 -> 282 (four chains), 11-14: three chains (-6 % .. -1 %; four lose 10 % at 12),
+// 15 / 16: two (three spill 63 / 76 registers: +3 % / +20 %)
+#define ITAL_GEN_BIG_NCB(T) ((T) <= 10 ? 4 : (T) <= 14 ? 3 : 2)
+#endif
+#ifndef ITAL_GEN_TAILQ
+#define ITAL_GEN_TAILQ 384     // doubles per wave of the Phi^-1 tail queue of the pipeline's lattice sums: up to 6 chains per lane
 #endif
 #ifndef ITAL_GEN_MAIN_WAVES
-#define ITAL_GEN_MAIN_WAVES(T) ((T) > 0 && (T) < 10 ? 3 : 2)   // measured: from 10 variables on three waves per SIMD spill
-                                                               // (C5' share 65 s against 22 s)
+#define ITAL_GEN_MAIN_WAVES(T) ((T) > 0 && (T) < 7 ? 3 : 2)    // three waves per SIMD (168 registers) only up to 6 variables
 #endif
 #ifndef ITAL_GEN_TFIX_MAX
 #define ITAL_GEN_TFIX_MAX 16   // largest dimension the pipeline takes (plain mode)
@@ -1136,7 +1140,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(ITAL_GEN_MA
     extern __shared__ double lds_all[];
     const int lane = threadIdx.x & 63;
     const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    double* rec = lds_all + (size_t)wid * (g.R + 256);
+    double* rec = lds_all + (size_t)wid * (g.R + ITAL_GEN_TAILQ);
     double* tailq = rec + g.R;
     const unsigned int count = g.count[T > 0 ? 0 : 1];
     const unsigned int last = (unsigned int)(g.slab_n * g.total) - 1u;
@@ -1334,7 +1338,7 @@ extern "C" int ital_score_generic(const ital_gscore_desc* d, hipStream_t stream)
             ap.master = 0;
             ap.wave_doubles = fixed + chunk_p * stride_p;
             const size_t lds_p = (size_t)2 * ap.wave_doubles * sizeof(double);
-            const size_t lds_m = (size_t)4 * (g.R + 256) * sizeof(double);
+            const size_t lds_m = (size_t)4 * (g.R + ITAL_GEN_TAILQ) * sizeof(double);
             // a slab is a few hundred candidates: one wave each would leave most of the chip idle during the preparation
             const int npass = (int)((total + chunk_p - 1) / chunk_p);
             g.nsplit = d->mc_fb > 0 ? 1 : (npass < ITAL_GEN_PREP_SPLIT ? (npass < 1 ? 1 : npass) : ITAL_GEN_PREP_SPLIT);
