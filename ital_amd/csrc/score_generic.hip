@@ -55,11 +55,17 @@
 // 15 / 16: two (three spill 63 / 76 registers: +3 % / +20 %)
 #define ITAL_GEN_BIG_NCB(T) ((T) <= 10 ? 4 : (T) <= 14 ? 3 : 2)
 #endif
+#ifndef ITAL_GEN_FIXED_NH
+// lattice items per lane and round of the pipeline's evaluator for 3 .. 6 variables: three (six chains) at 5 and 6
+// variables, which then run at two waves per SIMD (per step at 40 000 x 512: 13.6 -> 11.3 ms, 26.5 -> 20.5 ms; four items
+// lose again); two at 3 and 4, three waves per SIMD
+#define ITAL_GEN_FIXED_NH(T) ((T) == 5 || (T) == 6 ? 3 : 2)
+#endif
 #ifndef ITAL_GEN_TAILQ
 #define ITAL_GEN_TAILQ 384     // doubles per wave of the Phi^-1 tail queue of the pipeline's lattice sums: up to 6 chains per lane
 #endif
 #ifndef ITAL_GEN_MAIN_WAVES
-#define ITAL_GEN_MAIN_WAVES(T) ((T) > 0 && (T) < 7 ? 3 : 2)    // three waves per SIMD (168 registers) only up to 6 variables
+#define ITAL_GEN_MAIN_WAVES(T) ((T) > 0 && (T) < 5 ? 3 : 2)    // three waves per SIMD (168 registers) only up to 4 variables
 #endif
 #ifndef ITAL_GEN_TFIX_MAX
 #define ITAL_GEN_TFIX_MAX 16   // largest dimension the pipeline takes (plain mode)
@@ -672,8 +678,8 @@ __device__ double qmc_eval(int n, const double* __restrict__ slab, unsigned infi
 
 // One MVNDST pass for a call of compile-time dimension T whose rows all close their own group (no linearly dependent
 // variable): the evaluator of the perfect-user fast path (score.hip) -- factor and limits as wave-uniform scalars, fully
-// unrolled, 2 lattice items x antithetic partner per lane.
-template <int T>
+// unrolled, NHF lattice items x antithetic partner per lane.
+template <int T, int NHF = 2>
 __device__ __forceinline__ double qmc_eval_fixed_inl(const double* __restrict__ slab, unsigned infi,
                                                      const double* __restrict__ lat, int lane, double* __restrict__ tailq) {
     constexpr int NDIM = T - 1, NCOV = T * (T + 1) / 2, NCOR = T * (T - 1) / 2;
@@ -688,9 +694,9 @@ __device__ __forceinline__ double qmc_eval_fixed_inl(const double* __restrict__ 
 #if ITAL_GEN_HOTK
     HotK kk;
     kk.load();
-    const double acc = qmc_lane_sum<T, HotK>(lat, cf, lm, infi, tailq, lane, kk);
+    const double acc = qmc_lane_sum<T, HotK, NHF>(lat, cf, lm, infi, tailq, lane, kk);
 #else
-    const double acc = qmc_lane_sum<T>(lat, cf, lm, infi, tailq, lane);
+    const double acc = qmc_lane_sum<T, LitK, NHF>(lat, cf, lm, infi, tailq, lane);
 #endif
     return wave_sum(acc) / (16.0 * PRIME);
 }
@@ -750,7 +756,7 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(ITAL_GEN_WA
     int* usort = reinterpret_cast<int*>(SigU + ldS * ldS);
     int* ipos = usort + GN;
     double* tailq = SigU + ldS * ldS + (GN + GR + 1) / 2;
-    double* slabs = tailq + 256;
+    double* slabs = tailq + ITAL_GEN_TAILQ;
 
     const int row = d.cand[p];
     const int64_t gi = d.row_offset + row;
@@ -1162,7 +1168,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(ITAL_GEN_MA
             constexpr int TB = T >= 7 ? T : 7, NDIMB = TB - 1;
             value = wave_sum(qmc_lane_sum_big<TB, ITAL_GEN_BIG_NCB(TB)>(rec + g.lat, rec, infi, tailq, lane)) /
                     (16.0 * P_TAB[(NDIMB < 10 ? NDIMB : 10) - 1]);
-        } else if (T > 0) value = qmc_eval_fixed_inl<(T > 0 && T < 7 ? T : 3)>(rec, infi, rec + g.lat, lane, tailq);
+        } else if (T > 0) {
+            constexpr int TF = T > 0 && T < 7 ? T : 3;
+            value = qmc_eval_fixed_inl<TF, ITAL_GEN_FIXED_NH(TF)>(rec, infi, rec + g.lat, lane, tailq);
+        }
         else value = qmc_eval<ITAL_GENERIC_MAX_DIM, 1>(n, rec, infi, (unsigned)((m >> 40) & 0xffffffu), rec + g.lat, lane, tailq);
         if (lane == 0) meta[1] = value;
         pairs += 16ull * P_TAB[(n - 1 < 10 ? n - 1 : 10) - 1] * (n - 1);
@@ -1303,7 +1312,7 @@ extern "C" int ital_score_generic(const ital_gscore_desc* d, hipStream_t stream)
     a.slab = slab;
     a.lat = slab + fs_doubles(nr);
     a.master = clip ? slab + fs_doubles(nr) + 16 * (nUmax - 1) : 0;
-    const int fixed = nUmax + nUmax * nUmax + (GN + GR + 1) / 2 + 256;
+    const int fixed = nUmax + nUmax * nUmax + (GN + GR + 1) / 2 + ITAL_GEN_TAILQ;
     a.ldS = nUmax;
     a.wave_doubles = fixed + chunk * stride;
     const size_t lds = (size_t)2 * a.wave_doubles * sizeof(double);
