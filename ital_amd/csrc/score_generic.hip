@@ -61,6 +61,9 @@
 // lose again); two at 3 and 4, three waves per SIMD
 #define ITAL_GEN_FIXED_NH(T) ((T) == 5 || (T) == 6 ? 3 : 2)
 #endif
+#ifndef ITAL_GEN_ONE_TRIP
+#define ITAL_GEN_ONE_TRIP(T) ((T) >= 3 && (T) <= 6)   // dimensions whose lattice-sum launch runs one call per wave
+#endif
 #ifndef ITAL_GEN_TAILQ
 #define ITAL_GEN_TAILQ 384     // doubles per wave of the Phi^-1 tail queue of the pipeline's lattice sums: up to 6 chains per lane
 #endif
@@ -1152,7 +1155,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(ITAL_GEN_MA
     const unsigned int last = (unsigned int)(g.slab_n * g.total) - 1u;
     const unsigned int nwaves = gridDim.x * 4;
     unsigned long long pairs = 0;
-    for (unsigned int e = blockIdx.x * 4 + wid; e < count; e += nwaves) {
+    auto integrate = [&](unsigned int e) {
         const unsigned int item = g.list[T > 0 ? e : last - e];
         double* meta = g.meta + (size_t)item * 2;
         const long long m = __double_as_longlong(uniform_f64(meta[0]));
@@ -1176,6 +1179,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(ITAL_GEN_MA
         if (lane == 0) meta[1] = value;
         pairs += 16ull * P_TAB[(n - 1 < 10 ? n - 1 : 10) - 1] * (n - 1);
         wave_sync();
+    };
+    if (ITAL_GEN_ONE_TRIP(T)) {
+        // one call per wave, the grid covers the capacity of the list: no loop around the evaluator, whose register
+        // allocation then is the one of the perfect-user kernel (inside the striding loop the t = 4 instantiation spills
+        // 41 doubles and moves 3.5 GB of scratch per launch)
+        const unsigned int e = blockIdx.x * 4 + wid;
+        if (e < count) integrate(e);
+    } else {
+        for (unsigned int e = blockIdx.x * 4 + wid; e < count; e += nwaves) integrate(e);
     }
     if (lane == 0 && pair_count && pairs) atomicAdd(pair_count, pairs);
 }
@@ -1375,7 +1387,8 @@ extern "C" int ital_score_generic(const ital_gscore_desc* d, hipStream_t stream)
                 (void)hipEventRecord(ps->prep_done[buf], ps->prep);
                 (void)hipStreamWaitEvent(ps->main, ps->prep_done[buf], 0);
                 const unsigned mb = 768;     // 3 workgroups of 4 waves per CU; the waves stride over the slab's list
-#define ITAL_GEN_MAIN(T_) case T_: hipLaunchKernelGGL(gen_main_kernel<T_>, dim3(mb), dim3(256), lds_m, ps->main, g, d->pair_count); break;
+                const unsigned cap_b = (unsigned)((g.slab_n * total + 3) / 4);     // the whole list, one call per wave
+#define ITAL_GEN_MAIN(T_) case T_: hipLaunchKernelGGL(gen_main_kernel<T_>, dim3(ITAL_GEN_ONE_TRIP(T_) ? cap_b : mb), dim3(256), lds_m, ps->main, g, d->pair_count); break;
                 switch (tfix_p) {
                     ITAL_GEN_MAIN(3) ITAL_GEN_MAIN(4) ITAL_GEN_MAIN(5) ITAL_GEN_MAIN(6) ITAL_GEN_MAIN(7) ITAL_GEN_MAIN(8)
                     ITAL_GEN_MAIN(9) ITAL_GEN_MAIN(10) ITAL_GEN_MAIN(11) ITAL_GEN_MAIN(12) ITAL_GEN_MAIN(13) ITAL_GEN_MAIN(14)

@@ -121,6 +121,17 @@ for case in range(cases):
             if got != want and [int(inv.ravel()[i]) for i in got] == [int(inv.ravel()[i]) for i in want]:
                 status = "ok"                       # a tie between identical rows resolved the other way: same batch
                 break
+            if got != want and traced:
+                # a numerical tie: at the first step that differs the oracle itself rates the two samples equal to 1e-12
+                # (candidates that carry no information: all MI values agree to the last bits, the last bit picks)
+                t0 = next(i for i in range(min(len(got), len(want))) if got[i] != want[i])
+                cand0, vals0 = traced[t0]
+                at = {int(c): float(v) for c, v in zip(cand0, vals0)}
+                if got[t0] in at and abs(at[got[t0]] - at[want[t0]]) <= 1e-12 * abs(at[want[t0]]):
+                    status = "ok"
+                    print("case %3d: numerical tie at step %d (oracle MI %.17g vs %.17g), batch not compared further"
+                          % (case, t0, at[got[t0]], at[want[t0]]), flush=True)
+                    break
             if got != want:
                 status = "PICKS %s != %s" % (got, want)
             elif worst > 1e-5:
