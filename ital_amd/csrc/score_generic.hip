@@ -62,7 +62,11 @@
 #define ITAL_GEN_FIXED_NH(T) ((T) == 5 || (T) == 6 ? 3 : 2)
 #endif
 #ifndef ITAL_GEN_ONE_TRIP
-#define ITAL_GEN_ONE_TRIP(T) ((T) >= 3 && (T) <= 6)   // dimensions whose lattice-sum launch runs one call per wave
+// dimensions whose lattice-sum launch runs one call per wave (grid = capacity of the list; waves beyond its length leave
+// at once) instead of a fixed grid of waves striding over the list: all compile-time evaluators.  Around the evaluator the
+// striding loop cost registers in every instantiation (t = 4: 41 doubles spilled, 3.5 GB of scratch traffic per launch);
+// without it: noisy-user t = 4 step 42 -> 34.8 ms, monte_carlo_num_rel steps at 7 .. 16 variables -7 % .. -20 %
+#define ITAL_GEN_ONE_TRIP(T) ((T) >= 3)
 #endif
 #ifndef ITAL_GEN_TAILQ
 #define ITAL_GEN_TAILQ 384     // doubles per wave of the Phi^-1 tail queue of the pipeline's lattice sums: up to 6 chains per lane
@@ -1140,9 +1144,10 @@ __global__ __launch_bounds__(128) void gen_prep_kernel(GArgs a, GPipe g) {
     }
 }
 
-// Waves stride over the list of calls to integrate (a fixed grid: the length of the list is only known on the device).
-// T > 0: the regular calls (T variables, every row closes its own group) with the compile-time evaluator; T == 0: the calls
-// with linearly dependent variables, from the back of the list, with the runtime one.
+// The lattice sums of the list of calls to integrate; its length is only known on the device.  T > 0: the regular calls (T
+// variables, every row closes its own group) with the compile-time evaluator, one call per wave in a grid that covers the
+// capacity of the list (ITAL_GEN_ONE_TRIP); T == 0: the calls with linearly dependent variables, from the back of the
+// list, with the runtime evaluator in a small fixed grid of waves that stride over them.
 template <int T>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(ITAL_GEN_MAIN_WAVES(T), ITAL_GEN_MAIN_WAVES(T)))) void gen_main_kernel(
     GPipe g, unsigned long long* pair_count) {
@@ -1182,8 +1187,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(ITAL_GEN_MA
     };
     if (ITAL_GEN_ONE_TRIP(T)) {
         // one call per wave, the grid covers the capacity of the list: no loop around the evaluator, whose register
-        // allocation then is the one of the perfect-user kernel (inside the striding loop the t = 4 instantiation spills
-        // 41 doubles and moves 3.5 GB of scratch per launch)
+        // allocation then is the one of the perfect-user kernel
         const unsigned int e = blockIdx.x * 4 + wid;
         if (e < count) integrate(e);
     } else {
