@@ -213,15 +213,13 @@ constexpr int CB_T = 128;              // tile edge
 constexpr int CB_KS = 16;              // features per stage
 constexpr int CB_LD = CB_T + 4;        // padded row stride of a staged tile (doubles)
 
-template <bool ROWSUM>
 __global__ __launch_bounds__(256, 2) void cov_block_lds_kernel(CovArgs a) {
     __shared__ double lds[2][2][CB_KS][CB_LD];     // [buffer][A / B][feature][row]
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
     const int col = lane & 15, kg = lane >> 4;
     const int wy = wave >> 1, wx = wave & 1;       // quarter of the tile this wave owns
-    const int64_t ntile = (a.nb + CB_T - 1) / CB_T;
-    int64_t jt = blockIdx.x;
+    const int64_t jt = blockIdx.x;
     const int64_t i0 = (int64_t)blockIdx.y * CB_T;
     // staging role of this thread: feature pair sk, sk + 1 of the rows srow + 8 u (u = 0..3) of the tile.  Eight lanes
     // read the 128 contiguous bytes of a row's 16 features (8 cache lines per load instruction of a wave); lanes 0-31
@@ -232,12 +230,7 @@ __global__ __launch_bounds__(256, 2) void cov_block_lds_kernel(CovArgs a) {
     int a_off[4];
 #pragma unroll
     for (int u = 0; u < 4; u++) a_off[u] = (int)(min((int64_t)(srow + 8 * u), a.na - 1 - i0) * a.ldx);
-    double rs[4][4];
-#pragma unroll
-    for (int p = 0; p < 4; p++)
-#pragma unroll
-        for (int reg = 0; reg < 4; reg++) rs[p][reg] = 0.0;
-    do {
+    {
         const int64_t j0 = jt * CB_T;
         const double* b_base = a.Xb + j0 * a.ldx + sk;
         int b_off[4];
@@ -266,7 +259,6 @@ __global__ __launch_bounds__(256, 2) void cov_block_lds_kernel(CovArgs a) {
             }
         };
         fetch(0);
-        __syncthreads();                 // the previous column tile's readers are done with the buffers
         stage(0);
         __syncthreads();
         const int nstep = a.ldx / CB_KS;
@@ -333,30 +325,8 @@ __global__ __launch_bounds__(256, 2) void cov_block_lds_kernel(CovArgs a) {
 #pragma unroll
                 for (int reg = 0; reg < 4; reg++) {
                     const int64_t i = iw + 16 * p + kg + 4 * reg;
-                    if (ROWSUM) rs[p][reg] += j < a.nb ? fabs(acc[p][q][reg]) : 0.0;
-                    else if (i < a.na && j < a.nb) a.out[i * a.ldo + j] = acc[p][q][reg];
+                    if (i < a.na && j < a.nb) a.out[i * a.ldo + j] = acc[p][q][reg];
                 }
-        }
-        jt += gridDim.x;
-    } while (ROWSUM && jt < ntile);
-    if (ROWSUM) {
-        // the two waves that share a row quarter (wx = 0, 1) add their sums through LDS, in a fixed order
-        __syncthreads();
-        double* red = &lds[0][0][0][0];       // [2 (wy)][2 (wx)][64 rows]
-#pragma unroll
-        for (int p = 0; p < 4; p++)
-#pragma unroll
-            for (int reg = 0; reg < 4; reg++) {
-                double v = rs[p][reg];
-#pragma unroll
-                for (int off = 1; off < 16; off <<= 1) v += __shfl_xor(v, off, 64);
-                if (col == 0) red[(wy * 2 + wx) * 64 + 16 * p + kg + 4 * reg] = v;
-            }
-        __syncthreads();
-        if (tid < CB_T) {
-            const int64_t i = i0 + tid;
-            const int y = tid >> 6, r = tid & 63;
-            if (i < a.na) a.out[(int64_t)blockIdx.x * a.ldo + i] = red[(y * 2 + 0) * 64 + r] + red[(y * 2 + 1) * 64 + r];
         }
     }
 }
@@ -551,7 +521,7 @@ extern "C" int ital_cov_block(const double* Xa, const double* an, int64_t na, co
         const int64_t lx = (nb + CB_T - 1) / CB_T, ly = (na + CB_T - 1) / CB_T;
         if (ly > 65535) return ital_fail(-22, "ital_cov_block: too many rows per call");
         // (a grid dealt to the XCDs in 8 x 8-tile patches for L2 reuse was measured: 2-9 % slower than this plain sweep)
-        hipLaunchKernelGGL(cov_block_lds_kernel<false>, dim3((unsigned)lx, (unsigned)ly), dim3(256), 0, stream, a);
+        hipLaunchKernelGGL(cov_block_lds_kernel, dim3((unsigned)lx, (unsigned)ly), dim3(256), 0, stream, a);
         return ital_check_launch("ital_cov_block(lds)");
     }
     hipLaunchKernelGGL(cov_block_kernel<false>, dim3((unsigned)gx, (unsigned)gy), dim3(256), 0, stream, a);
@@ -571,9 +541,7 @@ extern "C" int ital_cov_abs_rowsum(const double* Xa, const double* an, int64_t n
     if (ldx % 16 != 0) return ital_fail(-22, "ital_cov_abs_rowsum: ldx must be a multiple of 16");
     if (m < 0 || (m > 0 && (!Va || !Vb))) return ital_fail(-22, "ital_cov_abs_rowsum: whitened blocks missing");
     if (!work || work_len < na) return ital_fail(-22, "ital_cov_abs_rowsum: work area smaller than na doubles");
-    const bool staged = ITAL_COV_LDS && ((na + CB_T - 1) / CB_T) * ((nb + CB_T - 1) / CB_T) >= ITAL_COV_LDS_MIN_TILES;
-    const int64_t ntile = staged ? (nb + CB_T - 1) / CB_T : (nb + 16 * COV_MJ - 1) / (16 * COV_MJ);
-    const int64_t gy = staged ? (na + CB_T - 1) / CB_T : (na + 64 * COV_MI - 1) / (64 * COV_MI);
+    const int64_t ntile = (nb + 16 * COV_MJ - 1) / (16 * COV_MJ), gy = (na + 64 * COV_MI - 1) / (64 * COV_MI);
     if (gy > 65535) return ital_fail(-22, "ital_cov_abs_rowsum: too many rows per call");
     // column splits: enough workgroups to fill the 256 CUs several times over, as many as the work area holds
     int64_t nsplit = (4096 + gy - 1) / gy;
@@ -581,8 +549,9 @@ extern "C" int ital_cov_abs_rowsum(const double* Xa, const double* an, int64_t n
     if (nsplit > work_len / na) nsplit = work_len / na;
     if (nsplit > 65535) nsplit = 65535;
     CovArgs a = {Xa, an, na, Xb, bn, nb, ldx, Va, ldva, Vb, ldvb, m, var, -2.0 * length_scale * length_scale, work, na};
-    if (staged) hipLaunchKernelGGL(cov_block_lds_kernel<true>, dim3((unsigned)nsplit, (unsigned)gy), dim3(256), 0, stream, a);
-    else hipLaunchKernelGGL(cov_block_kernel<true>, dim3((unsigned)nsplit, (unsigned)gy), dim3(256), 0, stream, a);
+    // (the row sums stay on the register-tiled kernel: with the 16 running sums on top of its 64 accumulators the
+    // LDS-staged one spills at two workgroups per CU)
+    hipLaunchKernelGGL(cov_block_kernel<true>, dim3((unsigned)nsplit, (unsigned)gy), dim3(256), 0, stream, a);
     hipLaunchKernelGGL(rowsum_reduce_kernel, dim3((unsigned)((na + 255) / 256)), dim3(256), 0, stream, work, na, (int)nsplit, na,
                        accumulate, out);
     return ital_check_launch("ital_cov_abs_rowsum");

@@ -26,8 +26,9 @@ def _load(name):
 @pytest.mark.parametrize("na,nb,d,m", [(1, 1, 3, 0), (70, 130, 21, 9), (257, 1000, 16, 5), (129, 63, 40, 17),
                                        (4200, 4100, 24, 6), (4097, 4225, 40, 0)])
 def test_cov_abs_rowsum_vs_cov_block(dev, na, nb, d, m):
-    """The fused row sums equal the sums over the materialised block (same tiles), with and without accumulation.  The two
-    large cases (more than 1024 tiles of 128 x 128) take the LDS-staged kernel, the others the register-tiled one."""
+    """The fused row sums equal the sums over the materialised block, with and without accumulation.  In the two large
+    cases (more than 1024 tiles of 128 x 128) the block comes from the LDS-staged kernel, the sums from the register-tiled
+    one: same accumulation order over the features, so the comparison is as tight as for the small ones."""
     from ital_amd import _lib
     from ital_amd.gp import _pad16, _ptr, _stream
     lib = _lib.lib()
