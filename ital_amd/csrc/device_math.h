@@ -403,7 +403,10 @@ __device__ __forceinline__ double mod_exact(double p, double m, double inv_m) {
     return r;
 }
 
-__device__ __forceinline__ double mrg_next_f(MrgStateF& s) {
+// MVNUNI's integer z in [1, 2^31 - 1] (as a double); the uniform is z * MRG_INVMP1 -- a prepared call may store the 32-bit
+// integer and the consumer form the identical double.
+constexpr double MRG_INVMP1 = 4.656612873077392578125e-10;
+__device__ __forceinline__ double mrg_next_z(MrgStateF& s) {
     const double M1 = 2147483647.0, M2 = 2145483479.0;
     const double p1 = mod_exact(fma(63308.0, s.x11, -183326.0 * s.x10), M1, 1.0 / 2147483647.0);
     const double p2 = mod_exact(fma(86098.0, s.x22, -539608.0 * s.x20), M2, 1.0 / 2145483479.0);
@@ -411,8 +414,9 @@ __device__ __forceinline__ double mrg_next_f(MrgStateF& s) {
     s.x20 = s.x21; s.x21 = s.x22; s.x22 = p2;
     double z = p1 - p2;
     z = z <= 0 ? z + M1 : z;
-    return z * 4.656612873077392578125e-10;
+    return z;
 }
+__device__ __forceinline__ double mrg_next_f(MrgStateF& s) { return mrg_next_z(s) * MRG_INVMP1; }
 
 // state <- J * state, J = two 3x3 matrices (row-major, entries already reduced): jump-ahead by a fixed count.
 __device__ __forceinline__ void mrg_apply(MrgState& s, const long long* __restrict__ J) {

@@ -160,7 +160,7 @@ __global__ __launch_bounds__(256) void score_t2_kernel(ScoreArgs a) {
 //                                                   COVSRT, saturation verdicts, the call's 8 shifted lattices -> one record
 //   qmc_main_kernel<T> wave per (candidate, r)      the lattice sum of the prior call (the FP64-VALU bound part), MI term of r
 //   qmc_combine_kernel thread per candidate         terms of the 2^T patterns in itertools.product order -> mi
-// The records travel through a workspace in HBM (472 B per call at T = 4); the candidates are processed in slabs that fit it.
+// The records travel through a workspace in HBM (208 B per call at T = 4); the candidates are processed in slabs that fit it.
 template <int T>
 struct Qmc {
     static constexpr int NDIM = T - 1;
@@ -170,9 +170,12 @@ struct Qmc {
     static constexpr int NCOR = T * (T - 1) / 2;
     static constexpr int NPAT = 1 << T;                       // sign patterns = prior calls per candidate
     static constexpr int NCALLS = 2 << T;                     // calls the reference makes per candidate (prior + updated)
-    static constexpr int LAT = 8 * NDIM * 2;                  // per call: permuted generators + shifts, 8 shifts
+    static constexpr int LAT = 8 * NDIM * 2;                  // per call: permuted generators + shifts, 8 shifts (in LDS)
+    // in the record the 8 NDIM shifts travel as MVNUNI's 32-bit integers and the 8 NDIM generators as byte indices into
+    // the generator vector (the lattice-sum kernel forms the identical doubles): 5 NDIM doubles instead of 16 NDIM
+    static constexpr int LATP = 5 * NDIM;
     static constexpr int R_LIM = NCOR, R_META = NCOR + T, R_LAT = NCOR + T + 1;
-    static constexpr int REC = R_LAT + LAT;                   // doubles per prepared call
+    static constexpr int REC = R_LAT + LATP;                  // doubles per prepared call
     static constexpr int SLAB_RAW = NCOV + 2 * T + NDIM;      // prep scratch per thread: packed factor, limits, expected values, generators
     static constexpr int SLAB = SLAB_RAW | 1;                 // odd stride: conflict-free per-thread slabs
     static constexpr int PREP_THREADS = T <= 6 ? 256 : 128;
@@ -421,8 +424,9 @@ __global__ __launch_bounds__(Qmc<T>::PREP_THREADS) void qmc_prep_kernel(ScoreArg
         MrgState sti = {sp[0], sp[1], sp[2], sp[3], sp[4], sp[5]};
         mrg_apply(sti, a.jumppat + (int64_t)r * 18);   // row r: 2r calls
         MrgStateF st = mrg_to_f(sti);
-        for (int j = 0; j < Q::NDIM; j++) gen[j] = a.vk[j];
-        double* L = rec + Q::R_LAT;
+        for (int j = 0; j < Q::NDIM; j++) gen[j] = (double)j;                  // positions in the generator vector a.vk
+        unsigned int* shifts = reinterpret_cast<unsigned int*>(rec + Q::R_LAT);
+        unsigned char* perm = reinterpret_cast<unsigned char*>(rec + Q::R_LAT + 4 * Q::NDIM);
         for (int sft = 0; sft < 8; sft++) {
             for (int j = 1; j <= Q::NDIM - 1; j++) {
                 const double u = mrg_next_f(st);
@@ -431,8 +435,8 @@ __global__ __launch_bounds__(Qmc<T>::PREP_THREADS) void qmc_prep_kernel(ScoreArg
                 gen[j - 1] = gen[jp - 1];
                 gen[jp - 1] = xt;
             }
-            for (int j = 0; j < Q::NDIM; j++) L[sft * Q::NDIM + j] = gen[j];
-            for (int j = 0; j < Q::NDIM; j++) L[8 * Q::NDIM + sft * Q::NDIM + j] = mrg_next_f(st);
+            for (int j = 0; j < Q::NDIM; j++) perm[sft * Q::NDIM + j] = (unsigned char)gen[j];
+            for (int j = 0; j < Q::NDIM; j++) shifts[sft * Q::NDIM + j] = (unsigned int)mrg_next_z(st);
         }
     }
     rec[Q::R_META] = __longlong_as_double(meta);
@@ -440,8 +444,8 @@ __global__ __launch_bounds__(Qmc<T>::PREP_THREADS) void qmc_prep_kernel(ScoreArg
 
 template <int T>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(ITAL_QMC_WAVES(T), ITAL_QMC_WAVES(T)))) void qmc_main_kernel(
-    const uint8_t* __restrict__ alive, int64_t slab_lo, int64_t slab_n, const double* __restrict__ recs, double eps,
-    int label_mode, double* __restrict__ terms) {
+    const uint8_t* __restrict__ alive, int64_t slab_lo, int64_t slab_n, const double* __restrict__ recs,
+    const double* __restrict__ vk, double eps, int label_mode, double* __restrict__ terms) {
     using Q = Qmc<T>;
     extern __shared__ double lds_all[];
     const int lane = threadIdx.x & 63;
@@ -456,7 +460,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(ITAL_QMC_WA
     if (meta & META_EVAL) {
         double* lat = lds_all + (size_t)wid * Q::WAVE_DOUBLES;
         double* tailq = lat + Q::LAT;
-        for (int q = lane; q < Q::LAT; q += 64) lat[q] = rec[Q::R_LAT + q];
+        {   // unpack the lattices: generator = vk[index], shift = integer * 1/(m1 + 1) exactly as MVNUNI forms it
+            const unsigned int* shifts = reinterpret_cast<const unsigned int*>(rec + Q::R_LAT);
+            const unsigned char* perm = reinterpret_cast<const unsigned char*>(rec + Q::R_LAT + 4 * Q::NDIM);
+            for (int q = lane; q < 8 * Q::NDIM; q += 64) {
+                lat[q] = vk[perm[q]];
+                lat[8 * Q::NDIM + q] = (double)shifts[q] * MRG_INVMP1;
+            }
+        }
         double cf[Q::NCOR > 0 ? Q::NCOR : 1], lm[T];
 #pragma unroll
         for (int q = 0; q < Q::NCOR; q++) cf[q] = uniform_f64(rec[q]);
@@ -522,7 +533,7 @@ static int launch_qmc(const ScoreArgs& a, double* work, int64_t work_doubles, hi
                            dim3(Q::PREP_THREADS), lds_prep, stream, a, lo, n, seeds, recs);
         if (ev0) (void)hipEventRecord(ev0, stream);
         hipLaunchKernelGGL(qmc_main_kernel<T>, dim3((unsigned)((n * Q::NPAT + 3) / 4)), dim3(256), lds_main, stream, a.alive, lo,
-                           n, recs, a.eps, a.label_mode, terms);
+                           n, recs, a.vk, a.eps, a.label_mode, terms);
         if (ev1) (void)hipEventRecord(ev1, stream);
         hipLaunchKernelGGL(qmc_combine_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, terms, a.alive, lo, n,
                            Q::NPAT, a.label_mode, a.mi);

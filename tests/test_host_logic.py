@@ -181,7 +181,7 @@ def test_score_workspace_size():
     """ital_score_workspace (host-only entry point): records of 2^t patterns, their terms and the generator state."""
     from ital_amd import _lib
     lib = _lib.load()
-    for t, lat in ((3, 32), (4, 48), (8, 112)):
+    for t, lat in ((3, 10), (4, 15), (8, 35)):      # lattices packed: 5 (t - 1) doubles per call
         ncor = t * (t - 1) // 2
         per_cand = (1 << t) * (ncor + t + 1 + lat + 1) + 3
         assert lib.ital_score_workspace(t, 1) == per_cand
