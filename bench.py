@@ -190,7 +190,7 @@ def other_workloads(X, rel, device):
     mvn_stream.GLOBAL.reset()
     L = ITAL(X, length_scale=LENGTH_SCALE, label_prob=0.5, mistake_prob=0.25, device=device)
     L.pair_counter = torch.zeros(1, dtype=torch.int64, device=device)
-    res, prof = timed(L, 3, BATCH, warm=1)
+    res, prof = timed(L, 6, BATCH, warm=2)
     top = prof.get(("score_generic", BATCH), [])
     roof = None
     if top:
