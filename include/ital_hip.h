@@ -97,6 +97,45 @@ int ital_topk(const double* v, int64_t n, int64_t index_offset, int k, double* o
               hipStream_t stream);
 int64_t ital_topk_workspace(void);
 
+/* ---- host-side bookkeeping of the reference's random streams (HOST pointers, no device work, usable without a GPU) ---
+ *
+ * SciPy's mvndst (reference ital/ital.py:380, :405, :425) draws its lattice shifts from MVNUNI, a generator whose state is
+ * process-global and cannot be seeded.  The scorers replay that stream in the reference's serial evaluation order; the
+ * host tells them where the stream stands.  A host that drives ital_score_step / ital_score_generic itself keeps one
+ * state per process:
+ *     int state[6]; ital_mvn_seed(state);                    once (the generator's DATA seed)
+ *     ... desc.seed = state; ital_score_step(&desc, s); ...   per greedy step t
+ *     ital_mvn_advance(state, n_alive * (2 << t) * ital_mvn_draws_per_call(t));   perfect user: 2 calls per sign pattern
+ * (n_alive = live candidates of the whole list, all ranks; ital_score_generic: the draws_out / draws_in it was given).
+ */
+int ital_mvn_seed(int state[6]);
+/* Uniforms one mvndst call with n finite-limit variables consumes: 8 (2 (n - 1) - 1), 0 for the closed forms n <= 2. */
+int ital_mvn_draws_per_call(int n);
+/* state <- state after n_draws more uniforms (3 x 3 matrix powers mod m1 / m2: O(log n_draws)). */
+int ital_mvn_advance(int state[6], int64_t n_draws);
+/* Tables of ital_score_desc for batch dimension t (3 .. ITAL_MAX_T), to be copied to device memory by the caller; any of
+ * the three may be NULL.  jump: [ITAL_JUMP_BITS][18], jumppat: [2^t][18], vk: [t - 1]. */
+int ital_mvn_tables(int t, long long* jump, long long* jumppat, double* vk);
+/* Tables of ital_gscore_desc: jump1 [ITAL_JUMP_BITS][18] (2^b uniforms), vk_all [nmax + 1][nmax] (row n: generators of
+ * dimension n), nmax <= ITAL_GENERIC_MAX_DIM; either may be NULL. */
+int ital_mvn_generic_tables(int nmax, long long* jump1, double* vk_all);
+
+/* numpy's legacy global generator (MT19937 + polar method), the stream the reference's Monte-Carlo pattern sampler draws
+ * its standard normals from: scipy.stats.multivariate_normal.rvs at reference ital/ital.py:297, one (t mc) x t block per
+ * live candidate in list order.  The generator cannot jump (data-dependent rejections), but a rank that scores only its
+ * own candidates need not COMPUTE the other ranks' normals: this advances the state past n_skip standard normals (raw
+ * draws and accept tests only, ~4 ns each against ~40 ns), then writes the next n_out to out[] -- bit-identical to
+ * np.random.standard_normal.  threads > 1: the values of a large request are produced by that many host threads (one more
+ * skipping pass finds the generator state at the start of every thread's share).  State as
+ * np.random.get_state(legacy=True) returns it / np.random.set_state takes it. */
+typedef struct ital_np_legacy_state {
+    uint32_t key[624];
+    int32_t pos;         /* 0 .. 624 */
+    int32_t has_gauss;
+    double gauss;        /* cached second value of the last pair when has_gauss */
+} ital_np_legacy_state;
+int ital_np_legacy_normals(ital_np_legacy_state* st, int64_t n_skip, double* out, int64_t n_out, int threads);
+
 /* ---- greedy batch construction ------------------------------------------------------------------------
  * Batch state, replicated on every rank, updated only by ital_select_resolve (device side, no host sync). */
 typedef struct ital_batch {

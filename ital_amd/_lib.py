@@ -57,8 +57,18 @@ class ItalMcmiDesc(ctypes.Structure):
                 ("ldc", c_int64), ("batch", ItalBatch), ("noise", c_double), ("eps", c_double), ("ce", c_void_p)]
 
 
+class ItalNpLegacyState(ctypes.Structure):
+    _fields_ = [("key", ctypes.c_uint32 * 624), ("pos", ctypes.c_int32), ("has_gauss", ctypes.c_int32), ("gauss", c_double)]
+
+
 SIGNATURES = {
     "ital_version": (ctypes.c_char_p, []),
+    "ital_mvn_seed": (c_int, [ctypes.POINTER(c_int)]),
+    "ital_mvn_draws_per_call": (c_int, [c_int]),
+    "ital_mvn_advance": (c_int, [ctypes.POINTER(c_int), c_int64]),
+    "ital_mvn_tables": (c_int, [c_int, c_void_p, c_void_p, c_void_p]),
+    "ital_mvn_generic_tables": (c_int, [c_int, c_void_p, c_void_p]),
+    "ital_np_legacy_normals": (c_int, [ctypes.POINTER(ItalNpLegacyState), c_int64, c_void_p, c_int64, c_int]),
     "ital_last_error": (ctypes.c_char_p, []),
     "ital_row_norms": (c_int, [c_void_p, c_int64, c_int, c_void_p, c_void_p]),
     "ital_rbf_cols": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_void_p, c_void_p, c_int, c_double, c_double,
@@ -126,3 +136,26 @@ def lib():
 def check(rc):
     if rc != 0:
         raise ItalHipError(f"libital_hip: error {rc}: {lib().ital_last_error().decode()}")
+
+
+def legacy_normals(n_skip, n_out, threads=1):
+    """Advances numpy's global legacy generator past `n_skip` standard normals without computing them, then draws the next
+    `n_out` (float64 array) -- the same values, and the same generator state afterwards, as
+    `np.random.standard_normal(n_skip); np.random.standard_normal(n_out)` (ital_np_legacy_normals; `threads` host threads
+    produce the values of a large request)."""
+    import numpy as np
+    n_skip, n_out = int(n_skip), int(n_out)
+    state = np.random.get_state(legacy=True)
+    if state[0] != "MT19937":                 # somebody replaced the global bit generator: numpy walks its own stream
+        if n_skip:
+            np.random.standard_normal(n_skip)
+        return np.random.standard_normal(n_out)
+    st = ItalNpLegacyState()
+    key = np.ascontiguousarray(state[1], dtype=np.uint32)
+    ctypes.memmove(st.key, key.ctypes.data, 624 * 4)
+    st.pos, st.has_gauss, st.gauss = int(state[2]), int(state[3]), float(state[4])
+    out = np.empty(n_out, dtype=np.float64)
+    check(lib().ital_np_legacy_normals(ctypes.byref(st), n_skip, out.ctypes.data, n_out, int(threads)))
+    np.random.set_state(("MT19937", np.frombuffer(st.key, dtype=np.uint32).copy(), int(st.pos), int(st.has_gauss),
+                         float(st.gauss)))
+    return out

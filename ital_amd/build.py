@@ -8,12 +8,15 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 INCLUDE = os.path.join(os.path.dirname(HERE), "include")
 LIB = os.path.join(HERE, "libital_hip.so")
-SOURCES = ["api.hip", "rbf.hip", "chol.hip", "score.hip", "select.hip", "mcmi.hip", "score_generic.hip", "topk.hip", "exchange.hip"]
+SOURCES = ["api.hip", "rbf.hip", "chol.hip", "score.hip", "select.hip", "mcmi.hip", "score_generic.hip", "topk.hip", "exchange.hip",
+           "mvn_stream.cpp", "np_legacy.cpp"]    # .cpp: host-only translation units (no HIP), also built by tools/asan_host.sh
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 EXTRA = os.environ.get("ITAL_HIPCC_EXTRA", "").split()
 LIB = os.environ.get("ITAL_HIP_LIB_OUT", LIB)
-FLAGS = EXTRA + ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fgpu-rdc" if False else "-fno-gpu-rdc",
+FLAGS = EXTRA + ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-gpu-rdc",
          "-I", INCLUDE, "-I", CSRC, "-Wall", "-Wno-unused-function"]
+# host-only units: no fused multiply-adds (np_legacy.cpp reproduces numpy's doubles bit for bit)
+HOST_FLAGS = ["-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-I", INCLUDE, "-I", CSRC, "-Wall"]
 
 
 def _newer(target, deps):
@@ -32,10 +35,10 @@ def build(force=False, verbose=False):
     objs = []
     for src in SOURCES:
         s = os.path.join(CSRC, src)
-        o = os.path.join(objdir, src.replace(".hip", ".o"))
+        o = os.path.join(objdir, os.path.splitext(src)[0] + ".o")
         objs.append(o)
         if force or _newer(o, [s] + headers):
-            jobs.append([HIPCC] + FLAGS + ["-c", s, "-o", o])
+            jobs.append([HIPCC] + (FLAGS if src.endswith(".hip") else HOST_FLAGS) + ["-c", s, "-o", o])
 
     def run(cmd):
         if verbose:
@@ -46,7 +49,7 @@ def build(force=False, verbose=False):
         with ThreadPoolExecutor(max_workers=4) as ex:
             list(ex.map(run, jobs))
     if jobs or force or _newer(LIB, objs):
-        run([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs + ["-ldl"])
+        run([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs + ["-ldl", "-lpthread"])
     return LIB
 
 

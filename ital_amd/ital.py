@@ -248,7 +248,8 @@ class ITAL(ActiveRetrievalBase):
     def _select(self, k, candidates):
         """Greedy construction of a batch of k out of `candidates` (k <= len(candidates))."""
         gp = self.gp
-        if self._needs_generic():
+        self._last_batch = None        # published only after the round's final successful download (update() pairs its
+        if self._needs_generic():      # sample ids with rows of the batch buffers)
             return self._fetch_generic(k, candidates)
         lib = _lib.lib()
         dev = gp.device
@@ -331,7 +332,6 @@ class ITAL(ActiveRetrievalBase):
                 n_alive -= 1
             host = b["ret"].cpu().tolist()     # the only synchronisation of the round: the picks and the status word
             ret, status = host[:k], host[b["kmax"]]   # status: OR over the greedy steps and over all ranks (same everywhere)
-            self._last_batch = (b, list(ret))
             if status & 6:
                 # linearly dependent variables inside a batch (duplicate samples), or a simulated update that does not pin the
                 # labels (large noise): the fast scorer carries neither MVNDFN's limit-intersection logic nor the updated
@@ -341,6 +341,7 @@ class ITAL(ActiveRetrievalBase):
                 return self._fetch_generic(k, candidates)
         if status:
             gp.check_status(status)
+        self._last_batch = (b, list(ret))
         return [int(i) for i in ret]
 
     # ------------------------------------------------------------------ general scorer (noisy users, estimation subset)
@@ -356,6 +357,7 @@ class ITAL(ActiveRetrievalBase):
         lib = _lib.lib()
         gp = self.gp
         dev = gp.device
+        self._last_batch = None
         subset_mode = self._ce_subset is not None
         fb_mode = self._fb_mode()
         E = list(self._ce_subset) if subset_mode else []
@@ -368,6 +370,9 @@ class ITAL(ActiveRetrievalBase):
             b = self._buffers(max(kmax_e, 4))
             kmax = b["kmax"]
             cand, n_loc, pos_offset, cand_d, gpos_d, alive = self._shard(candidates)
+            # every rank's candidates one contiguous run of the list (the ascending get_unseen() order; not after the
+            # argpartition order of top_candidates on several ranks)?  Decided from the list alone: the same on every rank
+            runs = sharding.contiguous_runs(cand, gp.n_total, gp.world)
             pos_of = {int(c): i for i, c in enumerate(cand.tolist())}
             mi = torch.zeros(max(n_loc, 1), dtype=torch.float64, device=dev)
             if "jump1" not in b:
@@ -400,6 +405,7 @@ class ITAL(ActiveRetrievalBase):
                 e_sig[: len(E), : len(E)] = gp.gather_columns(C[: len(E)], E).cpu().numpy()
                 e_mu[: len(E)] = self.rel_mean[np.asarray(E)]
             picks, pick_pos = [], []
+            self._mc_cache = {}           # host copies of this rank's variances / covariance columns (pattern sampling)
             self.last_scores = []
             self.last_patterns = []       # keep_scores: the sampled sign patterns of every Monte-Carlo step (diagnostics/tests)
             n_alive = len(candidates)
@@ -409,7 +415,6 @@ class ITAL(ActiveRetrievalBase):
                 nr = t
                 rel_mc, npat, fb_mc, nfb = self._mc_plan(nr, fb_mode)
                 clip_count = self._clip_active() and nE + 1 > 5
-                host_step = subset_mode or rel_mc or fb_mc or clip_count   # the host needs this step's winner before the next
                 dpc = mvn_stream.draws_per_call
                 if subset_mode:
                     draws_out = npat * (dpc(nr) + (1 + nfb) * dpc(nE + 1))
@@ -429,7 +434,7 @@ class ITAL(ActiveRetrievalBase):
                         e_sig[: t - 1, : t - 1] = b["sig"].view(kmax, kmax)[: t - 1, : t - 1].cpu().numpy()
                     mc = self._mc_samples(nr, npat, rel_mc, fb_mc, nfb, fb_mode, cand, picks, pos_of,
                                           E if subset_mode else picks, pick_pos, e_mu, e_sig, C, subset_mode, z_next,
-                                          (pos_offset, pos_offset + n_loc) if gpos_d is None else None)
+                                          (pos_offset, pos_offset + n_loc) if runs else None)
                 z_next = None
                 desc = ItalGscoreDesc()
                 desc.n_cand = n_loc
@@ -536,10 +541,15 @@ class ITAL(ActiveRetrievalBase):
                 n_alive -= 1
                 if t < k:
                     # the standard normals of the next step's pattern sampling depend on nothing but their count: drawn
-                    # now, while the scorer runs, they are off the critical path (same order on numpy's global generator)
+                    # now, while the scorer runs, they are off the critical path (same order on numpy's global generator).
+                    # Only this rank's candidates' normals are computed; the generator is walked past the others'
+                    # (ital_np_legacy_normals).  The next step's live ranks of the local positions [lo, hi) depend on the
+                    # pick this step is about to make: lo - t <= first, last <= hi covers every outcome
                     rel_nx, npat_nx, fb_nx, _ = self._mc_plan(nr + 1, fb_mode)
                     if rel_nx and not fb_nx:
-                        z_next = np.random.standard_normal((n_alive, npat_nx, nr + 1))
+                        g0, g1 = (0, n_alive) if not runs else \
+                            (max(pos_offset - t, 0), min(pos_offset + n_loc, n_alive))
+                        z_next = (g0, self._walk_normals(n_alive, g0, g1, npat_nx * (nr + 1)).reshape(-1, npat_nx, nr + 1))
                 if not subset_mode:
                     slot = t - 1
                     if not gp.collective and n_loc <= _FUSED_SELECT_MAX:
@@ -600,12 +610,23 @@ class ITAL(ActiveRetrievalBase):
             if not subset_mode:
                 host = b["ret"].cpu().tolist()        # picks and the status word (OR over steps and ranks)
                 picks, status = host[:k], host[kmax]
-                self._last_batch = (b, [int(i) for i in picks])
             else:
                 status = None                         # only the replicated Cholesky append reports here: same on all ranks
             keep.clear()
         gp.check_status(status)
+        if not subset_mode:
+            self._last_batch = (b, [int(i) for i in picks])
         return [int(i) for i in picks]
+
+    @staticmethod
+    def _walk_normals(n_live, j0, j1, per_cand):
+        """numpy's global generator walked over the `per_cand` standard normals of each of `n_live` candidates
+        (multivariate_normal.rvs per candidate, reference ital.py:297); returns those of candidates j0 .. j1-1 (flat)."""
+        j0, j1 = max(int(j0), 0), min(int(j1), int(n_live))
+        j1 = max(j1, j0)
+        z = _lib.legacy_normals(j0 * per_cand, (j1 - j0) * per_cand, _HOST_THREADS)
+        _lib.legacy_normals((n_live - j1) * per_cand, 0)
+        return z
 
     def _mc_samples(self, nr, npat, rel_mc, fb_mc, nfb, fb_mode, cand, picks, pos_of, E, pick_pos, e_mu, e_sig, C, subset_mode,
                     z_rel=None, local=None):
@@ -638,19 +659,32 @@ class ITAL(ActiveRetrievalBase):
             jl0, jl1 = int(np.searchsorted(live, local[0])), int(np.searchsorted(live, local[1]))
         if rel_mc:
             mu_all = np.asarray(self.rel_mean, dtype=np.float64)
-            s2_all = gp._full(gp.s2)
             pp = list(pick_pos)
-            cpick = np.stack([gp._full(C[b]) for b in pp]) if pp else np.zeros((0, gp.n_total))
             rows = cand[live[jl0:jl1]]
+            cache = self._mc_cache
+            if rel_mc and not fb_mc and local is not None:
+                # (the same decision on every rank: `local` is set for all of them or for none)
+                # every row read below is a row of this rank: variances and covariance columns come from the local shard
+                # (a column is downloaded once per fetch, when its member joins the batch) -- no collective, nothing N-sized
+                if "s2" not in cache:
+                    cache["s2"] = gp.s2[: gp.n].cpu().numpy()
+                for b in pp:
+                    if ("C", b) not in cache:
+                        cache[("C", b)] = C[b][: gp.n].cpu().numpy()
+                s2_all, rows_l = cache["s2"], rows - gp.row0
+                cpick = np.stack([cache[("C", b)] for b in pp]) if pp else np.zeros((0, gp.n))
+            else:
+                s2_all, rows_l = gp._full(gp.s2), rows
+                cpick = np.stack([gp._full(C[b]) for b in pp]) if pp else np.zeros((0, gp.n_total))
             mean = np.empty((len(rows), nr))
             cov = np.empty((len(rows), nr, nr))
             mean[:, : nr - 1] = e_mu[pp][None, :] if pp else 0
             cov[:, : nr - 1, : nr - 1] = e_sig[np.ix_(pp, pp)][None] if pp else 0
             mean[:, nr - 1] = mu_all[rows]
-            cov[:, nr - 1, nr - 1] = s2_all[rows]
+            cov[:, nr - 1, nr - 1] = s2_all[rows_l]
             if pp:
-                cov[:, : nr - 1, nr - 1] = cpick[:, rows].T
-                cov[:, nr - 1, : nr - 1] = cpick[:, rows].T
+                cov[:, : nr - 1, nr - 1] = cpick[:, rows_l].T
+                cov[:, nr - 1, : nr - 1] = cpick[:, rows_l].T
             if subset_mode:
                 for j in np.flatnonzero(in_e[live[jl0:jl1]] >= 0):  # members of the base set: covariances from E itself
                     idx = pp + [int(in_e[live[jl0 + j]])]
@@ -706,13 +740,17 @@ class ITAL(ActiveRetrievalBase):
         L = len(live)
         enum_pats = np.arange(npat, dtype=np.uint32)
         if rel_mc and not fb_mc:
-            # every rank walks the whole stream of normals (the legacy generator cannot jump), but only its own
-            # candidates' patterns are ever read: the decompositions are done for those alone
+            # the legacy generator cannot jump, so every rank walks the whole stream of normals -- but only its own
+            # candidates' are computed (the others are skipped: raw draws and accept tests, ital_np_legacy_normals), and
+            # the decompositions are done for those alone
             if z_rel is None:
-                z_rel = np.random.standard_normal((L, npat, nr))
+                z_loc = self._walk_normals(L, jl0, jl1, npat * nr).reshape(-1, npat, nr)
+            else:
+                g0, z = z_rel                                       # drawn ahead for live ranks g0 .. g0 + len(z) - 1
+                z_loc = z[jl0 - g0:jl1 - g0]
             rel_live = np.zeros((L, npat), dtype=np.uint32)
             if jl1 > jl0:
-                rel_live[jl0:jl1] = draw_rel(jl0, jl1, z_rel[jl0:jl1])
+                rel_live[jl0:jl1] = draw_rel(jl0, jl1, z_loc)
         elif fb_mc and not rel_mc:
             fb_live = draw_fb(np.broadcast_to(enum_pats, (L, npat)))
         else:

@@ -110,6 +110,7 @@ class MCMI_min(ActiveRetrievalBase):
             raise NotImplementedError("batches larger than %d are not enumerated on the device" % ITAL_MAX_T)
         lib = _lib.lib()
         dev = gp.device
+        self._last_batch = None      # published after the round's successful download only
         cand = np.asarray(cand, dtype=np.int64)
         nc = len(cand)
         with torch.cuda.device(dev):

@@ -3,41 +3,23 @@
 The reference draws its lattice shifts from a process-global, un-seedable generator inside
 scipy.stats.mvn.mvndst (reference ital/ital.py:380).  The device scorer replays that
 stream: this module knows where the stream stands (one global position per process, like the Fortran SAVE
-state), how many uniforms a call of dimension n consumes, and builds the jump-ahead matrices the kernel
+state), how many uniforms a call of dimension n consumes, and hands out the jump-ahead matrices the kernel
 applies to reach the offset of a given (candidate, pattern, call) in the reference's serial order.
-Pure integer arithmetic, no GPU needed.
+
+The arithmetic lives below the C ABI (csrc/mvn_stream.cpp: ital_mvn_seed / _advance / _tables / _generic_tables /
+_draws_per_call -- host code of libital_hip.so, no GPU needed), so that a host in any language can drive the
+scorers for t >= 3; this module is the ctypes wrapper plus the per-process position.
 """
+import ctypes
+
 import numpy as np
+
+from . import _lib
 
 M1, M2 = 2147483647, 2145483479
 SEED = (15485857, 17329489, 36312197, 55911127, 75906931, 96210113)
-# one step of each component as a matrix acting on (x_{n-3}, x_{n-2}, x_{n-1})^T
-A1 = ((0, 1, 0), (0, 0, 1), ((-183326) % M1, 63308, 0))
-A2 = ((0, 1, 0), (0, 0, 1), ((-539608) % M2, 0, 86098))
-
 PRIMES = (31, 47, 73, 113, 173, 263, 397, 593, 907, 1361)
-# Keast's optimal Korobov generators C(NP, NDIM-1), NP = min(NDIM, 10), for NDIM = 2..19 (Genz, MVNDST; pinned against
-# SciPy by tests/golden/mvndst_stream.npz and mvndst_stream_hi.npz through the oracle's restatement)
-KOROBOV_C = {2: 13, 3: 28, 4: 27, 5: 28, 6: 20, 7: 92, 8: 102, 9: 339, 10: 206, 11: 422, 12: 134, 13: 518, 14: 134,
-             15: 134, 16: 518, 17: 652, 18: 382, 19: 206}
-
-
-def _matmul(a, b, m):
-    return tuple(tuple(sum(a[i][k] * b[k][j] for k in range(3)) % m for j in range(3)) for i in range(3))
-
-
-def _matpow(a, e, m):
-    r = ((1, 0, 0), (0, 1, 0), (0, 0, 1))
-    while e:
-        if e & 1:
-            r = _matmul(a, r, m)
-        a = _matmul(a, a, m)
-        e >>= 1
-    return r
-
-
-def _apply(mat, vec, m):
-    return tuple(sum(mat[i][k] * vec[k] for k in range(3)) % m for i in range(3))
+_JUMP_BITS = _lib.ITAL_JUMP_BITS
 
 
 def draws_per_call(n):
@@ -46,35 +28,22 @@ def draws_per_call(n):
     return 0 if n <= 2 else 8 * (2 * (n - 1) - 1)
 
 
+def _state6(state):
+    return (ctypes.c_int * 6)(*[int(v) for v in state])
+
+
+def _advanced(state, n):
+    st = _state6(state)
+    _lib.check(_lib.lib().ital_mvn_advance(st, int(n)))
+    return tuple(int(v) for v in st)
+
+
 def korobov_vk(n):
     """Generator vector of the lattice rule used for n variables: VK(1) = 1/P, VK(i) = frac(C * VK(i-1)),
     evaluated in floating point exactly as SciPy's mvndst.f does."""
-    ndim = n - 1
-    p = PRIMES[min(ndim, 10) - 1]
-    vk = np.empty(ndim, dtype=np.float64)
-    vk[0] = 1.0 / p
-    c = float(KOROBOV_C[ndim]) if ndim >= 2 else 0.0
-    for i in range(1, ndim):
-        vk[i] = np.fmod(c * vk[i - 1], 1.0)
+    vk = np.empty(n - 1, dtype=np.float64)
+    _lib.check(_lib.lib().ital_mvn_tables(int(n), None, None, vk.ctypes.data))
     return vk
-
-
-_POW2 = {1: [A1], 2: [A2]}   # A^(2^b) of both components, extended on demand
-
-
-def _jump_state(vec, n, which, a, m):
-    """vec advanced by n steps of component `which`: one matrix-vector product per set bit of n (the squarings are
-    cached), instead of a fresh square-and-multiply of 3x3 matrices per call."""
-    pows = _POW2[which]
-    b = 0
-    while n:
-        if b >= len(pows):
-            pows.append(_matmul(pows[-1], pows[-1], m))
-        if n & 1:
-            vec = _apply(pows[b], vec, m)
-        n >>= 1
-        b += 1
-    return vec
 
 
 class MvnStream:
@@ -84,38 +53,34 @@ class MvnStream:
         self.reset()
 
     def reset(self):
-        self.state = SEED
+        st = (ctypes.c_int * 6)()
+        _lib.check(_lib.lib().ital_mvn_seed(st))
+        self.state = tuple(int(v) for v in st)
         self.draws = 0
 
     def advance(self, n):
         n = int(n)
         if n <= 0:
             return
-        self.state = _jump_state(self.state[:3], n, 1, A1, M1) + _jump_state(self.state[3:], n, 2, A2, M2)
+        self.state = _advanced(self.state, n)
         self.draws += n
 
     def peek(self, n):
         """State after n more draws, without moving."""
-        n = int(n)
-        return _jump_state(self.state[:3], n, 1, A1, M1) + _jump_state(self.state[3:], n, 2, A2, M2)
+        return _advanced(self.state, max(int(n), 0))
 
 
-_jump_cache = {}
+_cache = {}
 
 
-def jump_table(n, bits=48):
+def jump_table(n, bits=_JUMP_BITS):
     """int64 [bits][18]: transition matrices of both components for 2^b calls of dimension n."""
-    key = (n, bits)
-    if key not in _jump_cache:
-        d = draws_per_call(n)
-        j1, j2 = _matpow(A1, d, M1), _matpow(A2, d, M2)
-        out = np.empty((bits, 18), dtype=np.int64)
-        for b in range(bits):
-            out[b, :9] = np.array(j1, dtype=np.int64).ravel()
-            out[b, 9:] = np.array(j2, dtype=np.int64).ravel()
-            j1, j2 = _matmul(j1, j1, M1), _matmul(j2, j2, M2)
-        _jump_cache[key] = out
-    return _jump_cache[key]
+    key = ("calls", n)
+    if key not in _cache:
+        out = np.empty((_JUMP_BITS, 18), dtype=np.int64)
+        _lib.check(_lib.lib().ital_mvn_tables(int(n), out.ctypes.data, None, None))
+        _cache[key] = out
+    return _cache[key][:bits]
 
 
 def jump_pattern_table(n):
@@ -123,38 +88,27 @@ def jump_pattern_table(n):
     evaluates, per sign pattern r, the prior probability -- call 2r of the candidate -- and the probability after the
     simulated update, ital.py:191-206)."""
     key = ("pattern", n)
-    if key not in _jump_cache:
-        d = 2 * draws_per_call(n)
-        j1, j2 = _matpow(A1, d, M1), _matpow(A2, d, M2)
-        c1 = c2 = ((1, 0, 0), (0, 1, 0), (0, 0, 1))
+    if key not in _cache:
         out = np.empty((1 << n, 18), dtype=np.int64)
-        for r in range(1 << n):
-            out[r, :9] = np.array(c1, dtype=np.int64).ravel()
-            out[r, 9:] = np.array(c2, dtype=np.int64).ravel()
-            c1, c2 = _matmul(j1, c1, M1), _matmul(j2, c2, M2)
-        _jump_cache[key] = out
-    return _jump_cache[key]
+        _lib.check(_lib.lib().ital_mvn_tables(int(n), None, out.ctypes.data, None))
+        _cache[key] = out
+    return _cache[key]
 
 
-def jump1_table(bits=48):
+def jump1_table(bits=_JUMP_BITS):
     """int64 [bits][18]: transition matrices of both components for 2^b uniforms."""
-    key = ("single", bits)
-    if key not in _jump_cache:
-        j1, j2 = A1, A2
-        out = np.empty((bits, 18), dtype=np.int64)
-        for b in range(bits):
-            out[b, :9] = np.array(j1, dtype=np.int64).ravel()
-            out[b, 9:] = np.array(j2, dtype=np.int64).ravel()
-            j1, j2 = _matmul(j1, j1, M1), _matmul(j2, j2, M2)
-        _jump_cache[key] = out
-    return _jump_cache[key]
+    key = "single"
+    if key not in _cache:
+        out = np.empty((_JUMP_BITS, 18), dtype=np.int64)
+        _lib.check(_lib.lib().ital_mvn_generic_tables(0, out.ctypes.data, None))
+        _cache[key] = out
+    return _cache[key][:bits]
 
 
 def vk_table(nmax):
     """float64 [nmax + 1][nmax]: Korobov generator vector of every dimension 3..nmax (row n, first n - 1 entries)."""
     out = np.zeros((nmax + 1, nmax), dtype=np.float64)
-    for n in range(3, nmax + 1):
-        out[n, : n - 1] = korobov_vk(n)
+    _lib.check(_lib.lib().ital_mvn_generic_tables(int(nmax), None, out.ctypes.data))
     return out
 
 

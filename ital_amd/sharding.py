@@ -42,6 +42,17 @@ def shard_candidates(candidates, row0, row1):
     return cand[mine], first, None
 
 
+def contiguous_runs(candidates, n_total, world):
+    """True when the list positions of EVERY rank's candidates form one contiguous run of the list (then
+    `shard_candidates` returns no explicit positions on any rank).  A function of the list alone: all ranks agree."""
+    if world == 1:
+        return True
+    cand = np.asarray(candidates, dtype=np.int64)
+    bounds = np.array([row_range(n_total, world, r)[1] for r in range(world)], dtype=np.int64)
+    owner = np.searchsorted(bounds, cand, side="right")
+    return bool(np.all(np.diff(owner) >= 0))
+
+
 def _host_staged(t, group):
     """gloo moves host memory only: device tensors are staged through the host for it (CPU tests, and the
     two-ranks-on-one-GPU parity test); RCCL ("nccl") takes device pointers directly."""

@@ -53,13 +53,83 @@ def test_draws_per_call_matches_oracle():
         assert mvn.rng_draws() - before == ms.draws_per_call(n)
 
 
+# Keast's Korobov generators C(NP, NDIM-1) of Genz's MVNDST for NDIM = 2..19 (the tests' own copy: the library's table is
+# checked against it, and against SciPy through the oracle's restatement in test_oracle_mvndst.py)
+KOROBOV_C = {2: 13, 3: 28, 4: 27, 5: 28, 6: 20, 7: 92, 8: 102, 9: 339, 10: 206, 11: 422, 12: 134, 13: 518, 14: 134,
+             15: 134, 16: 518, 17: 652, 18: 382, 19: 206}
+
+
 def test_korobov_generators():
-    # first two components for every dimension used on the device
-    for n in range(3, 10):
+    for n in range(3, 21):
         vk = ms.korobov_vk(n)
         p = ms.PRIMES[min(n - 1, 10) - 1]
-        assert vk[0] == 1.0 / p
-        assert abs(vk[1] - (ms.KOROBOV_C[n - 1] % p) / p) < 1e-15
+        want = np.empty(n - 1)
+        want[0] = 1.0 / p
+        for i in range(1, n - 1):
+            want[i] = np.fmod(float(KOROBOV_C[n - 1]) * want[i - 1], 1.0)
+        assert np.array_equal(vk, want)
+        assert abs(vk[1] - (KOROBOV_C[n - 1] % p) / p) < 1e-15
+
+
+def test_stream_entry_points_of_the_c_abi():
+    """ital_mvn_seed / _advance / _draws_per_call / _tables / _generic_tables driven through ctypes alone (what a host that
+    is not Python binds, include/ital_hip.h) against the oracle's generator."""
+    from ital_amd import _lib
+    lib = _lib.load()
+    st = (ctypes.c_int * 6)()
+    assert lib.ital_mvn_seed(st) == 0 and tuple(st) == ms.SEED
+    mvn.rng_reset()
+    total = 0
+    for n in (1, 7, 40, 123456789, 3):
+        mvn.rng_skip(n)
+        assert lib.ital_mvn_advance(st, n) == 0
+        total += n
+        assert list(st) == mvn.rng_state()
+    assert lib.ital_mvn_advance(st, 0) == 0 and list(st) == mvn.rng_state()
+    assert lib.ital_mvn_advance(st, -1) != 0 and b"ital_mvn_advance" in lib.ital_last_error()
+    assert [lib.ital_mvn_draws_per_call(n) for n in (1, 2, 3, 4, 9)] == [0, 0, 24, 40, 120]
+    jump = np.zeros((48, 18), dtype=np.int64)
+    pat = np.zeros((16, 18), dtype=np.int64)
+    vk = np.zeros(3)
+    assert lib.ital_mvn_tables(4, jump.ctypes.data, pat.ctypes.data, vk.ctypes.data) == 0
+    calls = 0b110101
+    cur = list(ms.SEED)
+    for b in range(6):
+        if (calls >> b) & 1:
+            cur = _apply(jump[b], cur)
+    mvn.rng_reset()
+    mvn.rng_skip(calls * 40)
+    assert cur == mvn.rng_state()
+    mvn.rng_reset()
+    mvn.rng_skip(2 * 11 * 40)
+    assert _apply(pat[11], list(ms.SEED)) == mvn.rng_state() and _apply(pat[0], list(ms.SEED)) == list(ms.SEED)
+    assert np.array_equal(vk, ms.korobov_vk(4))
+    assert lib.ital_mvn_tables(2, None, None, None) != 0 and lib.ital_mvn_tables(9, None, pat.ctypes.data, None) != 0
+    assert lib.ital_mvn_generic_tables(21, None, None) != 0
+
+
+def test_legacy_normals_skip_and_fill_are_numpy_bit_for_bit():
+    """ital_np_legacy_normals against np.random.standard_normal: values and generator state, for every parity of
+    (cached value, skip count, fill count), across MT19937 block boundaries, single- and multi-threaded."""
+    from ital_amd import _lib
+    for seed, pre in ((0, 0), (1, 3), (2, 624 * 2 + 1)):
+        for skip, fill, th in ((0, 7, 1), (1, 10, 1), (2, 1001, 1), (5, 0, 1), (12345, 54321, 1), (1872, 5, 1),
+                               (77, 200001, 4), (1000000, 3, 1)):
+            np.random.seed(seed)
+            np.random.standard_normal(pre)            # an odd count leaves a cached second value behind
+            start = np.random.get_state()
+            np.random.standard_normal(skip)
+            want = np.random.standard_normal(fill)
+            tail = np.random.standard_normal(5)
+            np.random.set_state(start)
+            got = _lib.legacy_normals(skip, fill, th)
+            assert np.array_equal(got, want), (seed, pre, skip, fill)
+            assert np.array_equal(np.random.standard_normal(5), tail), (seed, pre, skip, fill)
+    np.random.seed(5)
+    a = np.random.uniform(size=3)                     # the uniform stream is the same generator: still aligned
+    np.random.seed(5)
+    _lib.legacy_normals(0, 0)
+    assert np.array_equal(np.random.uniform(size=3), a)
 
 
 def test_c_abi_exports_every_declared_symbol():
