@@ -50,7 +50,9 @@ VALU_PER_PAIR_CHAIN = 47 + 0.85 * 45 + 0.15 * 121      # vector instructions of 
 FLOP_PER_MCMI_TERM = 53 + 2 * 44 + 6
 # committed counter summaries (rocprofv3 --pmc passes of this very command, tools/profile_gpu.sh + tools/pmc_summary.py):
 # HBM traffic and instruction counts per launch are read from these files and the file is named in the output
-PMC_FILES = {"headline": "profiles/r2_pmc_summary.csv", "general": "profiles/r2_general_pmc_summary.csv"}
+PMC_FILES = {"headline": "profiles/r2_pmc_summary.csv", "general": "profiles/r2_general_pmc_summary.csv",
+             "k8": "profiles/r3_k8_pmc_summary.csv"}
+ROUND_GAPS_FILE = "profiles/r3_round_gaps.json"   # launches / busy fraction of a round out of a committed kernel trace
 CALIBRATION_FILE = "profiles/r2_oracle_calibration.json"
 
 
@@ -153,6 +155,16 @@ def pmc_fields(which, kernel_prefix, launch_s):
     return out
 
 
+def round_gaps():
+    """GPU-busy fraction and launches of one headline round out of the committed kernel trace summary (tools/round_gaps.py
+    on a rocprofv3 --kernel-trace run of this command), or None."""
+    path = os.path.join(ROOT, ROUND_GAPS_FILE)
+    if not os.path.exists(path):
+        return None
+    with open(path) as f:
+        return dict(json.load(f), file=ROUND_GAPS_FILE)
+
+
 def other_workloads(X, rel, device):
     """Secondary timings on the same synthetic data (rank 0, N = 1 only; not part of `value`): the general scorer with a
     noisy user (reference configs usps-mistakes / mirflickr-mistakes style) and MCMI_min with the reference's subsample,
@@ -213,6 +225,8 @@ def other_workloads(X, rel, device):
                            traffic_note="traffic: per launch of gen_main_kernel, one of the ~12 slab launches of a step"))
     out["ital_general_user_k4"] = dict(res, roofline=roof,
                                        config="label_prob 0.5, mistake_prob 0.25: 3^t - 1 feedback configurations per pattern")
+    del L
+    out["ital_k8_25000x512"] = k8_workload(device)
     np.random.seed(0)
     m = MCMI_min(X, length_scale=LENGTH_SCALE, subsample=1000, device=device)
     r, prof = timed(m, 20, BATCH)
@@ -244,6 +258,52 @@ def other_workloads(X, rel, device):
                                                                "launches of 1000 and 9273 candidates averaged)"})
     out["mcmi_min_subsample1000_k4"] = dict(r, roofline=roofs, config="MCMI_min, subsample 1000 (reference configs/usps.conf)")
     return out
+
+
+def k8_workload(device, n=25000, d=512, k=8):
+    """BASELINE.json configs[2] / SURVEY.md 8d C3': 25 000 x 512, batches of 8, perfect user, full 2^t enumeration -- one
+    fetch + update round after a warm-up round, with the roofline of its dominant kernel (the t = 8 lattice sums)."""
+    import torch
+    from ital_amd import ITAL, mvn_stream
+    X = make_data(n, d, seed=3)
+    rel = np.where(X[:, 0] > 0.5, 1.0, -1.0)
+    mvn_stream.GLOBAL.reset()
+    L = ITAL(X, length_scale=float(np.sqrt(d / 12.0)), device=device)
+    L.update({0: 1})
+    ret = L.fetch_unlabelled(k)
+    L.update({int(i): float(rel[i]) for i in ret})
+    L.profile = []
+    L.event_pool = [torch.cuda.Event(enable_timing=True) for _ in range(8 * k)]
+    for ev in L.event_pool:
+        ev.record()
+    torch.cuda.synchronize()
+    n_c = len(L.get_unseen())
+    t0 = time.perf_counter()
+    ret = L.fetch_unlabelled(k)
+    L.update({int(i): float(rel[i]) for i in ret})
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    scored = sum(n_c - t for t in range(k))
+    prof = {(name, t): (e0.elapsed_time(e1) * 1e-3, c) for name, t, c, e0, e1 in L.profile}
+    res = {"ms_per_round": dt * 1e3, "candidates_per_s": scored / dt,
+           "config": "synthetic %d x %d, k=%d, perfect user, full 2^t enumeration (BASELINE.json configs[2], SURVEY 8d C3')" % (n, d, k),
+           "kernel_ms": {"%s_t%d" % key: v[0] * 1e3 for key, v in sorted(prof.items())}}
+    roofs = {}
+    for t in (7, 8):
+        if ("qmc_main", t) in prof:
+            sec, n_cand = prof[("qmc_main", t)]
+            pairs = qmc_pairs(t, n_cand)
+            ach = pairs * FLOP_PER_PAIR / sec / 1e12
+            roofs["qmc_main_kernel<%d>" % t] = dict(
+                {"bound": "fp64-valu", "achieved": ach, "peak": FP64_VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
+                 "frac": ach / FP64_VALU_PEAK_TFLOPS, "avg_launch_ms": sec * 1e3, "pairs_per_s": pairs / sec,
+                 "algorithmic_pairs_per_launch": pairs},
+                **pmc_fields("k8", "void ital::qmc_main_kernel<%d>" % t, sec))
+    res["roofline"] = roofs
+    del L
+    gc.collect()
+    torch.cuda.empty_cache()
+    return res
 
 
 def cpu_baseline(X, cores):
@@ -306,7 +366,9 @@ def scaling_workload(device, rank, world, group, rounds=3):
     for ev in L.event_pool:
         ev.record()
     scored = 0
+    from ital_amd import _lib
     barrier()
+    launches0 = _lib.lib().ital_launch_count()
     t0 = time.perf_counter()
     for _ in range(rounds):
         n_cand = n - len(L.relevant_ids) - len(L.irrelevant_ids)
@@ -314,6 +376,7 @@ def scaling_workload(device, rank, world, group, rounds=3):
         scored += sum(n_cand - t for t in range(k))
     barrier()
     dt = time.perf_counter() - t0
+    launches = (_lib.lib().ital_launch_count() - launches0) / rounds
     if world > 1:
         import torch.distributed as dist
         tt = torch.tensor([dt], dtype=torch.float64, device=device)
@@ -336,7 +399,9 @@ def scaling_workload(device, rank, world, group, rounds=3):
             "backend": backend, "rounds": rounds, "ms_per_round": dt / rounds * 1e3, "candidates_per_s": scored / dt,
             "exchange_ms_per_greedy_step": float(np.mean(ex)) if ex else None,
             "kernel_ms": {"%s_t%d" % key: float(np.mean(v)) for key, v in sorted(prof.items())},
-            "peak_device_memory_gib": mem,
+            "kernel_ms_note": "qmc_main_t*: the lattice-sum kernel alone (one slab of the workspace); qmc_slabsN_t*: first to "
+                              "last lattice sum of a step that needed N slabs, incl. the preparation / combine launches between",
+            "library_launches_per_round": launches, "peak_device_memory_gib": mem,
             "note": "per-step exchange = all_gather_into_tensor of one record per rank (null on one rank: no collective)"}
 
 
@@ -413,19 +478,30 @@ def main():
     restart()
     for _ in range(args.warmup):
         one_round()
+    # the same K steps once with the interpreter's heap as it is (reported next to the headline, not as the headline)
+    restart()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        one_round()
+    barrier()
+    dt_unfrozen = time.perf_counter() - t0
     restart()
     learner.profile = None if os.environ.get("ITAL_BENCH_NO_EVENTS") else []
     # timing events are created before the timed region (only recorded inside it)
     learner.event_pool = [torch.cuda.Event(enable_timing=True) for _ in range(8 * (2 * BATCH) * args.steps)]
     for ev in learner.event_pool:
         ev.record()          # creates the handle (the library records some of them itself, around single kernels)
-    # a serving process freezes its start-up heap: without this CPython's generation-2 collector walks torch's ~10^5
-    # objects once every few rounds (a 40 ms pause, measured: ten 3.4 ms rounds cost 73 ms), which has nothing to do with
-    # the path under test
-    gc.collect()
-    gc.freeze()
+    # a serving process freezes its start-up heap (ital_amd.serving_mode()): without this CPython's generation-2 collector
+    # walks torch's ~10^5 objects once every few rounds (a 40 ms pause, measured: ten 3.4 ms rounds cost 73 ms), which has
+    # nothing to do with the path under test; the figure without it is reported as ms_per_step_unfrozen_heap
+    import ital_amd
+    ital_amd.serving_mode()
+    from ital_amd import _lib
+    rows_local = learner.gp.n
     scored = 0
     barrier()
+    launches0 = _lib.lib().ital_launch_count()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         n_cand = n_total - len(learner.relevant_ids) - len(learner.irrelevant_ids)
@@ -433,11 +509,12 @@ def main():
         scored += sum(n_cand - t for t in range(BATCH))
     barrier()
     dt = time.perf_counter() - t0
+    launches = (_lib.lib().ital_launch_count() - launches0) / args.steps
     if world > 1:
         import torch.distributed as dist
-        tt = torch.tensor([dt], dtype=torch.float64, device=device)
+        tt = torch.tensor([dt, dt_unfrozen], dtype=torch.float64, device=device)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt.item())
+        dt, dt_unfrozen = float(tt[0].item()), float(tt[1].item())
 
     # per-kernel durations from the HIP events recorded on the launch stream during the timed region
     prof = {}
@@ -477,7 +554,7 @@ def main():
         if cc:
             avg_s = float(np.mean([d for d, _ in cc]))
             m_avg = float(np.mean([c for _, c in cc]))
-            bytes_alg = ROWS_PER_GPU * 8.0 * (DIM + m_avg + 1)
+            bytes_alg = rows_local * 8.0 * (DIM + m_avg + 1)
             ach = bytes_alg / avg_s / 1e9
             roof_hbm = {"bound": "hbm", "kernel": "kcols_kernel (cross-covariance column)", "achieved": ach,
                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": None,
@@ -494,7 +571,13 @@ def main():
                "roofline": roof, "roofline_hbm": hbm_stream_probe(device) if world == 1 else roof_hbm,
                "roofline_hbm_at_workload_size": roof_hbm,
                "kernel_ms": {"%s_t%d" % k: float(np.mean([d for d, _ in v])) * 1e3 for k, v in sorted(prof.items())},
+               "ms_per_step_unfrozen_heap": dt_unfrozen / args.steps * 1e3,
+               "library_launches_per_step": launches, "round_gaps": round_gaps(),
                "scaling_workload": scale}
+        if scale is not None:
+            # the strong-scaling figure north_star asks for (1M x 512, k = 4, rows split over the ranks), also at top level
+            out["value_strong_1M"] = scale["candidates_per_s"]
+            out["ms_per_round_strong_1M"] = scale["ms_per_round"]
         if world == 1 and not os.environ.get("ITAL_BENCH_NO_EXTRAS"):
             out["other_workloads"] = other_workloads(X, rel, device)
         out["cpu_baseline"] = cpu_base

@@ -32,6 +32,8 @@ typedef struct ihipStream_t* hipStream_t; /* same declaration as hip_runtime_api
 /* Library identification / error reporting. */
 const char* ital_version(void);
 const char* ital_last_error(void);
+/* Kernels this library has launched in the calling process so far (instrumentation: launches per round). */
+int64_t ital_launch_count(void);
 
 /* ---- GP core ------------------------------------------------------------------------------------------
  * Feature rows are fp64, row-major, leading dimension ldx = d rounded up to a multiple of 16 (zero padded).
@@ -183,8 +185,10 @@ typedef struct ital_score_desc {
      * lattices of every evaluated call -- 0.5 to 1 KB per call) */
     double* work;
     int64_t work_doubles;
-    void* ev_start;         /* optional hipEvent_t pair recorded on the stream right before / after the lattice-sum kernel */
-    void* ev_stop;          /* (the FP64-VALU bound kernel of the step; with several slabs: the last one) */
+    void* ev_start;         /* optional hipEvent_t pair recorded on the stream right before the first / after the last */
+    void* ev_stop;          /* lattice-sum kernel of the step (the FP64-VALU bound one).  One slab: that kernel alone; with
+                               ceil(n_cand / slab) > 1 slabs the pair also spans the preparation / combine launches of the
+                               slabs in between (a few percent of the lattice sums) */
 } ital_score_desc;
 
 /* Scores every live candidate position: mi[p] = MI(batch + candidate p).

@@ -8,7 +8,17 @@ The arithmetic lives in hand-written HIP kernels (ital_amd/csrc, C ABI in includ
 from . import mvn_stream
 from .mvn_stream import GLOBAL as mvn_global_stream
 
-__all__ = ["ITAL", "GaussianProcess", "ActiveRetrievalBase", "mvn_stream", "mvn_global_stream"]
+__all__ = ["ITAL", "MCMI_min", "GaussianProcess", "ActiveRetrievalBase", "mvn_stream", "mvn_global_stream", "serving_mode"]
+
+
+def serving_mode():
+    """For a long-running process that calls fetch_unlabelled() / update() in a loop (a retrieval server; bench.py): moves
+    everything allocated so far -- the heap of an imported torch, ~10^5 objects -- out of the reach of CPython's cyclic
+    garbage collector (gc.freeze()).  Without it the generation-2 collector walks that heap once every few rounds: a
+    40 ms pause in a loop of 3 ms rounds.  Objects created afterwards are collected as usual."""
+    import gc
+    gc.collect()
+    gc.freeze()
 
 
 def __getattr__(name):

@@ -70,6 +70,7 @@ SIGNATURES = {
     "ital_mvn_generic_tables": (c_int, [c_int, c_void_p, c_void_p]),
     "ital_np_legacy_normals": (c_int, [ctypes.POINTER(ItalNpLegacyState), c_int64, c_void_p, c_int64, c_int]),
     "ital_last_error": (ctypes.c_char_p, []),
+    "ital_launch_count": (c_int64, []),
     "ital_row_norms": (c_int, [c_void_p, c_int64, c_int, c_void_p, c_void_p]),
     "ital_rbf_cols": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_void_p, c_void_p, c_int, c_double, c_double,
                               c_void_p, c_int64, c_void_p]),

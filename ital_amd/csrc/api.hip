@@ -7,6 +7,7 @@
 #include "ital_internal.h"
 
 static thread_local char g_err[512] = "";
+long long g_ital_launches = 0;
 
 int ital_fail(int code, const char* msg) {
     snprintf(g_err, sizeof(g_err), "%s", msg);
@@ -34,4 +35,5 @@ int ital_raise_lds_limit(const void* kernel, int bytes, ItalLdsFlags& flags, con
 }
 
 extern "C" const char* ital_last_error(void) { return g_err; }
+extern "C" int64_t ital_launch_count(void) { return g_ital_launches; }
 extern "C" const char* ital_version(void) { return "ital_hip 0.1 (gfx950)"; }

@@ -186,7 +186,7 @@ extern "C" int ital_chol_append(const double* XT, const double* XTn, int ldx, do
                                 int* status, hipStream_t stream) {
     if (c < 1 || c > 16) return ital_fail(-22, "ital_chol_append: c must be in 1..16");
     if (m < 0 || m + c > ldl) return ital_fail(-22, "ital_chol_append: factor capacity exceeded");
-    hipLaunchKernelGGL(ital::chol_append_kernel, dim3(1), dim3(1024), 0, stream, XT, XTn, ldx, L, ldl, alpha, ynew, m,
+    ITAL_LAUNCH(ital::chol_append_kernel, dim3(1), dim3(1024), 0, stream, XT, XTn, ldx, L, ldl, alpha, ynew, m,
                        c, var, -2.0 * length_scale * length_scale, noise, status);
     return ital_check_launch("ital_chol_append");
 }

@@ -52,6 +52,23 @@ struct HotK {
     }
 };
 
+// The same coefficients as opaque SCALAR-register values: for the kernels that read their factor from LDS (T >= 7 of
+// the perfect-user scorer) the scalar file has room for them, and the 38 vector registers go to the chains instead
+// (one scalar operand per v_fma_f64 is what gfx9 encodes).
+__device__ __forceinline__ double opaque_s(double k) { asm volatile("" : "+s"(k)); return k; }
+struct HotKS {
+    double e[10], l[9];
+    __device__ __forceinline__ void load() {
+        e[0] = opaque_s(2.5100375832561321544e-8); e[1] = opaque_s(2.7620075879983480862e-7);
+        e[2] = opaque_s(2.7557268480310025341e-6); e[3] = opaque_s(0.000024801521322368693026);
+        e[4] = opaque_s(0.00019841269863040545271); e[5] = opaque_s(0.0013888888917196719077);
+        e[6] = opaque_s(0.0083333333333300644495); e[7] = opaque_s(0.041666666666624161903);
+        e[8] = opaque_s(0.16666666666666667452); e[9] = opaque_s(0.50000000000000010211);
+#pragma unroll
+        for (int i = 0; i < 9; i++) l[i] = opaque_s(2.0 / (19 - 2 * i));
+    }
+};
+
 // exp(x) for x in [-745, 0]: Cody-Waite reduction by ln2, degree-13 Taylor polynomial on |r| <= ln2/2 (relative error
 // < 1e-16), scaling by v_ldexp_f64.  19 VALU instructions against ~42 for the general-purpose library routine.
 __device__ __forceinline__ double exp_neg(double x) {
@@ -91,7 +108,8 @@ __device__ __forceinline__ double exp_neg(double x) {
 }
 
 __device__ __forceinline__ double exp_neg(double x, const LitK&) { return exp_neg(x); }
-__device__ __forceinline__ double exp_neg(double x, const HotK& k) {
+template <class KT>
+__device__ __forceinline__ double exp_neg(double x, const KT& k) {
     const double LOG2E = 1.4426950408889634074, LN2_HI = 6.93147180369123816490e-01, LN2_LO = 1.90821492927058770002e-10;
     const double n = rint(x * LOG2E);
     double r = fma(-n, LN2_HI, x);
@@ -131,7 +149,8 @@ __device__ __forceinline__ double log_pos(double x) {
 }
 
 __device__ __forceinline__ double log_pos(double x, const LitK&) { return log_pos(x); }
-__device__ __forceinline__ double log_pos(double x, const HotK& k) {
+template <class KT>
+__device__ __forceinline__ double log_pos(double x, const KT& k) {
     const double LN2_HI = 6.93147180369123816490e-01, LN2_LO = 1.90821492927058770002e-10;
     int e = __builtin_amdgcn_frexp_exp(x);
     double m = __builtin_amdgcn_frexp_mant(x);  // [0.5, 1)

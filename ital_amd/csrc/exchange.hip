@@ -2,11 +2,19 @@
 // all ranks receive all of them -- ncclAllGather over RCCL (xGMI inside a node).  ~1.3 KB x world at d = 128 .. ~20 KB at
 // d = 2048: latency bound, one ring step per peer.
 //
-// RCCL is resolved at run time from what the process already has loaded (a PyTorch host brings its own librccl.so;
-// linking a second copy into this library would give the process two RCCL instances) and only then by name.
+// RCCL is resolved at run time from what the process ALREADY has loaded (a PyTorch host brings its own librccl.so; a
+// second copy in the process would be handed communicators the first one created: undefined behaviour).  Order:
+//   1. the global symbol scope (a host linked against RCCL, or one that loaded it RTLD_GLOBAL);
+//   2. the loaded objects themselves (dl_iterate_phdr): a Python host loads torch's RCCL with RTLD_LOCAL, invisible to (1);
+//      the object whose file name starts with "librccl" is re-opened by its own path with RTLD_NOLOAD (no new copy possible);
+//   3. only if the environment names a library explicitly (ITAL_RCCL_LIBRARY=/path/librccl.so.1) is anything loaded by path.
+// Nothing is ever loaded by bare name.
 #include <dlfcn.h>
 #include <hip/hip_runtime.h>
+#include <link.h>
 #include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
 
 #include "ital_hip.h"
 #include "ital_internal.h"
@@ -19,20 +27,42 @@ constexpr int NCCL_FLOAT64 = 8;   // ncclDouble (nccl.h: ncclFloat64 = 8)
 
 all_gather_fn g_all_gather = nullptr;
 error_string_fn g_error_string = nullptr;
+char g_how[600] = "";
+
+int find_loaded_rccl(struct dl_phdr_info* info, size_t, void* out) {
+    const char* path = info->dlpi_name;
+    if (!path || !*path) return 0;
+    const char* base = strrchr(path, '/');
+    base = base ? base + 1 : path;
+    if (strncmp(base, "librccl", 7) != 0) return 0;
+    snprintf(static_cast<char*>(out), 512, "%s", path);
+    return 1;   // stop: first match
+}
 
 bool resolve() {
     if (g_all_gather) return true;
+    void* handle = nullptr;
     void* sym = dlsym(RTLD_DEFAULT, "ncclAllGather");
+    if (sym) {
+        snprintf(g_how, sizeof(g_how), "global symbol scope");
+    } else {
+        char path[512] = "";
+        if (dl_iterate_phdr(find_loaded_rccl, path) && (handle = dlopen(path, RTLD_NOW | RTLD_NOLOAD))) {
+            sym = dlsym(handle, "ncclAllGather");
+            snprintf(g_how, sizeof(g_how), "already loaded %s", path);
+        }
+    }
     if (!sym) {
-        const char* names[] = {"librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so"};
-        for (const char* n : names) {
-            void* h = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
-            if (h && (sym = dlsym(h, "ncclAllGather"))) break;
+        const char* env = getenv("ITAL_RCCL_LIBRARY");
+        if (env && *env && (handle = dlopen(env, RTLD_NOW | RTLD_LOCAL))) {
+            sym = dlsym(handle, "ncclAllGather");
+            snprintf(g_how, sizeof(g_how), "ITAL_RCCL_LIBRARY=%s", env);
         }
     }
     if (!sym) return false;
     g_all_gather = reinterpret_cast<all_gather_fn>(sym);
-    g_error_string = reinterpret_cast<error_string_fn>(dlsym(RTLD_DEFAULT, "ncclGetErrorString"));
+    g_error_string = reinterpret_cast<error_string_fn>(handle ? dlsym(handle, "ncclGetErrorString")
+                                                              : dlsym(RTLD_DEFAULT, "ncclGetErrorString"));
     return true;
 }
 
@@ -42,7 +72,9 @@ extern "C" int ital_select_exchange(const double* record, double* records_all, i
                                     hipStream_t stream) {
     if (!record || !records_all || rec_len <= 0) return ital_fail(-22, "ital_select_exchange: bad arguments");
     if (!nccl_comm) return ital_fail(-22, "ital_select_exchange: communicator missing (ncclComm_t of this rank)");
-    if (!resolve()) return ital_fail(-38, "ital_select_exchange: RCCL (ncclAllGather) not found in this process");
+    if (!resolve())
+        return ital_fail(-38, "ital_select_exchange: no RCCL (ncclAllGather) loaded in this process -- create the communicator "
+                              "with the RCCL the host uses first, or name the library in ITAL_RCCL_LIBRARY");
     const int rc = g_all_gather(record, records_all, (size_t)rec_len, NCCL_FLOAT64, nccl_comm, stream);
     if (rc != 0) {
         char msg[256];

@@ -498,7 +498,7 @@ __global__ __launch_bounds__(256) void mcmi_score_kernel(McmiArgs a) {
 
 template <int T>
 static int launch_mcmi(const McmiArgs& a, hipStream_t stream) {
-    hipLaunchKernelGGL(mcmi_score_kernel<T>, dim3((unsigned)a.n_i), dim3(256), 0, stream, a);
+    ITAL_LAUNCH(mcmi_score_kernel<T>, dim3((unsigned)a.n_i), dim3(256), 0, stream, a);
     return ital_check_launch("ital_mcmi_score_step");
 }
 
@@ -521,10 +521,10 @@ extern "C" int ital_cov_block(const double* Xa, const double* an, int64_t na, co
         const int64_t lx = (nb + CB_T - 1) / CB_T, ly = (na + CB_T - 1) / CB_T;
         if (ly > 65535) return ital_fail(-22, "ital_cov_block: too many rows per call");
         // (a grid dealt to the XCDs in 8 x 8-tile patches for L2 reuse was measured: 2-9 % slower than this plain sweep)
-        hipLaunchKernelGGL(cov_block_lds_kernel, dim3((unsigned)lx, (unsigned)ly), dim3(256), 0, stream, a);
+        ITAL_LAUNCH(cov_block_lds_kernel, dim3((unsigned)lx, (unsigned)ly), dim3(256), 0, stream, a);
         return ital_check_launch("ital_cov_block(lds)");
     }
-    hipLaunchKernelGGL(cov_block_kernel<false>, dim3((unsigned)gx, (unsigned)gy), dim3(256), 0, stream, a);
+    ITAL_LAUNCH(cov_block_kernel<false>, dim3((unsigned)gx, (unsigned)gy), dim3(256), 0, stream, a);
     return ital_check_launch("ital_cov_block");
 }
 
@@ -551,8 +551,8 @@ extern "C" int ital_cov_abs_rowsum(const double* Xa, const double* an, int64_t n
     CovArgs a = {Xa, an, na, Xb, bn, nb, ldx, Va, ldva, Vb, ldvb, m, var, -2.0 * length_scale * length_scale, work, na};
     // (the row sums stay on the register-tiled kernel: with the 16 running sums on top of its 64 accumulators the
     // LDS-staged one spills at two workgroups per CU)
-    hipLaunchKernelGGL(cov_block_kernel<true>, dim3((unsigned)nsplit, (unsigned)gy), dim3(256), 0, stream, a);
-    hipLaunchKernelGGL(rowsum_reduce_kernel, dim3((unsigned)((na + 255) / 256)), dim3(256), 0, stream, work, na, (int)nsplit, na,
+    ITAL_LAUNCH(cov_block_kernel<true>, dim3((unsigned)nsplit, (unsigned)gy), dim3(256), 0, stream, a);
+    ITAL_LAUNCH(rowsum_reduce_kernel, dim3((unsigned)((na + 255) / 256)), dim3(256), 0, stream, work, na, (int)nsplit, na,
                        accumulate, out);
     return ital_check_launch("ital_cov_abs_rowsum");
 }

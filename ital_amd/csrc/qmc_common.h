@@ -45,6 +45,9 @@ __device__ __forceinline__ void phinv_wave(const double (&p)[NC], double (&out)[
         slot[c] = total + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
         total += __popcll(m);
         if (need[c]) q[slot[c]] = p[c];
+#ifdef ITAL_QMC_PS_SCHED_BARRIER
+        if (NC > 4 && (c & 1)) __builtin_amdgcn_sched_barrier(0);   // two central branches at a time: bounds the transient registers
+#endif
     }
     if (total == 0) return;
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -184,6 +187,114 @@ __device__ __forceinline__ double qmc_lane_sum(const double* __restrict__ lat,
             dead[NCLA - 1] = !ok;
         }
         acc += eval_chains<T, NCLA>(xx, dead, cf, lm, infi_c, tailq, lane, kk);
+    }
+    return acc;
+}
+
+// The lattice sum for the larger batch dimensions of the perfect-user kernel (T = 7, 8), where the form above runs out of
+// registers (six chains: 6 (T-1) lattice coordinates + 6 (T-1) conditioned values = 168 VGPRs at T = 8 before any
+// arithmetic; it spilled 40 VGPRs / 62 SGPRs at two waves per SIMD).  Here a lane keeps per lattice item only the point
+// number and the offset of its shift; the coordinate of stage i is formed at stage i from the lattice in LDS (two
+// broadcast reads per item: 64 consecutive items span at most two shifts) and serves the point and its antithetic partner.
+// CFL: the factor and the limits are read from LDS at use as well (`slab`: NCOR factor values, then T limits) instead
+// of living in 2 (NCOR + T) scalar registers.
+template <int T, int NI, bool CFL, class K>
+__device__ __forceinline__ double eval_items_ps(const int (&kq)[NI], const int (&so)[NI], const bool (&ok)[NI],
+                                                const double* __restrict__ lat,
+                                                const double (&cf)[(T * (T - 1) / 2 > 0 ? T * (T - 1) / 2 : 1)],
+                                                const double (&lm)[T], const double* __restrict__ slab, unsigned infi_c,
+                                                double* tailq, int lane, const K& kk) {
+    constexpr int NDIM = T - 1, NCB = 2 * NI, NCOR = T * (T - 1) / 2;
+    double yy[NCB][NDIM], ff[NCB];
+#pragma unroll
+    for (int c = 0; c < NCB; c++) ff[c] = ok[c >> 1] ? 1.0 : 0.0;
+#pragma unroll
+    for (int i = 0; i < T; i++) {
+        const bool lower = (infi_c >> i) & 1u;
+        if (CFL) __asm__ volatile("" ::: "memory");   // keeps this row's factor loads inside the lattice loop
+        const double lmi = CFL ? slab[NCOR + i] : lm[i];
+        double sc[NCB];
+#pragma unroll
+        for (int c = 0; c < NCB; c++) sc[c] = 0;
+#pragma unroll
+        for (int j = 0; j < i; j++) {
+            const double cij = CFL ? slab[i * (i - 1) / 2 + j] : cf[i * (i - 1) / 2 + j];
+#pragma unroll
+            for (int c = 0; c < NCB; c++) sc[c] = fma(cij, yy[c][j], sc[c]);
+        }
+        double pin[NCB];
+#pragma unroll
+        for (int h = 0; h < NI; h++) {
+            double x0 = 0;
+            if (i < T - 1) {
+                const double v = kq[h] * lat[so[h] + i] + lat[8 * NDIM + so[h] + i];
+                const double fr = v - floor(v);
+                x0 = fabs(2 * fr - 1);
+            }
+#pragma unroll
+            for (int a = 0; a < 2; a++) {
+                const int c = 2 * h + a;
+                const double ph = mvn_phi(lmi - sc[c], kk);
+                const double d = lower ? ph : 0.0;
+                const double w = lower ? 1.0 - ph : ph;
+                ff[c] *= w;
+                if (i < T - 1) pin[c] = fma(a ? 1 - x0 : x0, w, d);
+            }
+#ifdef ITAL_QMC_PS_SCHED_BARRIER
+            __builtin_amdgcn_sched_barrier(0);   // one item's two chains at a time: bounds the transient registers
+#endif
+        }
+        if (i < T - 1) {
+            double out[NCB];
+            phinv_wave<NCB>(pin, out, tailq, lane, kk);
+#pragma unroll
+            for (int c = 0; c < NCB; c++) yy[c][i] = out[c];
+        }
+    }
+    double acc = 0.0;
+#pragma unroll
+    for (int c = 0; c < NCB; c++) acc += ff[c];
+    return acc;
+}
+
+template <int T, class K, int NH, bool CFL>
+__device__ __forceinline__ double qmc_lane_sum_ps(const double* __restrict__ lat,
+                                                  const double (&cf)[(T * (T - 1) / 2 > 0 ? T * (T - 1) / 2 : 1)],
+                                                  const double (&lm)[T], const double* __restrict__ slab, unsigned infi_c,
+                                                  double* __restrict__ tailq, int lane, const K& kk) {
+    constexpr int NDIM = T - 1, PRIME = P_TAB[(NDIM < 10 ? NDIM : 10) - 1];
+    constexpr int NITEM = 8 * PRIME, FULL = NITEM / (64 * NH), REST = NITEM - FULL * 64 * NH;
+    constexpr int NIL = (REST + 63) / 64;              // items per lane of the last, partial round
+    constexpr int LOOP_END = (NIL == NH ? FULL + 1 : FULL) * 64 * NH;
+    double acc = 0.0;
+    for (int base = 0; base < LOOP_END; base += 64 * NH) {
+        int kq[NH], so[NH];
+        bool ok[NH];
+#pragma unroll
+        for (int h = 0; h < NH; h++) {
+            const int item = base + 64 * h + lane;
+            ok[h] = NIL != NH || item < NITEM;
+            const int it = ok[h] ? item : 0;
+            const int sft = it / PRIME;
+            kq[h] = it - sft * PRIME + 1;
+            so[h] = sft * NDIM;
+        }
+        acc += eval_items_ps<T, NH, CFL>(kq, so, ok, lat, cf, lm, slab, infi_c, tailq, lane, kk);
+    }
+    if (NIL > 0 && NIL != NH) {
+        constexpr int NILA = NIL > 0 ? NIL : 1;
+        int kq[NILA], so[NILA];
+        bool ok[NILA];
+#pragma unroll
+        for (int h = 0; h < NILA; h++) {
+            const int item = FULL * 64 * NH + 64 * h + lane;
+            ok[h] = item < NITEM;
+            const int it = ok[h] ? item : 0;
+            const int sft = it / PRIME;
+            kq[h] = it - sft * PRIME + 1;
+            so[h] = sft * NDIM;
+        }
+        acc += eval_items_ps<T, NILA, CFL>(kq, so, ok, lat, cf, lm, slab, infi_c, tailq, lane, kk);
     }
     return acc;
 }

@@ -228,7 +228,7 @@ extern "C" int ital_stage_labelled(const double* rows, int ldx, ital_label_batch
                                    double* y_dst, hipStream_t stream) {
     if (lb.c < 1 || lb.c > 16) return ital_fail(-22, "ital_stage_labelled: 1..16 samples per call");
     if (ldx % 16 != 0) return ital_fail(-22, "ital_stage_labelled: ldx must be a multiple of 16");
-    hipLaunchKernelGGL(stage_labelled_kernel, dim3(lb.c), dim3(64), 0, stream, rows, ldx, lb, XT_dst, XTn_dst, y_dst);
+    ITAL_LAUNCH(stage_labelled_kernel, dim3(lb.c), dim3(64), 0, stream, rows, ldx, lb, XT_dst, XTn_dst, y_dst);
     return ital_check_launch("ital_stage_labelled");
 }
 
@@ -237,7 +237,7 @@ extern "C" int ital_row_norms(const double* X, int64_t n, int ldx, double* xnorm
     if (ldx % 16 != 0) return ital_fail(-22, "ital_row_norms: ldx must be a multiple of 16");
     int64_t blocks = (n + 3) / 4;
     if (blocks > 8192) blocks = 8192;
-    hipLaunchKernelGGL(row_norms_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, X, n, ldx, xnorm);
+    ITAL_LAUNCH(row_norms_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, X, n, ldx, xnorm);
     return ital_check_launch("ital_row_norms");
 }
 
@@ -247,7 +247,7 @@ static int launch_kcols(KcolsArgs& a, hipStream_t stream, const char* who) {
     if (a.c < 1 || a.c > 16) return ital_fail(-22, "kcols: c must be in 1..16");
     if (a.m < 0 || (a.m > 0 && (!a.W || !a.V))) return ital_fail(-22, "kcols: W/V missing");
     int64_t blocks = (a.n + 63) / 64;
-    hipLaunchKernelGGL(kcols_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, a);
+    ITAL_LAUNCH(kcols_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, a);
     return ital_check_launch(who);
 }
 
@@ -294,13 +294,13 @@ extern "C" int ital_predict(const double* Xt, int64_t nt, int ldx, const double*
     int rc = ital_row_norms(Xt, nt, ldx, xtn, stream);
     if (rc) return rc;
     const unsigned blocks = (unsigned)((nt + 255) / 256);
-    hipLaunchKernelGGL(predict_init_kernel, dim3(blocks), dim3(256), 0, stream, nt, var, mean, pvar);
+    ITAL_LAUNCH(predict_init_kernel, dim3(blocks), dim3(256), 0, stream, nt, var, mean, pvar);
     for (int c0 = 0; c0 < m; c0 += 16) {
         const int c = m - c0 < 16 ? m - c0 : 16;
         rc = ital_whiten_append(Xt, xtn, nt, ldx, XT + (int64_t)c0 * ldx, XTn + c0, c, L + (int64_t)c0 * ldl, ldl,
                                 L + (int64_t)c0 * ldl + c0, alpha + c0, Vt, ldvt, c0, var, length_scale, mean, pvar, stream);
         if (rc) return rc;
     }
-    if (clamp) hipLaunchKernelGGL(clamp0_kernel, dim3(blocks), dim3(256), 0, stream, nt, pvar);
+    if (clamp) ITAL_LAUNCH(clamp0_kernel, dim3(blocks), dim3(256), 0, stream, nt, pvar);
     return ital_check_launch("ital_predict");
 }

@@ -20,6 +20,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <type_traits>
+
 #include "device_math.h"
 #include "ital_hip.h"
 #include "ital_internal.h"
@@ -33,6 +35,15 @@
 #endif
 #ifndef ITAL_QMC_WAVES
 #define ITAL_QMC_WAVES(T) ((T) <= 4 ? 3 : 2)   // waves per SIMD the register allocation aims at (measured)
+#endif
+#ifndef ITAL_QMC_MAIN_PS
+#define ITAL_QMC_MAIN_PS(T) ((T) >= 7)   // lattice coordinates formed per stage (qmc_lane_sum_ps): T = 7, 8 spill otherwise
+#endif
+#ifndef ITAL_QMC_MAIN_KS
+#define ITAL_QMC_MAIN_KS(T) 1
+#endif
+#ifndef ITAL_QMC_MAIN_CFL
+#define ITAL_QMC_MAIN_CFL(T) ((T) >= 8)  // ... with the factor read from LDS at use instead of held in scalar registers
 #endif
 
 namespace ital {
@@ -184,7 +195,10 @@ struct Qmc {
     // full waves instead of 60 %); at t = 4 six chains spill at three waves per SIMD (4.3 ms) and lose at two (2.41 ms)
     static constexpr int NH = ITAL_QMC_MAIN_NH(T);
     static constexpr int TAILQ = 128 * NH;                    // compaction queue of the Phi^-1 tail branch (in place)
-    static constexpr int WAVE_DOUBLES = LAT + TAILQ;
+    static constexpr bool PS = ITAL_QMC_MAIN_PS(T), CFL = PS && ITAL_QMC_MAIN_CFL(T);
+    static constexpr int WAVE_DOUBLES = LAT + TAILQ + (CFL ? NCOR + T : 0);
+    // exp / log coefficients: vector-register operands, or scalar ones where the factor does not occupy the scalar file
+    typedef typename std::conditional<(CFL && ITAL_QMC_MAIN_KS(T)), HotKS, HotK>::type Coef;
     static constexpr int64_t CAND_DOUBLES = (int64_t)NPAT * (REC + 1) + 3;   // records, terms, 6 ints of generator state
 };
 // meta word of a record: bit 0 evaluate the lattice sum; bit 1 prior probability == 1 (else 0) when not evaluated;
@@ -469,18 +483,24 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(ITAL_QMC_WA
             }
         }
         double cf[Q::NCOR > 0 ? Q::NCOR : 1], lm[T];
+        double* slab = tailq + Q::TAILQ;
+        if (Q::CFL) {
+            for (int q = lane; q < Q::NCOR + T; q += 64) slab[q] = rec[q];     // factor, then limits (R_LIM == NCOR)
+        } else {
 #pragma unroll
-        for (int q = 0; q < Q::NCOR; q++) cf[q] = uniform_f64(rec[q]);
+            for (int q = 0; q < Q::NCOR; q++) cf[q] = uniform_f64(rec[q]);
 #pragma unroll
-        for (int q = 0; q < T; q++) lm[q] = uniform_f64(rec[Q::R_LIM + q]);
+            for (int q = 0; q < T; q++) lm[q] = uniform_f64(rec[Q::R_LIM + q]);
+        }
         const unsigned infi = (unsigned)(meta >> 8);
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 #if ITAL_QMC_HOTK
-        HotK kk;
+        typename Q::Coef kk;
         kk.load();
-        const double acc = qmc_lane_sum<T, HotK, Q::NH>(lat, cf, lm, infi, tailq, lane, kk);
+        const double acc = Q::PS ? qmc_lane_sum_ps<T, typename Q::Coef, Q::NH, Q::CFL>(lat, cf, lm, slab, infi, tailq, lane, kk)
+                                 : qmc_lane_sum<T, typename Q::Coef, Q::NH>(lat, cf, lm, infi, tailq, lane, kk);
 #else
         const double acc = qmc_lane_sum<T, LitK, Q::NH>(lat, cf, lm, infi, tailq, lane);
 #endif
@@ -528,14 +548,14 @@ static int launch_qmc(const ScoreArgs& a, double* work, int64_t work_doubles, hi
     int* seeds = reinterpret_cast<int*>(terms + slab * Q::NPAT);
     for (int64_t lo = 0; lo < a.n_cand; lo += slab) {
         const int64_t n = a.n_cand - lo < slab ? a.n_cand - lo : slab;
-        hipLaunchKernelGGL(qmc_seed_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, a, Q::NCALLS, lo, n, seeds);
-        hipLaunchKernelGGL(qmc_prep_kernel<T>, dim3((unsigned)((n + Q::PREP_THREADS - 1) / Q::PREP_THREADS), Q::NPAT),
+        ITAL_LAUNCH(qmc_seed_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, a, Q::NCALLS, lo, n, seeds);
+        ITAL_LAUNCH(qmc_prep_kernel<T>, dim3((unsigned)((n + Q::PREP_THREADS - 1) / Q::PREP_THREADS), Q::NPAT),
                            dim3(Q::PREP_THREADS), lds_prep, stream, a, lo, n, seeds, recs);
-        if (ev0) (void)hipEventRecord(ev0, stream);
-        hipLaunchKernelGGL(qmc_main_kernel<T>, dim3((unsigned)((n * Q::NPAT + 3) / 4)), dim3(256), lds_main, stream, a.alive, lo,
+        if (ev0 && lo == 0) (void)hipEventRecord(ev0, stream);
+        ITAL_LAUNCH(qmc_main_kernel<T>, dim3((unsigned)((n * Q::NPAT + 3) / 4)), dim3(256), lds_main, stream, a.alive, lo,
                            n, recs, a.vk, a.eps, a.label_mode, terms);
-        if (ev1) (void)hipEventRecord(ev1, stream);
-        hipLaunchKernelGGL(qmc_combine_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, terms, a.alive, lo, n,
+        if (ev1 && lo + n >= a.n_cand) (void)hipEventRecord(ev1, stream);
+        ITAL_LAUNCH(qmc_combine_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, terms, a.alive, lo, n,
                            Q::NPAT, a.label_mode, a.mi);
         int rc = ital_check_launch("ital_score_step(qmc)");
         if (rc) return rc;
@@ -579,11 +599,11 @@ extern "C" int ital_score_step(const ital_score_desc* d, hipStream_t stream) {
     a.jumppat = d->jumppat; a.vk = d->vk; a.status = d->status;
     for (int i = 0; i < 6; i++) a.seed[i] = d->seed[i];
     if (d->t == 1) {
-        hipLaunchKernelGGL(score_t1_kernel, dim3((unsigned)((d->n_cand + 255) / 256)), dim3(256), 0, stream, a);
+        ITAL_LAUNCH(score_t1_kernel, dim3((unsigned)((d->n_cand + 255) / 256)), dim3(256), 0, stream, a);
         return ital_check_launch("ital_score_step(t=1)");
     }
     if (d->t == 2) {
-        hipLaunchKernelGGL(score_t2_kernel, dim3((unsigned)((d->n_cand + 31) / 32)), dim3(256), 0, stream, a);
+        ITAL_LAUNCH(score_t2_kernel, dim3((unsigned)((d->n_cand + 31) / 32)), dim3(256), 0, stream, a);
         return ital_check_launch("ital_score_step(t=2)");
     }
     if (!d->jump || !d->jumppat || !d->vk) return ital_fail(-22, "ital_score_step: jump tables / generators missing for t >= 3");

@@ -1391,22 +1391,22 @@ extern "C" int ital_score_generic(const ital_gscore_desc* d, hipStream_t stream)
                 g.list = reinterpret_cast<unsigned int*>(g.recs + g.slab_n * total * g.R);
                 if (nslab >= 2) (void)hipStreamWaitEvent(ps->prep, ps->comb_done[buf], 0);   // the buffer is free again
                 (void)hipMemsetAsync(g.count, 0, 2 * sizeof(unsigned int), ps->prep);
-                hipLaunchKernelGGL(gen_prep_kernel, dim3((unsigned)((g.slab_n * g.nsplit + 1) / 2)), dim3(128), lds_p, ps->prep, ap, g);
+                ITAL_LAUNCH(gen_prep_kernel, dim3((unsigned)((g.slab_n * g.nsplit + 1) / 2)), dim3(128), lds_p, ps->prep, ap, g);
                 (void)hipEventRecord(ps->prep_done[buf], ps->prep);
                 (void)hipStreamWaitEvent(ps->main, ps->prep_done[buf], 0);
                 const unsigned mb = 768;     // 3 workgroups of 4 waves per CU; the waves stride over the slab's list
                 const unsigned cap_b = (unsigned)((g.slab_n * total + 3) / 4);     // the whole list, one call per wave
-#define ITAL_GEN_MAIN(T_) case T_: hipLaunchKernelGGL(gen_main_kernel<T_>, dim3(ITAL_GEN_ONE_TRIP(T_) ? cap_b : mb), dim3(256), lds_m, ps->main, g, d->pair_count); break;
+#define ITAL_GEN_MAIN(T_) case T_: ITAL_LAUNCH(gen_main_kernel<T_>, dim3(ITAL_GEN_ONE_TRIP(T_) ? cap_b : mb), dim3(256), lds_m, ps->main, g, d->pair_count); break;
                 switch (tfix_p) {
                     ITAL_GEN_MAIN(3) ITAL_GEN_MAIN(4) ITAL_GEN_MAIN(5) ITAL_GEN_MAIN(6) ITAL_GEN_MAIN(7) ITAL_GEN_MAIN(8)
                     ITAL_GEN_MAIN(9) ITAL_GEN_MAIN(10) ITAL_GEN_MAIN(11) ITAL_GEN_MAIN(12) ITAL_GEN_MAIN(13) ITAL_GEN_MAIN(14)
                     ITAL_GEN_MAIN(15) ITAL_GEN_MAIN(16)
                 }
 #undef ITAL_GEN_MAIN
-                hipLaunchKernelGGL(gen_main_kernel<0>, dim3(64), dim3(256), lds_m, ps->main, g, d->pair_count);
+                ITAL_LAUNCH(gen_main_kernel<0>, dim3(64), dim3(256), lds_m, ps->main, g, d->pair_count);
                 (void)hipEventRecord(ps->main_done[buf], ps->main);
                 (void)hipStreamWaitEvent(ps->comb, ps->main_done[buf], 0);       // the slab's terms add up under the next slab's sums
-                hipLaunchKernelGGL(gen_combine_kernel, dim3((unsigned)((g.slab_n + 3) / 4)), dim3(256), 0, ps->comb, ap, g);
+                ITAL_LAUNCH(gen_combine_kernel, dim3((unsigned)((g.slab_n + 3) / 4)), dim3(256), 0, ps->comb, ap, g);
                 (void)hipEventRecord(ps->comb_done[buf], ps->comb);
                 int rc = ital_check_launch("ital_score_generic(pipeline)");
                 if (rc) return rc;
@@ -1422,7 +1422,7 @@ extern "C" int ital_score_generic(const ital_gscore_desc* d, hipStream_t stream)
         if (const int rc = ital_raise_lds_limit(reinterpret_cast<const void*>(&score_generic_kernel<NMAX_, NH_, TFIX_, CLIP_>), \
                                                 160 * 1024, lds_flags, "ital_score_generic"))                          \
             return rc;                                                                                                 \
-        hipLaunchKernelGGL((score_generic_kernel<NMAX_, NH_, TFIX_, CLIP_>), dim3((unsigned)blocks), dim3(128), lds, stream, a); \
+        ITAL_LAUNCH((score_generic_kernel<NMAX_, NH_, TFIX_, CLIP_>), dim3((unsigned)blocks), dim3(128), lds, stream, a); \
     } while (0)
     if (clip) {     // grouped probabilities: the instantiations that carry the group passes
         if (nUmax <= 6) ITAL_GEN_LAUNCH(6, 2, 0, true);

@@ -240,19 +240,19 @@ extern "C" int ital_select_local(const double* mi, const int32_t* cand, const ui
     if (n_cand <= (1 << 18)) {
         RecordArgs a1 = {cand, pos_offset, gpos, row_offset, rank, mode, 0, mu, s2, X, xnorm, ldx, V, ldv, m, ldw,
                          C, ldc, nprev, kmax, nullptr, record, status};
-        hipLaunchKernelGGL(select_local_small_kernel, dim3(1), dim3(1024), 0, stream, mi, alive, n_cand, a1);
+        ITAL_LAUNCH(select_local_small_kernel, dim3(1), dim3(1024), 0, stream, mi, alive, n_cand, a1);
         return ital_check_launch("ital_select_local(small)");
     }
     int nparts = (int)((n_cand + 255) / 256);
     if (nparts > 1024) nparts = 1024;
     if (nparts < 1) nparts = 1;
-    hipLaunchKernelGGL(select_partial_kernel, dim3(nparts), dim3(256), 0, stream, mi, alive, n_cand, pos_offset, gpos, mode,
+    ITAL_LAUNCH(select_partial_kernel, dim3(nparts), dim3(256), 0, stream, mi, alive, n_cand, pos_offset, gpos, mode,
                        work);
     int rc = ital_check_launch("ital_select_local(partial)");
     if (rc) return rc;
     RecordArgs a = {cand, pos_offset, gpos, row_offset, rank, mode, nparts, mu, s2, X, xnorm, ldx, V, ldv, m, ldw,
                     C, ldc, nprev, kmax, work, record, status};
-    hipLaunchKernelGGL(select_record_kernel, dim3(1), dim3(256), 0, stream, a);
+    ITAL_LAUNCH(select_record_kernel, dim3(1), dim3(256), 0, stream, a);
     return ital_check_launch("ital_select_local(record)");
 }
 
@@ -267,7 +267,7 @@ extern "C" int ital_select_fused(const double* mi, const int32_t* cand, uint8_t*
     if (ldx != batch.ldx || ldw != batch.ldw) return ital_fail(-22, "ital_select_fused: batch layout mismatch");
     RecordArgs a = {cand, pos_offset, gpos, row_offset, rank, mode, 0, mu, s2, X, xnorm, ldx, V, ldv, m, ldw,
                     C, ldc, nprev, batch.kmax, nullptr, record, status};
-    hipLaunchKernelGGL(select_fused_kernel, dim3(1), dim3(1024), 0, stream, mi, n_cand, a, slot, batch, alive, ret);
+    ITAL_LAUNCH(select_fused_kernel, dim3(1), dim3(1024), 0, stream, mi, n_cand, a, slot, batch, alive, ret);
     return ital_check_launch("ital_select_fused");
 }
 
@@ -276,7 +276,7 @@ extern "C" int ital_select_resolve(const double* records, int world, int rec_len
     if (slot < 0 || slot >= batch.kmax) return ital_fail(-22, "ital_select_resolve: slot outside the batch capacity");
     if (rec_len != ITAL_REC_HEADER + batch.ldx + batch.ldw + batch.kmax)
         return ital_fail(-22, "ital_select_resolve: record length does not match the batch layout");
-    hipLaunchKernelGGL(select_resolve_kernel, dim3(1), dim3(256), 0, stream, records, world, rec_len, rank, mode, slot,
+    ITAL_LAUNCH(select_resolve_kernel, dim3(1), dim3(256), 0, stream, records, world, rec_len, rank, mode, slot,
                        batch, alive, ret);
     return ital_check_launch("ital_select_resolve");
 }

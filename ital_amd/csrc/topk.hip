@@ -168,16 +168,16 @@ extern "C" int ital_topk(const double* v, int64_t n, int64_t index_offset, int k
     int blocks = (int)((n + 1023) / 1024);
     if (blocks > 2048) blocks = 2048;
     if (blocks < 1) blocks = 1;
-    hipLaunchKernelGGL(topk_init_kernel, dim3(1), dim3(256), 0, stream, w, k);
+    ITAL_LAUNCH(topk_init_kernel, dim3(1), dim3(256), 0, stream, w, k);
     for (int pass = 0; pass < 8; pass++) {
-        hipLaunchKernelGGL(topk_hist_kernel, dim3(blocks), dim3(256), 0, stream, v, n, pass, w);
-        hipLaunchKernelGGL(topk_pick_kernel, dim3(1), dim3(256), 0, stream, w, pass);
+        ITAL_LAUNCH(topk_hist_kernel, dim3(blocks), dim3(256), 0, stream, v, n, pass, w);
+        ITAL_LAUNCH(topk_pick_kernel, dim3(1), dim3(256), 0, stream, w, pass);
     }
-    hipLaunchKernelGGL(topk_collect_kernel, dim3(blocks), dim3(256), 0, stream, v, n, index_offset, w, out_vals, out_idx);
+    ITAL_LAUNCH(topk_collect_kernel, dim3(blocks), dim3(256), 0, stream, v, n, index_offset, w, out_vals, out_idx);
     static ItalLdsFlags lds_flags;
     const size_t lds = (size_t)TOPK_MAX * 16;
     if (const int rc = ital_raise_lds_limit(reinterpret_cast<const void*>(&topk_finish_kernel), (int)lds, lds_flags, "ital_topk"))
         return rc;
-    hipLaunchKernelGGL(topk_finish_kernel, dim3(1), dim3(1024), lds, stream, v, n, index_offset, w, k, out_vals, out_idx);
+    ITAL_LAUNCH(topk_finish_kernel, dim3(1), dim3(1024), lds, stream, v, n, index_offset, w, k, out_vals, out_idx);
     return ital_check_launch("ital_topk");
 }

@@ -286,14 +286,16 @@ class ITAL(ActiveRetrievalBase):
                         desc.seed[j] = stream.state[j]
                     work = self._qmc_workspace(b, t, n_loc)
                     desc.work, desc.work_doubles = _ptr(work), work.numel()
-                    if self.profile is not None:
+                    if self.profile is not None and n_loc > 0:
                         # the lattice-sum kernel alone, bracketed by events the library records on the launch stream (an
                         # event has to be recorded once before its handle exists: the pool's events are, see bench.py).
                         # Every record is a barrier packet in the queue (~4 us of idle GPU in a 3 ms round), so the step
                         # as a whole is only bracketed where no kernel-level pair exists
                         k0, k1 = self._event(), self._event()
                         desc.ev_start, desc.ev_stop = k0.cuda_event, k1.cuda_event
-                        self.profile.append(("qmc_main", t, n_alive, k0, k1))
+                        # several slabs: the pair spans first .. last lattice sum incl. the launches between them
+                        slabs = -(-n_loc // max(work.numel() // int(lib.ital_score_workspace(t, 1)), 1))
+                        self.profile.append(("qmc_main" if slabs == 1 else "qmc_slabs%d" % slabs, t, n_alive, k0, k1))
                 ev0 = self._mark() if t < 3 else None
                 check(lib.ital_score_step(ctypes.byref(desc), st))
                 if t < 3:

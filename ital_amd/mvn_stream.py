@@ -53,9 +53,7 @@ class MvnStream:
         self.reset()
 
     def reset(self):
-        st = (ctypes.c_int * 6)()
-        _lib.check(_lib.lib().ital_mvn_seed(st))
-        self.state = tuple(int(v) for v in st)
+        self.state = SEED          # = ital_mvn_seed (checked in tests/test_host_logic.py); no library call at import time
         self.draws = 0
 
     def advance(self, n):

@@ -188,7 +188,14 @@ def test_record_exchange_below_the_c_abi_through_rccl():
     import ctypes
     from ital_amd import _lib
     lib = _lib.lib()
-    rccl = ctypes.CDLL(os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so"), mode=ctypes.RTLD_GLOBAL)
+    # torch's own RCCL, opened the way a Python host opens it: RTLD_LOCAL -- its symbols are NOT in the global scope, the
+    # library has to find the loaded object itself (and must not bring a second RCCL into the process)
+    rccl = ctypes.CDLL(os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so"))
+
+    def rccl_objects():
+        with open("/proc/self/maps") as f:
+            return {line.split()[-1] for line in f if "librccl" in line}
+    before = rccl_objects()
 
     class UniqueId(ctypes.Structure):
         _fields_ = [("internal", ctypes.c_char * 128)]
@@ -207,6 +214,7 @@ def test_record_exchange_below_the_c_abi_through_rccl():
                                             torch.cuda.current_stream().cuda_stream))
         torch.cuda.synchronize()
         assert torch.equal(out[0], rec)
+        assert rccl_objects() == before and len(before) == 1      # still the one RCCL the communicator came from
         assert lib.ital_select_exchange(rec.data_ptr(), out.data_ptr(), rec_len, None,
                                         torch.cuda.current_stream().cuda_stream) != 0     # no communicator: refused
     finally:
