@@ -13,6 +13,7 @@ Candidates are sharded by rows across ranks; the per-step exchange is ONE fixed-
 """
 import ctypes
 import os
+import time
 from concurrent.futures import ThreadPoolExecutor
 
 import numpy as np
@@ -67,6 +68,7 @@ class ITAL(ActiveRetrievalBase):
         self.event_pool = []     # pre-created timing events (bench.py)
         self.profile = None      # list to receive (stage, t, size, start_event, end_event) per launch (bench.py)
         self._fetch_bufs = None
+        self.mc_walk = [0, 0, 0.0]   # Monte-Carlo pattern sampling: standard normals computed / skipped, host seconds
 
     # ------------------------------------------------------------------ helpers
     def _perfect_user(self):
@@ -620,14 +622,18 @@ class ITAL(ActiveRetrievalBase):
             self._last_batch = (b, [int(i) for i in picks])
         return [int(i) for i in picks]
 
-    @staticmethod
-    def _walk_normals(n_live, j0, j1, per_cand):
+    def _walk_normals(self, n_live, j0, j1, per_cand):
         """numpy's global generator walked over the `per_cand` standard normals of each of `n_live` candidates
-        (multivariate_normal.rvs per candidate, reference ital.py:297); returns those of candidates j0 .. j1-1 (flat)."""
+        (multivariate_normal.rvs per candidate, reference ital.py:297); returns those of candidates j0 .. j1-1 (flat).
+        `mc_walk` accumulates [normals computed, normals skipped, seconds] (diagnostics / tests)."""
         j0, j1 = max(int(j0), 0), min(int(j1), int(n_live))
         j1 = max(j1, j0)
+        t0 = time.perf_counter()
         z = _lib.legacy_normals(j0 * per_cand, (j1 - j0) * per_cand, _HOST_THREADS)
         _lib.legacy_normals((n_live - j1) * per_cand, 0)
+        self.mc_walk[0] += (j1 - j0) * per_cand
+        self.mc_walk[1] += (n_live - (j1 - j0)) * per_cand
+        self.mc_walk[2] += time.perf_counter() - t0
         return z
 
     def _mc_samples(self, nr, npat, rel_mc, fb_mc, nfb, fb_mode, cand, picks, pos_of, E, pick_pos, e_mu, e_sig, C, subset_mode,
