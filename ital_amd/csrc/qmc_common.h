@@ -45,9 +45,6 @@ __device__ __forceinline__ void phinv_wave(const double (&p)[NC], double (&out)[
         slot[c] = total + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
         total += __popcll(m);
         if (need[c]) q[slot[c]] = p[c];
-#ifdef ITAL_QMC_PS_SCHED_BARRIER
-        if (NC > 4 && (c & 1)) __builtin_amdgcn_sched_barrier(0);   // two central branches at a time: bounds the transient registers
-#endif
     }
     if (total == 0) return;
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -240,9 +237,6 @@ __device__ __forceinline__ double eval_items_ps(const int (&kq)[NI], const int (
                 ff[c] *= w;
                 if (i < T - 1) pin[c] = fma(a ? 1 - x0 : x0, w, d);
             }
-#ifdef ITAL_QMC_PS_SCHED_BARRIER
-            __builtin_amdgcn_sched_barrier(0);   // one item's two chains at a time: bounds the transient registers
-#endif
         }
         if (i < T - 1) {
             double out[NCB];

@@ -31,7 +31,11 @@
 #define ITAL_QMC_HOTK 1   // exp / log coefficients of the lattice loop as vector-register operands (device_math.h HotK)
 #endif
 #ifndef ITAL_QMC_MAIN_NH
-#define ITAL_QMC_MAIN_NH(T) ((T) == 4 ? 2 : 3)   // t = 4 at three waves per SIMD has no room for six chains; 25 000 x 512, k = 8: 1.90 -> 1.84 s
+// lattice items per lane and round (x 2 chains): t = 4 at three waves per SIMD has no room for six chains; 25 000 x 512,
+// k = 8: 1.90 -> 1.84 s with six at t = 5, 6.  t = 7, 8: six chains spill whichever way the sum is written (52 / 152 B per lane
+// of scratch in round 2); four chains with per-stage coordinates and the factor in LDS run without scratch and faster
+// (25 000 x 256, k = 8, one round: 1.752 -> 1.659 s; t = 8 launches -7.6 %, t = 7 +1.5 %; profiles/r3_k8_variants.txt)
+#define ITAL_QMC_MAIN_NH(T) (((T) == 4 || (T) >= 7) ? 2 : 3)
 #endif
 #ifndef ITAL_QMC_WAVES
 #define ITAL_QMC_WAVES(T) ((T) <= 4 ? 3 : 2)   // waves per SIMD the register allocation aims at (measured)
@@ -40,10 +44,10 @@
 #define ITAL_QMC_MAIN_PS(T) ((T) >= 7)   // lattice coordinates formed per stage (qmc_lane_sum_ps): T = 7, 8 spill otherwise
 #endif
 #ifndef ITAL_QMC_MAIN_KS
-#define ITAL_QMC_MAIN_KS(T) 1
+#define ITAL_QMC_MAIN_KS(T) 0            // exp / log coefficients as scalar-register operands (measured: +7 % at t = 8, dropped)
 #endif
 #ifndef ITAL_QMC_MAIN_CFL
-#define ITAL_QMC_MAIN_CFL(T) ((T) >= 8)  // ... with the factor read from LDS at use instead of held in scalar registers
+#define ITAL_QMC_MAIN_CFL(T) ((T) >= 7)  // ... with the factor read from LDS at use instead of held in scalar registers
 #endif
 
 namespace ital {

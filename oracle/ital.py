@@ -305,7 +305,11 @@ class OracleITAL(OracleLearnerBase):
         return mi
 
     # ---- greedy batch construction (ital.py:84-134 with AppendedMutualInformation, :485-586)
-    def fetch_unlabelled(self, k, show_progress=False):
+    def fetch_unlabelled(self, k, show_progress=False, forced=None, patterns=None):
+        """`forced` (tests): the picks to append instead of the arg-max of every step -- the trace then holds this
+        restatement's MI of every candidate GIVEN that batch (what a differing pick has to be judged against: a numerical
+        tie of the two top values).  `patterns` (tests): per greedy step a dict candidate -> list of sign patterns to use
+        instead of the Monte-Carlo sampler's (the estimate for a given sample; numpy's generator is then not touched)."""
         cand = self.get_unseen()
         k = min(k, len(cand))
         if self.change_estimation_subset is None:
@@ -323,10 +327,12 @@ class OracleITAL(OracleLearnerBase):
                 cand = [cand[i] for i in sel]
         state = _Appended(self)
         self.trace = []
-        for _ in range(k):
-            vals = [state.score(i) for i in cand]
+        for step in range(k):
+            vals = [state.score(i, patterns=None if patterns is None else patterns[step][i]) for i in cand]
             best = int(np.argmax(vals))  # first maximum; NaN wins (ital.py:130)
             self.trace.append((list(cand), np.array(vals, dtype=np.float64), cand[best]))
+            if forced is not None:
+                best = cand.index(int(forced[step]))
             state.append(cand[best])
             del cand[best]
         return state.ret
