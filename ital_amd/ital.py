@@ -489,6 +489,8 @@ class ITAL(ActiveRetrievalBase):
                         b["qmc_work"] = w = torch.empty(want, dtype=torch.float64, device=dev)
                     desc.work, desc.work_doubles = _ptr(w), w.numel()
                 total_draws = None
+                if mc is None and self.keep_scores:
+                    self.last_patterns.append(None)          # this step enumerates its patterns
                 if mc is not None:
                     rel_arr, fb_arr, draws_pp = mc          # per list position (dead positions hold zeros)
                     if self.keep_scores:

@@ -328,7 +328,8 @@ class OracleITAL(OracleLearnerBase):
         state = _Appended(self)
         self.trace = []
         for step in range(k):
-            vals = [state.score(i, patterns=None if patterns is None else patterns[step][i]) for i in cand]
+            given = None if patterns is None else patterns[step]
+            vals = [state.score(i, patterns=None if given is None else given[i]) for i in cand]
             best = int(np.argmax(vals))  # first maximum; NaN wins (ital.py:130)
             self.trace.append((list(cand), np.array(vals, dtype=np.float64), cand[best]))
             if forced is not None:
