@@ -189,6 +189,23 @@ typedef struct ital_score_desc {
     void* ev_stop;          /* lattice-sum kernel of the step (the FP64-VALU bound one).  One slab: that kernel alone; with
                                ceil(n_cand / slab) > 1 slabs the pair also spans the preparation / combine launches of the
                                slabs in between (a few percent of the lattice sums) */
+    /* Optional, one rank: end the step with its selection -- everything ital_select_fused(mi, ..., nprev = slot = t - 1)
+     * does -- inside the last scoring launch instead of a launch of its own (every block leaves its best candidate in
+     * sel_parts, the block that finishes last selects, packs the record and appends the winner to the batch state; the
+     * winner's alive flag is cleared, hence `alive` is written in this mode).  Off when sel_record == NULL. */
+    const double* sel_X;    /* [rows][sel_ldx] feature rows, sel_xnorm their squared norms */
+    const double* sel_xnorm;
+    int sel_ldx;
+    const double* sel_V;    /* [m][sel_ldv] whitened block */
+    int64_t sel_ldv;
+    int sel_m, sel_ldw;
+    int sel_rank;
+    double* sel_record;     /* scratch: ITAL_REC_HEADER + ldx + ldw + kmax doubles */
+    int64_t* sel_ret;       /* [kmax + 1] as ital_select_fused */
+    double* sel_parts;      /* scratch: 3 doubles per block of the step's scoring launches (t = 1: n_cand / 256, t = 2:
+                               n_cand / 32, t >= 3: n_cand / 256 + one per slab, rounded up) */
+    int64_t sel_parts_len;  /* doubles in sel_parts */
+    unsigned int* sel_counter; /* one zero-initialised word; left at zero by every call */
 } ital_score_desc;
 
 /* Scores every live candidate position: mi[p] = MI(batch + candidate p).
@@ -199,6 +216,33 @@ int ital_score_step(const ital_score_desc* d, hipStream_t stream);
 
 /* Doubles of workspace that let ital_score_step(t >= 3) handle n_cand candidates in one slab (0 for t < 3). */
 int64_t ital_score_workspace(int t, int64_t n_cand);
+
+/* One whole round of the one-rank path -- fetch_unlabelled(k), reference ital/ital.py:98-134 -- enqueued by ONE call:
+ * candidate-list upkeep, then for t = 1 .. k ital_score_step (ending with the selection inside its last launch: `step.sel_*`
+ * must be set) and, for t < k, the new member's cross-covariance column (ital_cross_cov_cols out of the batch state into
+ * C[t - 1]).  Nothing synchronises; the picks are ret[0 .. k), the status word ret[kmax].  At most 2^18 candidates. */
+typedef struct ital_round_desc {
+    int k;                          /* greedy steps */
+    ital_score_desc step;           /* the steps' descriptor; t, mi (with mi_keep), seed, jump, jumppat, vk, ev_* are filled in per step */
+    int seeds[ITAL_MAX_T + 1][6];   /* [t]: generator state before step t (t >= 3); the host advances its state by
+                                       n_alive(t) * (2 << t) * ital_mvn_draws_per_call(t) per step, n_alive(t) = n_cand - (t - 1) */
+    const long long* jump[ITAL_MAX_T + 1];      /* [t]: tables of ital_mvn_tables(t, ...) in device memory, t = 3 .. k */
+    const long long* jumppat[ITAL_MAX_T + 1];
+    const double* vk[ITAL_MAX_T + 1];
+    void* ev_start[ITAL_MAX_T + 1]; /* optional hipEvent_t pairs around the lattice sums of step t */
+    void* ev_stop[ITAL_MAX_T + 1];
+    int64_t n_rows;                 /* rows of X / V / C (the covariance columns span all of them) */
+    double var, length_scale;
+    double* mi_keep;                /* optional [k][n_cand]: the scores of every step are kept (written there instead of step.mi) */
+    /* candidate list upkeep before the first step: 0 none (cand / alive / ret[kmax] are ready); 1: alive[0 .. n_cand) = 1,
+     * ret[kmax] = 0; 2: additionally step.cand = the entries of cand_prev[0 .. n_prev) whose alive flag is still set (the
+     * previous round's list without its picks: reference retrieval_base.py:78-87 after an update with exactly that batch);
+     * the survivors must number step.n_cand, else status |= 8 */
+    int begin;
+    const int32_t* cand_prev;
+    int64_t n_prev;
+} ital_round_desc;
+int ital_fetch_round(const ital_round_desc* r, hipStream_t stream);
 
 /* Local arg-extreme over the live positions + selection record for the exchange between ranks.
  * mode 0: first maximum, NaN wins (np.argmax, reference ital/ital.py:130); mode 1: first minimum (np.argmin,

@@ -35,7 +35,17 @@ class ItalScoreDesc(ctypes.Structure):
                 ("pos_offset", c_int64), ("gpos", c_void_p), ("batch", ItalBatch), ("noise", c_double), ("eps", c_double),
                 ("label_mode", c_int), ("mi", c_void_p), ("seed", c_int * 6), ("jump", c_void_p), ("jumppat", c_void_p),
                 ("vk", c_void_p), ("status", c_void_p), ("work", c_void_p), ("work_doubles", c_int64), ("ev_start", c_void_p),
-                ("ev_stop", c_void_p)]
+                ("ev_stop", c_void_p), ("sel_X", c_void_p), ("sel_xnorm", c_void_p), ("sel_ldx", c_int), ("sel_V", c_void_p),
+                ("sel_ldv", c_int64), ("sel_m", c_int), ("sel_ldw", c_int), ("sel_rank", c_int), ("sel_record", c_void_p),
+                ("sel_ret", c_void_p), ("sel_parts", c_void_p), ("sel_parts_len", c_int64), ("sel_counter", c_void_p)]
+
+
+class ItalRoundDesc(ctypes.Structure):
+    _fields_ = [("k", c_int), ("step", ItalScoreDesc), ("seeds", (c_int * 6) * (ITAL_MAX_T + 1)),
+                ("jump", c_void_p * (ITAL_MAX_T + 1)), ("jumppat", c_void_p * (ITAL_MAX_T + 1)),
+                ("vk", c_void_p * (ITAL_MAX_T + 1)), ("ev_start", c_void_p * (ITAL_MAX_T + 1)),
+                ("ev_stop", c_void_p * (ITAL_MAX_T + 1)), ("n_rows", c_int64), ("var", c_double), ("length_scale", c_double),
+                ("mi_keep", c_void_p), ("begin", c_int), ("cand_prev", c_void_p), ("n_prev", c_int64)]
 
 
 class ItalGscoreDesc(ctypes.Structure):
@@ -88,6 +98,7 @@ SIGNATURES = {
     "ital_topk_workspace": (c_int64, []),
     "ital_score_step": (c_int, [ctypes.POINTER(ItalScoreDesc), c_void_p]),
     "ital_score_workspace": (c_int64, [c_int, c_int64]),
+    "ital_fetch_round": (c_int, [ctypes.POINTER(ItalRoundDesc), c_void_p]),
     "ital_cov_block": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_int, c_void_p, c_int64,
                                c_void_p, c_int64, c_int, c_double, c_double, c_void_p, c_int64, c_void_p]),
     "ital_cov_abs_rowsum": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_int, c_void_p, c_int64,

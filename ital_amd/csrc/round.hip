@@ -1,0 +1,104 @@
+// One fetch_unlabelled(k) round of the one-rank path as ONE call below the C ABI (reference ital/ital.py:98-134): candidate
+// list upkeep, then per greedy step the scorer (ending with the selection inside its last launch) and the new member's
+// cross-covariance column.  Nothing here computes anything new -- it is ital_score_step / ital_cross_cov_cols enqueued in a
+// C loop: at 9298 candidates the first two greedy steps are 10 - 25 us kernels and a Python host needs 10 - 17 us per launch
+// (descriptor marshalling through ctypes), the GPU idles in between; from C the launches are ~3 us apart.
+//
+// Candidate list upkeep on the device: between two rounds of the retrieval loop the candidate list loses exactly the
+// samples of the last batch (reference retrieval_base.py:78-87: ascending indices without the seen ones).  Instead of a new
+// list from the host every round (build, pageable upload -- a synchronising copy -- and two fill launches) one single-
+// workgroup launch compacts the previous list by its alive flags, re-arms the flags and clears the round's status slot.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "ital_hip.h"
+#include "ital_internal.h"
+
+namespace ital {
+
+// mode 0: alive[0 .. n) = 1, ret[kmax] = 0.   mode 1: additionally cand_new = cand_prev[alive_prev != 0] (order kept),
+// n = number of survivors the host expects; a different count raises status bit 8.
+__global__ __launch_bounds__(1024) void fetch_begin_kernel(int mode, const int32_t* __restrict__ cand_prev, int64_t n_prev,
+                                                           int32_t* __restrict__ cand_new, uint8_t* __restrict__ alive,
+                                                           int64_t n, int64_t* __restrict__ ret, int kmax,
+                                                           int* __restrict__ status) {
+    __shared__ int wave_tot[16];
+    __shared__ int s_total;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (mode == 1) {
+        const int64_t chunk = (n_prev + blockDim.x - 1) / blockDim.x;
+        const int64_t lo = (int64_t)tid * chunk, hi = lo + chunk < n_prev ? lo + chunk : n_prev;
+        int cnt = 0;
+        for (int64_t p = lo; p < hi; p++) cnt += alive[p] != 0;
+        // exclusive prefix of the per-thread counts: wave scan, then the wave totals
+        int incl = cnt;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const int o = __shfl_up(incl, off, 64);
+            if (lane >= off) incl += o;
+        }
+        if (lane == 63) wave_tot[wave] = incl;
+        __syncthreads();
+        int base = 0;
+        for (int w = 0; w < wave; w++) base += wave_tot[w];
+        if (tid == 0) {
+            int tot = 0;
+            for (int w = 0; w < (int)(blockDim.x >> 6); w++) tot += wave_tot[w];
+            s_total = tot;
+        }
+        int64_t at = base + incl - cnt;
+        for (int64_t p = lo; p < hi; p++)
+            if (alive[p] != 0) cand_new[at++] = cand_prev[p];
+        __syncthreads();                      // all flags read before any is re-armed
+        if (tid == 0 && s_total != n) atomicOr(status, 8);
+    }
+    for (int64_t p = tid; p < n; p += blockDim.x) alive[p] = 1;
+    if (tid == 0) ret[kmax] = 0;
+}
+
+}  // namespace ital
+
+using namespace ital;
+
+extern "C" int ital_fetch_round(const ital_round_desc* r, hipStream_t stream) {
+    if (!r) return ital_fail(-22, "ital_fetch_round: null descriptor");
+    const ital_score_desc& tpl = r->step;
+    if (r->k < 1 || r->k > ITAL_MAX_T || r->k > tpl.batch.kmax) return ital_fail(-22, "ital_fetch_round: k outside 1..min(ITAL_MAX_T, kmax)");
+    if (tpl.n_cand < r->k) return ital_fail(-22, "ital_fetch_round: fewer candidates than greedy steps");
+    if (tpl.n_cand > (1 << 18)) return ital_fail(-22, "ital_fetch_round: more than 2^18 candidates (use the per-step entry points)");
+    if (!tpl.sel_record || !tpl.sel_ret) return ital_fail(-22, "ital_fetch_round: the round selects inside the scorer: sel_* missing");
+    if (r->begin < 0 || r->begin > 2) return ital_fail(-22, "ital_fetch_round: begin must be 0, 1 or 2");
+    if (r->begin == 2 && (!r->cand_prev || r->n_prev < tpl.n_cand || r->n_prev > (1 << 18) || r->cand_prev == tpl.cand))
+        return ital_fail(-22, "ital_fetch_round: begin = 2 needs the previous list in a buffer of its own");
+    if (r->begin) {
+        ITAL_LAUNCH(fetch_begin_kernel, dim3(1), dim3(1024), 0, stream, r->begin - 1, r->cand_prev, r->n_prev,
+                    const_cast<int32_t*>(tpl.cand), const_cast<uint8_t*>(tpl.alive), tpl.n_cand, tpl.sel_ret, tpl.batch.kmax,
+                    tpl.status);
+        const int rc = ital_check_launch("ital_fetch_round(begin)");
+        if (rc) return rc;
+    }
+    for (int t = 1; t <= r->k; t++) {
+        ital_score_desc d = tpl;
+        d.t = t;
+        if (r->mi_keep) d.mi = r->mi_keep + (int64_t)(t - 1) * tpl.n_cand;
+        if (t >= 3) {
+            d.jump = r->jump[t];
+            d.jumppat = r->jumppat[t];
+            d.vk = r->vk[t];
+            for (int j = 0; j < 6; j++) d.seed[j] = r->seeds[t][j];
+        }
+        d.ev_start = r->ev_start[t];
+        d.ev_stop = r->ev_stop[t];
+        int rc = ital_score_step(&d, stream);
+        if (rc) return rc;
+        if (t < r->k) {
+            const int slot = t - 1;
+            rc = ital_cross_cov_cols(tpl.sel_X, tpl.sel_xnorm, r->n_rows, tpl.sel_ldx, tpl.batch.XB + (int64_t)slot * tpl.batch.ldx,
+                                     tpl.batch.XBn + slot, 1, tpl.batch.VB + (int64_t)slot * tpl.batch.ldw, tpl.batch.ldw,
+                                     tpl.sel_V, tpl.sel_ldv, tpl.sel_m, r->var, r->length_scale,
+                                     const_cast<double*>(tpl.C) + (int64_t)slot * tpl.ldc, tpl.ldc, stream);
+            if (rc) return rc;
+        }
+    }
+    return 0;
+}

@@ -26,6 +26,7 @@
 #include "ital_hip.h"
 #include "ital_internal.h"
 #include "qmc_common.h"
+#include "select_common.h"
 
 #ifndef ITAL_QMC_HOTK
 #define ITAL_QMC_HOTK 1   // exp / log coefficients of the lattice loop as vector-register operands (device_math.h HotK)
@@ -74,6 +75,7 @@ struct ScoreArgs {
     const long long* jumppat;   // [2^t][18]: transition matrices for 2r calls (the prior call of sign pattern r)
     const double* vk;       // [t-1] Korobov generators
     int* status;
+    SelectTail sel;         // optional: the step's selection as the tail of its last scoring launch (sel.enabled)
 };
 
 __device__ __forceinline__ double log_eps(double p, double eps) { return log(p + eps); }
@@ -91,28 +93,34 @@ __device__ __forceinline__ void mi_accumulate(double& mi, double pr, double pu, 
 
 // ------------------------------------------------------------------------------------------------ t = 1
 __global__ __launch_bounds__(256) void score_t1_kernel(ScoreArgs a) {
-    int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (p >= a.n_cand) return;
-    if (!a.alive[p]) return;
-    const int row = a.cand[p];
-    const double mu = a.mu[row];
-    const double su = a.s2[row];               // unclamped: what the simulated update sees (gp.py:334)
-    const double sc = fmax(0.0, su);           // clamped: predict_stored(cov_mode='diag') (gp.py:229, ital.py:558)
-    const double p_irr = norm_cdf0(mu, sqrt(sc));
-    const double w = 1.0 / (su + a.noise);
-    const double g = su * w;
-    const double s_upd = a.noise * g;
+    const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const bool valid = p < a.n_cand && a.alive[p];
     double mi = 0.0;
+    if (valid) {
+        const int row = a.cand[p];
+        const double mu = a.mu[row];
+        const double su = a.s2[row];               // unclamped: what the simulated update sees (gp.py:334)
+        const double sc = fmax(0.0, su);           // clamped: predict_stored(cov_mode='diag') (gp.py:229, ital.py:558)
+        const double p_irr = norm_cdf0(mu, sqrt(sc));
+        const double w = 1.0 / (su + a.noise);
+        const double g = su * w;
+        const double s_upd = a.noise * g;
 #pragma unroll
-    for (int r = 0; r < 2; r++) {
-        const double f = r ? 1.0 : -1.0;
-        const double mu_upd = mu + g * (f - mu);
-        const double q = norm_cdf0(mu_upd, sqrt(s_upd));
-        const double pr = r ? 1.0 - p_irr : p_irr;
-        const double pu = r ? 1.0 - q : q;
-        mi_accumulate(mi, pr, pu, a.eps, a.label_mode);
+        for (int r = 0; r < 2; r++) {
+            const double f = r ? 1.0 : -1.0;
+            const double mu_upd = mu + g * (f - mu);
+            const double q = norm_cdf0(mu_upd, sqrt(s_upd));
+            const double pr = r ? 1.0 - p_irr : p_irr;
+            const double pu = r ? 1.0 - q : q;
+            mi_accumulate(mi, pr, pu, a.eps, a.label_mode);
+        }
+        a.mi[p] = mi;
     }
-    a.mi[p] = mi;
+    if (a.sel.enabled) {
+        Best c = {mi, valid ? (a.gpos ? a.gpos[p] : a.pos_offset + p) : -1, p};
+        c = block_best(c, 0);
+        select_tail(a.sel, c, blockIdx.x, gridDim.x, true, gridDim.x);
+    }
 }
 
 // ------------------------------------------------------------------------------------------------ t = 2
@@ -157,6 +165,7 @@ __global__ __launch_bounds__(256) void score_t2_kernel(ScoreArgs a) {
     }
     vals[updated ? 1 : 0][pair] = val;
     __syncthreads();
+    Best c = {0.0, -1, 0};
     if (threadIdx.x < 32) {
         const int64_t pc = (int64_t)blockIdx.x * 32 + threadIdx.x;
         if (pc < a.n_cand && a.alive[pc]) {
@@ -164,7 +173,14 @@ __global__ __launch_bounds__(256) void score_t2_kernel(ScoreArgs a) {
 #pragma unroll
             for (int q = 0; q < 4; q++) mi_accumulate(mi, vals[0][4 * threadIdx.x + q], vals[1][4 * threadIdx.x + q], a.eps, a.label_mode);
             a.mi[pc] = mi;
+            c.val = mi;
+            c.pos = a.gpos ? a.gpos[pc] : a.pos_offset + pc;
+            c.loc = pc;
         }
+    }
+    if (a.sel.enabled) {
+        c = block_best(c, 0);
+        select_tail(a.sel, c, blockIdx.x, gridDim.x, true, gridDim.x);
     }
 }
 
@@ -517,24 +533,36 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(ITAL_QMC_WA
     }
 }
 
-// mi[p] from the terms of the 2^T patterns, in pattern order (the reference's loop, ital.py:207-222).
+// mi[p] from the terms of the 2^T patterns, in pattern order (the reference's loop, ital.py:207-222); with `sel` the
+// blocks also leave their best candidate behind and the step's last block selects (select_tail).
 __global__ __launch_bounds__(256) void qmc_combine_kernel(const double* __restrict__ terms, const uint8_t* __restrict__ alive,
                                                           int64_t slab_lo, int64_t slab_n, int npat, int label_mode,
-                                                          double* __restrict__ mi) {
+                                                          double* __restrict__ mi, int64_t pos_offset,
+                                                          const int64_t* __restrict__ gpos, SelectTail sel, int part0,
+                                                          int nparts, int finishing) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= slab_n || !alive[slab_lo + i]) return;
+    const bool valid = i < slab_n && alive[slab_lo + i];
     double s = 0.0;
-    for (int r = 0; r < npat; r++) {
-        const double cur = terms[i * npat + r];
-        if (label_mode == 1) { if (cur > s) s = cur; }
-        else if (label_mode == 2) { if (s == 0 || cur < s) s = cur; }
-        else s += cur;
+    if (valid) {
+        for (int r = 0; r < npat; r++) {
+            const double cur = terms[i * npat + r];
+            if (label_mode == 1) { if (cur > s) s = cur; }
+            else if (label_mode == 2) { if (s == 0 || cur < s) s = cur; }
+            else s += cur;
+        }
+        mi[slab_lo + i] = s;
     }
-    mi[slab_lo + i] = s;
+    if (sel.enabled) {
+        const int64_t p = slab_lo + i;
+        Best c = {s, valid ? (gpos ? gpos[p] : pos_offset + p) : -1, p};
+        c = block_best(c, 0);
+        select_tail(sel, c, part0 + blockIdx.x, nparts, finishing != 0, gridDim.x);
+    }
 }
 
 template <int T>
-static int launch_qmc(const ScoreArgs& a, double* work, int64_t work_doubles, hipEvent_t ev0, hipEvent_t ev1, hipStream_t stream) {
+static int launch_qmc(const ScoreArgs& a, double* work, int64_t work_doubles, int64_t sel_parts_len, hipEvent_t ev0, hipEvent_t ev1,
+                      hipStream_t stream) {
     using Q = Qmc<T>;
     int64_t slab = work_doubles / Q::CAND_DOUBLES;
     if (slab < 1) return ital_fail(-12, "ital_score_step: workspace smaller than one candidate (see ital_score_workspace)");
@@ -550,6 +578,10 @@ static int launch_qmc(const ScoreArgs& a, double* work, int64_t work_doubles, hi
     double* recs = work;
     double* terms = recs + slab * Q::NPAT * Q::REC;
     int* seeds = reinterpret_cast<int*>(terms + slab * Q::NPAT);
+    int nparts = 0, part0 = 0;
+    for (int64_t lo = 0; lo < a.n_cand; lo += slab) nparts += (int)(((a.n_cand - lo < slab ? a.n_cand - lo : slab) + 255) / 256);
+    if (a.sel.enabled && 3 * (int64_t)nparts > sel_parts_len)
+        return ital_fail(-22, "ital_score_step: sel_parts too small for the blocks of this step");
     for (int64_t lo = 0; lo < a.n_cand; lo += slab) {
         const int64_t n = a.n_cand - lo < slab ? a.n_cand - lo : slab;
         ITAL_LAUNCH(qmc_seed_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, a, Q::NCALLS, lo, n, seeds);
@@ -560,7 +592,8 @@ static int launch_qmc(const ScoreArgs& a, double* work, int64_t work_doubles, hi
                            n, recs, a.vk, a.eps, a.label_mode, terms);
         if (ev1 && lo + n >= a.n_cand) (void)hipEventRecord(ev1, stream);
         ITAL_LAUNCH(qmc_combine_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, terms, a.alive, lo, n,
-                           Q::NPAT, a.label_mode, a.mi);
+                    Q::NPAT, a.label_mode, a.mi, a.pos_offset, a.gpos, a.sel, part0, nparts, lo + n >= a.n_cand ? 1 : 0);
+        part0 += (int)((n + 255) / 256);
         int rc = ital_check_launch("ital_score_step(qmc)");
         if (rc) return rc;
     }
@@ -602,24 +635,45 @@ extern "C" int ital_score_step(const ital_score_desc* d, hipStream_t stream) {
     a.noise = d->noise; a.eps = d->eps; a.label_mode = d->label_mode; a.mi = d->mi; a.jump = d->jump;
     a.jumppat = d->jumppat; a.vk = d->vk; a.status = d->status;
     for (int i = 0; i < 6; i++) a.seed[i] = d->seed[i];
+    if (d->sel_record) {
+        // the selection of this step as the tail of its last scoring launch (what ital_select_fused does separately)
+        if (!d->sel_ret || !d->sel_parts || !d->sel_counter || !d->sel_X || !d->sel_xnorm || (d->sel_m > 0 && !d->sel_V))
+            return ital_fail(-22, "ital_score_step: fused selection needs sel_ret, sel_parts, sel_counter, sel_X, sel_xnorm, sel_V");
+        if (d->sel_m > d->sel_ldw || d->sel_ldx != d->batch.ldx || d->sel_ldw != d->batch.ldw)
+            return ital_fail(-22, "ital_score_step: fused selection: batch layout mismatch");
+        a.sel.rec = {d->cand, d->pos_offset, d->gpos, d->row_offset, d->sel_rank, 0, 0, d->mu, d->s2, d->sel_X, d->sel_xnorm,
+                     d->sel_ldx, d->sel_V, d->sel_ldv, d->sel_m, d->sel_ldw, d->C, d->ldc, d->t - 1, d->batch.kmax, nullptr,
+                     d->sel_record, d->status};
+        a.sel.slot = d->t - 1;
+        a.sel.b = d->batch;
+        a.sel.alive = const_cast<uint8_t*>(d->alive);
+        a.sel.ret = d->sel_ret;
+        a.sel.parts = d->sel_parts;
+        a.sel.counter = d->sel_counter;
+        a.sel.enabled = 1;
+    }
     if (d->t == 1) {
-        ITAL_LAUNCH(score_t1_kernel, dim3((unsigned)((d->n_cand + 255) / 256)), dim3(256), 0, stream, a);
+        const int64_t blocks = (d->n_cand + 255) / 256;
+        if (a.sel.enabled && 3 * blocks > d->sel_parts_len) return ital_fail(-22, "ital_score_step: sel_parts too small (t = 1)");
+        ITAL_LAUNCH(score_t1_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, a);
         return ital_check_launch("ital_score_step(t=1)");
     }
     if (d->t == 2) {
-        ITAL_LAUNCH(score_t2_kernel, dim3((unsigned)((d->n_cand + 31) / 32)), dim3(256), 0, stream, a);
+        const int64_t blocks = (d->n_cand + 31) / 32;
+        if (a.sel.enabled && 3 * blocks > d->sel_parts_len) return ital_fail(-22, "ital_score_step: sel_parts too small (t = 2)");
+        ITAL_LAUNCH(score_t2_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, a);
         return ital_check_launch("ital_score_step(t=2)");
     }
     if (!d->jump || !d->jumppat || !d->vk) return ital_fail(-22, "ital_score_step: jump tables / generators missing for t >= 3");
     if (!d->work) return ital_fail(-22, "ital_score_step: workspace missing for t >= 3 (see ital_score_workspace)");
     hipEvent_t ev0 = static_cast<hipEvent_t>(d->ev_start), ev1 = static_cast<hipEvent_t>(d->ev_stop);
     switch (d->t) {
-        case 3: return launch_qmc<3>(a, d->work, d->work_doubles, ev0, ev1, stream);
-        case 4: return launch_qmc<4>(a, d->work, d->work_doubles, ev0, ev1, stream);
-        case 5: return launch_qmc<5>(a, d->work, d->work_doubles, ev0, ev1, stream);
-        case 6: return launch_qmc<6>(a, d->work, d->work_doubles, ev0, ev1, stream);
-        case 7: return launch_qmc<7>(a, d->work, d->work_doubles, ev0, ev1, stream);
-        case 8: return launch_qmc<8>(a, d->work, d->work_doubles, ev0, ev1, stream);
+        case 3: return launch_qmc<3>(a, d->work, d->work_doubles, d->sel_parts_len, ev0, ev1, stream);
+        case 4: return launch_qmc<4>(a, d->work, d->work_doubles, d->sel_parts_len, ev0, ev1, stream);
+        case 5: return launch_qmc<5>(a, d->work, d->work_doubles, d->sel_parts_len, ev0, ev1, stream);
+        case 6: return launch_qmc<6>(a, d->work, d->work_doubles, d->sel_parts_len, ev0, ev1, stream);
+        case 7: return launch_qmc<7>(a, d->work, d->work_doubles, d->sel_parts_len, ev0, ev1, stream);
+        case 8: return launch_qmc<8>(a, d->work, d->work_doubles, d->sel_parts_len, ev0, ev1, stream);
     }
     return ital_fail(-22, "ital_score_step: unsupported batch dimension");
 }

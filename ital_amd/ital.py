@@ -68,6 +68,9 @@ class ITAL(ActiveRetrievalBase):
         self.event_pool = []     # pre-created timing events (bench.py)
         self.profile = None      # list to receive (stage, t, size, start_event, end_event) per launch (bench.py)
         self._fetch_bufs = None
+        self.round_call = True        # one rank, up to 2^18 candidates: a whole round through ital_fetch_round (False: step by step from Python)
+        self._dev_list = None         # the candidate list the device holds: (buffers, host array, picks flagged dead)
+        self.select_in_scorer = True  # False: the selection of a greedy step always runs as a launch of its own (cross-check in tests)
         self.mc_walk = [0, 0, 0.0]   # Monte-Carlo pattern sampling: standard normals computed / skipped, host seconds
 
     # ------------------------------------------------------------------ helpers
@@ -252,7 +255,11 @@ class ITAL(ActiveRetrievalBase):
         gp = self.gp
         self._last_batch = None        # published only after the round's final successful download (update() pairs its
         if self._needs_generic():      # sample ids with rows of the batch buffers)
+            self._dev_list = None
             return self._fetch_generic(k, candidates)
+        if self.round_call and self.select_in_scorer and not gp.collective and k <= len(candidates) <= _FUSED_SELECT_MAX:
+            return self._select_round(k, candidates)
+        self._dev_list = None
         lib = _lib.lib()
         dev = gp.device
         with torch.cuda.device(dev):
@@ -298,13 +305,28 @@ class ITAL(ActiveRetrievalBase):
                         # several slabs: the pair spans first .. last lattice sum incl. the launches between them
                         slabs = -(-n_loc // max(work.numel() // int(lib.ital_score_workspace(t, 1)), 1))
                         self.profile.append(("qmc_main" if slabs == 1 else "qmc_slabs%d" % slabs, t, n_alive, k0, k1))
+                fused = not gp.collective and 0 < n_loc <= _FUSED_SELECT_MAX
+                if fused and self.select_in_scorer:
+                    # one rank, small problem: the scoring launch ends with the selection itself (the block that finishes
+                    # last selects) -- no selection launch
+                    parts = b.get("sel_parts")
+                    if parts is None or parts.numel() < 3 * (n_loc // 32 + 64):
+                        b["sel_parts"] = parts = torch.empty(3 * (n_loc // 32 + 64), dtype=torch.float64, device=dev)
+                        b["sel_counter"] = torch.zeros(1, dtype=torch.int32, device=dev)
+                    desc.sel_X, desc.sel_xnorm, desc.sel_ldx = _ptr(gp.Xd), _ptr(gp.xnorm), gp.ldx
+                    desc.sel_V, desc.sel_ldv, desc.sel_m, desc.sel_ldw, desc.sel_rank = _ptr(gp.V), gp.ldv, gp.m, gp.cap, gp.rank
+                    desc.sel_record, desc.sel_ret = _ptr(b["rec"]), _ptr(b["ret"])
+                    desc.sel_parts, desc.sel_parts_len, desc.sel_counter = _ptr(parts), parts.numel(), _ptr(b["sel_counter"])
+                    fused = None
                 ev0 = self._mark() if t < 3 else None
                 check(lib.ital_score_step(ctypes.byref(desc), st))
                 if t < 3:
                     self._mark("score", t, n_alive, ev0)
                 if self.keep_scores:
                     self.last_scores.append(mi.clone())
-                if not gp.collective and n_loc <= _FUSED_SELECT_MAX:
+                if fused is None:
+                    pass
+                elif fused:
                     check(lib.ital_select_fused(_ptr(mi), _ptr(cand_d), _ptr(alive), n_loc, pos_offset, _ptr(gpos_d), gp.row0,
                                                 gp.rank, 0, _ptr(gp.mu), _ptr(gp.s2), _ptr(gp.Xd), _ptr(gp.xnorm), gp.ldx,
                                                 _ptr(gp.V), gp.ldv, gp.m, gp.cap, _ptr(b["C"]), gp.ldv, t - 1, t - 1, b["batch"],
@@ -346,6 +368,109 @@ class ITAL(ActiveRetrievalBase):
         if status:
             gp.check_status(status)
         self._last_batch = (b, list(ret))
+        return [int(i) for i in ret]
+
+    def _select_round(self, k, candidates):
+        """The one-rank path of _select as ONE call below the C ABI (ital_fetch_round): candidate-list upkeep, k scoring
+        steps that end with their selection, k - 1 covariance columns -- enqueued from C (a Python host needs 10 - 17 us per
+        launch, the first greedy steps are shorter than that).  The candidate list stays on the device between rounds: when
+        the list is the previous one minus the previous batch (the retrieval loop: fetch, label the batch, fetch), it is
+        compacted there by its alive flags instead of being rebuilt and uploaded."""
+        lib = _lib.lib()
+        gp = self.gp
+        dev = gp.device
+        n = len(candidates)
+        with torch.cuda.device(dev):
+            b = self._buffers(k)
+            st = _stream()
+            # ---- candidate list: two device buffers (the compaction reads one, writes the other)
+            lists = b.get("cand_lists")
+            if lists is None or lists[0].numel() < n:
+                b["cand_lists"] = lists = [torch.empty(max(n, 1), dtype=torch.int32, device=dev) for _ in range(2)]
+                b["cand_cur"] = 0
+                self._dev_list = None
+            if b.get("alive") is None or b["alive"].numel() < n:
+                b["alive"] = torch.empty(n, dtype=torch.uint8, device=dev)
+                b["mi"] = torch.empty(n, dtype=torch.float64, device=dev)
+                self._dev_list = None
+            parts = b.get("sel_parts")
+            if parts is None or parts.numel() < 3 * (n // 32 + 64):
+                b["sel_parts"] = parts = torch.empty(3 * (n // 32 + 64), dtype=torch.float64, device=dev)
+                b["sel_counter"] = torch.zeros(1, dtype=torch.int32, device=dev)
+            dl = self._dev_list
+            uc = getattr(self, "_unseen_cache", None)
+            prev_n = 0
+            if (dl is not None and dl["b"] is b and uc is not None and candidates is uc["array"] and uc["parent"] is dl["host"]
+                    and len(uc["removed"]) == len(dl["picks"]) and set(uc["removed"].tolist()) == set(dl["picks"])):
+                begin, prev = 2, lists[b["cand_cur"]]        # the device holds the parent list with exactly those picks flagged
+                prev_n = len(dl["host"])
+                b["cand_cur"] ^= 1
+                cand_d = lists[b["cand_cur"]]
+            else:
+                begin, prev = 1, None
+                cand_d = lists[b["cand_cur"]]
+                cand_d[:n].copy_(torch.from_numpy(np.asarray(candidates, dtype=np.int64).astype(np.int32)))
+            self._dev_list = None                              # re-published after the round's successful download
+            alive, mi = b["alive"], b["mi"]
+            r = b.get("round_desc")
+            if r is None:
+                r = b["round_desc"] = _lib.ItalRoundDesc()
+            d = r.step
+            r.k, r.n_rows, r.var, r.length_scale = k, gp.n, float(self.var), float(self.length_scale)
+            r.begin, r.cand_prev, r.n_prev = begin, _ptr(prev), prev_n
+            d.n_cand = n
+            d.cand, d.alive, d.mu, d.s2 = _ptr(cand_d), _ptr(alive), _ptr(gp.mu), _ptr(gp.s2)
+            d.C, d.ldc, d.row_offset, d.pos_offset, d.gpos = _ptr(b["C"]), gp.ldv, gp.row0, 0, None
+            d.batch = b["batch"]
+            d.noise, d.eps, d.label_mode = float(self.noise), float(self.eps), _LABEL_MODES[self.label_estimation]
+            d.mi, d.status = _ptr(mi), _ptr(gp.status)
+            d.sel_X, d.sel_xnorm, d.sel_ldx = _ptr(gp.Xd), _ptr(gp.xnorm), gp.ldx
+            d.sel_V, d.sel_ldv, d.sel_m, d.sel_ldw, d.sel_rank = _ptr(gp.V), gp.ldv, gp.m, gp.cap, gp.rank
+            d.sel_record, d.sel_ret = _ptr(b["rec"]), _ptr(b["ret"])
+            d.sel_parts, d.sel_parts_len, d.sel_counter = _ptr(parts), parts.numel(), _ptr(b["sel_counter"])
+            keep = None
+            if self.keep_scores:
+                keep = torch.zeros((k, n), dtype=torch.float64, device=dev)
+            r.mi_keep = _ptr(keep)
+            stream = mvn_stream.GLOBAL
+            saved_stream = (stream.state, stream.draws)
+            if k >= 3:
+                work = self._qmc_workspace(b, k, n)
+                d.work, d.work_doubles = _ptr(work), work.numel()
+            n_alive = n
+            for t in range(1, k + 1):
+                r.ev_start[t] = r.ev_stop[t] = None
+                if t >= 3:
+                    if t not in b["jump"]:
+                        b["jump"][t] = torch.from_numpy(mvn_stream.jump_table(t, ITAL_JUMP_BITS)).to(dev)
+                        b["jumppat"][t] = torch.from_numpy(mvn_stream.jump_pattern_table(t)).to(dev)
+                        b["vk"][t] = torch.from_numpy(mvn_stream.korobov_vk(t)).to(dev)
+                    r.jump[t], r.jumppat[t], r.vk[t] = _ptr(b["jump"][t]), _ptr(b["jumppat"][t]), _ptr(b["vk"][t])
+                    for j in range(6):
+                        r.seeds[t][j] = stream.state[j]
+                    if self.profile is not None:
+                        k0, k1 = self._event(), self._event()
+                        r.ev_start[t], r.ev_stop[t] = k0.cuda_event, k1.cuda_event
+                        slabs = -(-n // max(work.numel() // int(lib.ital_score_workspace(t, 1)), 1))
+                        self.profile.append(("qmc_main" if slabs == 1 else "qmc_slabs%d" % slabs, t, n_alive, k0, k1))
+                # the reference's serial loop consumes this many uniforms of mvndst's stream at step t
+                stream.advance(n_alive * (2 << t) * mvn_stream.draws_per_call(t))
+                n_alive -= 1
+            check(lib.ital_fetch_round(ctypes.byref(r), st))
+            host = b["ret"].cpu().tolist()     # the only synchronisation of the round: the picks and the status word
+            ret, status = host[:k], host[b["kmax"]]
+            self.last_scores = [keep[t, :n] for t in range(k)] if keep is not None else []
+            if status & 8:
+                raise RuntimeError("ital_amd: the candidate list kept on the device lost track of the host's (internal error)")
+            if status & 6:
+                # see _select: duplicates inside the batch / a simulated update that does not pin the labels
+                gp.status.bitwise_and_(~6)
+                stream.state, stream.draws = saved_stream
+                return self._fetch_generic(k, candidates)
+        if status:
+            gp.check_status(status)
+        self._last_batch = (b, list(ret))
+        self._dev_list = dict(b=b, host=candidates, picks=[int(i) for i in ret])
         return [int(i) for i in ret]
 
     # ------------------------------------------------------------------ general scorer (noisy users, estimation subset)

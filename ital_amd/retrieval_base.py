@@ -41,6 +41,7 @@ class ActiveRetrievalBase(object):
         self.irrelevant_ids = set()
         self.unnameable_ids = set()
         self._last_batch = None
+        self._unseen_cache = None
         self.gp.reset()
         if len(self.queries) > 0:
             n = len(self.data)
@@ -71,12 +72,42 @@ class ActiveRetrievalBase(object):
         return self._unseen_array().tolist()
 
     def _unseen_array(self):
+        """Ascending indices of the samples without feedback (int64 array; treat as read-only).  The array of the previous
+        call is kept: after an update() that only added feedback it is shortened by the newly seen samples instead of being
+        rebuilt from the three sets (N-sized work on the critical path of every round otherwise)."""
+        sizes = (len(self.relevant_ids), len(self.irrelevant_ids), len(self.unnameable_ids))
+        c = getattr(self, "_unseen_cache", None)
+        if c is not None and c["sizes"] == sizes:
+            return c["array"]
         seen = self.relevant_ids | self.irrelevant_ids | self.unnameable_ids
         if not seen:
-            return np.arange(len(self.data), dtype=np.int64)
-        mask = np.ones(len(self.data), dtype=bool)
-        mask[np.fromiter(seen, dtype=np.int64, count=len(seen))] = False
-        return np.flatnonzero(mask)
+            arr = np.arange(len(self.data), dtype=np.int64)
+        else:
+            mask = np.ones(len(self.data), dtype=bool)
+            mask[np.fromiter(seen, dtype=np.int64, count=len(seen))] = False
+            arr = np.flatnonzero(mask)
+        self._unseen_cache = dict(sizes=sizes, array=arr, parent=None, removed=None)
+        return arr
+
+    def _unseen_after(self, new_ids, sizes_before):
+        """Called by update() once the id sets hold `new_ids` (samples that had no feedback before): the cached array minus
+        them, remembering what it was derived from (the device keeps its candidate list the same way, ital.py)."""
+        c = getattr(self, "_unseen_cache", None)
+        if c is None or c["sizes"] != sizes_before:
+            self._unseen_cache = None
+            return
+        arr = c["array"]
+        ids = np.asarray(sorted(set(int(i) for i in new_ids)), dtype=np.int64)
+        if len(ids):
+            at = np.searchsorted(arr, ids)
+            if np.any(at >= len(arr)) or np.any(arr[np.minimum(at, len(arr) - 1)] != ids):
+                self._unseen_cache = None          # feedback for something that was not a candidate: rebuild next time
+                return
+            new = np.delete(arr, at)
+        else:
+            new = arr
+        sizes = (len(self.relevant_ids), len(self.irrelevant_ids), len(self.unnameable_ids))
+        self._unseen_cache = dict(sizes=sizes, array=new, parent=arr, removed=ids)
 
     def fetch_unlabelled(self, k):
         raise NotImplementedError('fetch_unlabelled() has to be implemented in a derived class.')
@@ -84,6 +115,7 @@ class ActiveRetrievalBase(object):
     def update(self, feedback):
         """reference retrieval_base.py:105-126"""
         rel, irr, unnameable = self.partition_feedback(feedback)
+        sizes_before = (len(self.relevant_ids), len(self.irrelevant_ids), len(self.unnameable_ids))
         if len(rel) + len(irr) > 0:
             self.gp.update(rel + irr, np.concatenate((np.ones(len(rel)), -1 * np.ones(len(irr)))),
                            row_cache=self._batch_rows())
@@ -91,7 +123,9 @@ class ActiveRetrievalBase(object):
             self.relevant_ids.update(rel)
             self.irrelevant_ids.update(irr)
             self.rounds += 1
+        new_unnameable = [i for i in unnameable if i not in self.unnameable_ids]
         self.unnameable_ids.update(unnameable)
+        self._unseen_after(rel + irr + new_unnameable, sizes_before)
 
     def _batch_rows(self):
         """Feature rows of the last fetched batch as kept (replicated) in the device batch state, or None."""

@@ -57,6 +57,84 @@ def test_scores_do_not_depend_on_the_workspace_slabs(dev, n, k):
             np.testing.assert_array_equal(a[live], b[live])
 
 
+@pytest.mark.parametrize("n,k,work_bytes", [(2500, 4, 1 << 30), (300, 6, 1 << 30), (3300, 4, 1 << 20), (33, 3, 1 << 30)])
+def test_selection_inside_the_scoring_launch_equals_the_separate_launch(dev, n, k, work_bytes):
+    """One rank, small problems: the last block of a step's scoring launch selects (select_tail) instead of a launch of
+    ital_select_fused.  Same picks, same batch state, same alive flags -- also with several slabs and with ties."""
+    from ital_amd import ITAL, mvn_stream
+    rng = np.random.default_rng(4)
+    X = rng.random((n, 10))
+    X[n // 2] = X[n // 3]                      # an exact twin: equal scores, the lower list position has to win
+    out = []
+    for mode in ("round", "steps", "separate"):
+        # round: the whole round through ital_fetch_round (candidate list kept / compacted on the device); steps: the same
+        # kernels launched step by step from Python; separate: the selection as a launch of its own (ital_select_fused)
+        mvn_stream.GLOBAL.reset()
+        L = ITAL(X, length_scale=0.9, device=dev)
+        L.round_call = mode == "round"
+        L.select_in_scorer = mode != "separate"
+        L.qmc_work_bytes = work_bytes
+        L.keep_scores = True
+        L.update({0: 1, 1: -1})
+        picks, live_scores = [], []
+        for rnd in range(3):
+            unseen = np.asarray(L._unseen_array())
+            ret = L.fetch_unlabelled(k)
+            picks.append(ret)
+            b = L._fetch_bufs
+            state = {q: b[q].cpu().numpy().copy() for q in ("bidx", "bgpos", "bsort", "bmu", "sig", "XB", "XBn", "VB", "ret")}
+            state["alive"] = b["alive"][: len(unseen)].cpu().numpy().copy()
+            for t, s_ in enumerate(L.last_scores):          # scores of the positions still alive at step t
+                s_ = s_.cpu().numpy()[: len(unseen)].copy()
+                s_[np.searchsorted(unseen, ret[:t])] = 0.0
+                live_scores.append(s_)
+            L.update({i: 1.0 if X[i, 0] > 0.5 else -1.0 for i in ret})
+        assert (L._dev_list is not None) == (mode == "round")
+        out.append((picks, state, mvn_stream.GLOBAL.draws, live_scores))
+    for other in out[1:]:
+        assert out[0][0] == other[0] and out[0][2] == other[2]
+        for key, a in out[0][1].items():
+            np.testing.assert_array_equal(a, other[1][key], err_msg=key)
+        for x, y in zip(out[0][3], other[3]):
+            np.testing.assert_array_equal(x, y)
+
+
+def test_device_candidate_list_follows_arbitrary_feedback(dev):
+    """The candidate list kept on the device between rounds is reused only when the host's list is the previous one minus
+    exactly the previous batch; partial feedback, feedback for other samples, unnameable feedback and reset() must fall back
+    to a fresh upload -- same picks as the step-by-step path either way."""
+    from ital_amd import ITAL, mvn_stream
+    rng = np.random.default_rng(6)
+    X = rng.random((400, 8))
+    lab = lambda i: 1.0 if X[i, 0] > 0.5 else -1.0   # noqa: E731
+    out = []
+    for rounds_in_c in (True, False):
+        mvn_stream.GLOBAL.reset()
+        L = ITAL(X, length_scale=0.8, device=dev)
+        L.round_call = rounds_in_c
+        L.update({5: 1, 9: -1})
+        log, reused = [], []
+        def fetch(k):                                  # noqa: E306
+            ret = L.fetch_unlabelled(k)
+            log.append(ret)
+            reused.append(bool(L._fetch_bufs["round_desc"].begin == 2) if rounds_in_c else None)
+            return ret
+        r = fetch(4); L.update({i: lab(i) for i in r})                   # the loop of the reference: whole batch labelled
+        r = fetch(4); L.update({i: lab(i) for i in r[:3]})               # one pick left without feedback: candidate again
+        r = fetch(3); L.update(dict({i: lab(i) for i in r}, **{17: 1}))  # feedback for a sample outside the batch
+        r = fetch(4); L.update({r[0]: 0, r[1]: lab(r[1]), r[2]: lab(r[2]), r[3]: 0})   # unnameable: seen, not trained on
+        r = fetch(4); L.update({i: lab(i) for i in r})
+        r = fetch(2); L.update({i: lab(i) for i in r})
+        r = fetch(4)
+        L.reset(); mvn_stream.GLOBAL.reset(); L.update({5: 1, 9: -1})
+        r = fetch(4); L.update({i: lab(i) for i in r})
+        r = fetch(4)
+        out.append((log, reused, mvn_stream.GLOBAL.draws))
+    assert out[0][0] == out[1][0] and out[0][2] == out[1][2]
+    #                 first  whole  partial  extra  unnameable  whole  whole  (no update)  reset  whole
+    assert out[0][1] == [False, True, False, False, True, True, True, False, True]
+
+
 def test_stream_position_is_a_function_of_the_work_done(dev):
     """Uniforms consumed by a fetch = sum over steps of live candidates * 2 * 2^t * draws per call."""
     from ital_amd import ITAL, mvn_stream

@@ -136,7 +136,7 @@ def test_c_abi_exports_every_declared_symbol():
     from ital_amd import _lib
     header = open(os.path.join(ROOT, "include", "ital_hip.h")).read()
     declared = set(re.findall(r"\b(ital_[a-z_0-9]+)\s*\(", header))
-    declared -= {"ital_batch", "ital_score_desc"}
+    declared -= {"ital_batch", "ital_score_desc", "ital_round_desc"}
     assert declared == set(_lib.SIGNATURES), (declared ^ set(_lib.SIGNATURES))
     lib = ctypes.CDLL(_lib.LIB_PATH)
     for name in declared:
@@ -226,10 +226,14 @@ def test_ctypes_structs_have_the_layout_of_the_header(tmp_path):
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     probes = {"ital_batch": (_lib.ItalBatch, ["kmax", "bidx", "VB"]),
               "ital_label_batch": (_lib.ItalLabelBatch, ["c", "slot", "y"]),
-              "ital_score_desc": (_lib.ItalScoreDesc, ["t", "gpos", "batch", "label_mode", "seed", "jumppat", "status", "work", "work_doubles", "ev_stop"]),
+              "ital_score_desc": (_lib.ItalScoreDesc, ["t", "gpos", "batch", "label_mode", "seed", "jumppat", "status", "work", "work_doubles", "ev_stop", "sel_ldx", "sel_ldv", "sel_rank", "sel_ret", "sel_parts_len",
+                                                       "sel_counter"]),
               "ital_gscore_desc": (_lib.ItalGscoreDesc, ["n_cand", "gpos", "nE", "ldE", "pick_pos", "label_prob", "clip_cov", "seed",
                                                          "draws_in", "dead_pos", "fb_samples", "draw_count", "status", "work_doubles", "pair_count"]),
-              "ital_mcmi_desc": (_lib.ItalMcmiDesc, ["t", "alive", "ld_cov", "batch", "ce"])}
+              "ital_mcmi_desc": (_lib.ItalMcmiDesc, ["t", "alive", "ld_cov", "batch", "ce"]),
+              "ital_round_desc": (_lib.ItalRoundDesc, ["k", "step", "seeds", "jump", "vk", "ev_stop", "n_rows", "length_scale",
+                                                       "mi_keep", "begin", "cand_prev", "n_prev"]),
+              "ital_np_legacy_state": (_lib.ItalNpLegacyState, ["key", "pos", "has_gauss", "gauss"])}
     lines = []
     for name, (_, fields) in probes.items():
         lines.append('printf("%s %%zu\\n", sizeof(%s));' % (name, name))
