@@ -73,6 +73,33 @@ typedef struct ital_label_batch {
 int ital_stage_labelled(const double* rows, int ldx, ital_label_batch lb, double* XT_dst, double* XTn_dst, double* y_dst,
                         hipStream_t stream);
 
+/* ital_stage_labelled + ital_chol_append + ital_whiten_append of one update() as ONE call (two launches: the rows are staged
+ * by the workgroup that appends to the factor).  rows[lb.slot[j]] = feature row of new sample j, lb.y[j] its label; XT, XTn,
+ * L, alpha, V, mu, s2 as in the three entry points; ybuf: 16 doubles of scratch.
+ * Replaces GaussianProcess.update + the predict_stored refresh, reference ital/gp.py:164-200, ital/retrieval_base.py:119-120. */
+typedef struct ital_append_desc {
+    const double* rows;
+    int ldx;
+    ital_label_batch lb;
+    const double* X;
+    const double* xnorm;
+    int64_t n;
+    double* XT;
+    double* XTn;
+    double* L;
+    int ldl;
+    double* alpha;
+    double* ybuf;
+    double* V;
+    int64_t ldv;
+    int m;
+    double var, length_scale, noise;
+    double* mu;
+    double* s2;
+    int* status;
+} ital_append_desc;
+int ital_gp_append(const ital_append_desc* a, hipStream_t stream);
+
 /* Appends the c whitened rows V[m..m+c-1][:] = L22^-1 (K[new,:] - L21 V) and refreshes the predictive mean
  * mu += V_new^T alpha_new and variance s2 -= colsum(V_new^2) of every row.  L21 = &L[m][0] (ld ldw),
  * L22 = &L[m][m] (ld ldw).  Replaces predict_stored after an update, reference ital/gp.py:203-232 as called from
@@ -115,6 +142,10 @@ int ital_mvn_seed(int state[6]);
 int ital_mvn_draws_per_call(int n);
 /* state <- state after n_draws more uniforms (3 x 3 matrix powers mod m1 / m2: O(log n_draws)). */
 int ital_mvn_advance(int state[6], int64_t n_draws);
+/* A whole round of k greedy steps with the perfect user (2 calls per sign pattern and live candidate): seeds[t] = the state
+ * before step t (t = 1 .. k; what ital_round_desc.seeds takes), state <- the state after the round (n_cand live
+ * candidates at step 1, one fewer per step). */
+int ital_mvn_round_seeds(int state[6], int64_t n_cand, int k, int seeds[][6]);
 /* Tables of ital_score_desc for batch dimension t (3 .. ITAL_MAX_T), to be copied to device memory by the caller; any of
  * the three may be NULL.  jump: [ITAL_JUMP_BITS][18], jumppat: [2^t][18], vk: [t - 1]. */
 int ital_mvn_tables(int t, long long* jump, long long* jumppat, double* vk);

@@ -29,6 +29,13 @@ class ItalLabelBatch(ctypes.Structure):
     _fields_ = [("c", c_int), ("slot", c_int * 16), ("y", c_double * 16)]
 
 
+class ItalAppendDesc(ctypes.Structure):
+    _fields_ = [("rows", c_void_p), ("ldx", c_int), ("lb", ItalLabelBatch), ("X", c_void_p), ("xnorm", c_void_p), ("n", c_int64),
+                ("XT", c_void_p), ("XTn", c_void_p), ("L", c_void_p), ("ldl", c_int), ("alpha", c_void_p), ("ybuf", c_void_p),
+                ("V", c_void_p), ("ldv", c_int64), ("m", c_int), ("var", c_double), ("length_scale", c_double),
+                ("noise", c_double), ("mu", c_void_p), ("s2", c_void_p), ("status", c_void_p)]
+
+
 class ItalScoreDesc(ctypes.Structure):
     _fields_ = [("t", c_int), ("n_cand", c_int64), ("cand", c_void_p), ("alive", c_void_p), ("mu", c_void_p),
                 ("s2", c_void_p), ("C", c_void_p), ("ldc", c_int64), ("row_offset", c_int64),
@@ -76,6 +83,7 @@ SIGNATURES = {
     "ital_mvn_seed": (c_int, [ctypes.POINTER(c_int)]),
     "ital_mvn_draws_per_call": (c_int, [c_int]),
     "ital_mvn_advance": (c_int, [ctypes.POINTER(c_int), c_int64]),
+    "ital_mvn_round_seeds": (c_int, [ctypes.POINTER(c_int), c_int64, c_int, c_void_p]),
     "ital_mvn_tables": (c_int, [c_int, c_void_p, c_void_p, c_void_p]),
     "ital_mvn_generic_tables": (c_int, [c_int, c_void_p, c_void_p]),
     "ital_np_legacy_normals": (c_int, [ctypes.POINTER(ItalNpLegacyState), c_int64, c_void_p, c_int64, c_int]),
@@ -92,6 +100,7 @@ SIGNATURES = {
                                    c_void_p, c_void_p, c_void_p, c_int64, c_int, c_double, c_double, c_void_p,
                                    c_void_p, c_void_p]),
     "ital_stage_labelled": (c_int, [c_void_p, c_int, ItalLabelBatch, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "ital_gp_append": (c_int, [ctypes.POINTER(ItalAppendDesc), c_void_p]),
     "ital_predict": (c_int, [c_void_p, c_int64, c_int, c_void_p, c_void_p, c_int, c_void_p, c_int, c_void_p,
                              c_double, c_double, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_void_p]),
     "ital_topk": (c_int, [c_void_p, c_int64, c_int64, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),

@@ -10,6 +10,7 @@
 #include <stdint.h>
 
 #include "device_math.h"
+#include "ital_hip.h"
 #include "ital_internal.h"
 
 namespace ital {
@@ -18,11 +19,21 @@ __device__ __forceinline__ double readlane_f64(double v, int l) {
     return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), l), __builtin_amdgcn_readlane(__double2loint(v), l));
 }
 
-__global__ __launch_bounds__(1024) void chol_append_kernel(const double* __restrict__ XT, const double* __restrict__ XTn,
+// Optional staging in front (ital_gp_append): the new samples' feature rows are picked out of a row matrix (the batch state
+// of the last fetch), their squared norms and the labels written -- what ital_stage_labelled does in a launch of its own.
+struct StageArgs {
+    const double* rows;      // nullptr: XT / XTn / ynew are ready
+    ital_label_batch lb;
+    double* XT_w;            // writable aliases of XT + m * ldx, XTn + m, ynew
+    double* XTn_w;
+    double* y_w;
+};
+
+__global__ __launch_bounds__(1024) void chol_append_kernel(const double* XT, const double* XTn,
                                                            int ldx, double* __restrict__ L, int ldl,
-                                                           double* __restrict__ alpha, const double* __restrict__ ynew,
+                                                           double* __restrict__ alpha, const double* ynew,
                                                            int m, int c, double var, double s, double noise,
-                                                           int* __restrict__ status) {
+                                                           int* __restrict__ status, StageArgs sa) {
     __shared__ double S[16][17];
     __shared__ double tvec[16];
     __shared__ double Lb[64][65];    // one 64 x 64 diagonal block of the existing factor at a time
@@ -30,6 +41,22 @@ __global__ __launch_bounds__(1024) void chol_append_kernel(const double* __restr
     const int j = threadIdx.x >> 6;  // new row handled by this wave
     const int g = m + j;             // its row in L
     double* Lg = L + (int64_t)g * ldl;
+    if (sa.rows) {
+        if (j < c) {
+            const double* src = sa.rows + (int64_t)sa.lb.slot[j] * ldx;
+            double* dst = sa.XT_w + (int64_t)j * ldx;
+            double acc = 0;
+            for (int k = lane; k < ldx; k += 64) {
+                const double v = src[k];
+                dst[k] = v;
+                acc += v * v;
+            }
+            acc = wave_sum(acc);
+            if (lane == 0) { sa.XTn_w[j] = acc; sa.y_w[j] = sa.lb.y[j]; }
+        }
+        __threadfence_block();
+        __syncthreads();
+    }
 #ifdef ITAL_CHOL_TIMING
     long long tstamp[6];
     tstamp[0] = __builtin_readcyclecounter();
@@ -187,6 +214,24 @@ extern "C" int ital_chol_append(const double* XT, const double* XTn, int ldx, do
     if (c < 1 || c > 16) return ital_fail(-22, "ital_chol_append: c must be in 1..16");
     if (m < 0 || m + c > ldl) return ital_fail(-22, "ital_chol_append: factor capacity exceeded");
     ITAL_LAUNCH(ital::chol_append_kernel, dim3(1), dim3(1024), 0, stream, XT, XTn, ldx, L, ldl, alpha, ynew, m,
-                       c, var, -2.0 * length_scale * length_scale, noise, status);
+                       c, var, -2.0 * length_scale * length_scale, noise, status, ital::StageArgs{});
     return ital_check_launch("ital_chol_append");
+}
+
+// update() of the retrieval loop as ONE call (reference ital/gp.py:164-200 + predict_stored, gp.py:203-232): the samples'
+// rows staged out of `rows`, the rank-c Cholesky append (both in one single-workgroup launch) and the whitening sweep.
+extern "C" int ital_gp_append(const ital_append_desc* a, hipStream_t stream) {
+    if (!a) return ital_fail(-22, "ital_gp_append: null descriptor");
+    const int c = a->lb.c, m = a->m;
+    if (c < 1 || c > 16) return ital_fail(-22, "ital_gp_append: 1..16 samples per call");
+    if (m < 0 || m + c > a->ldl) return ital_fail(-22, "ital_gp_append: factor capacity exceeded");
+    if (a->ldx % 16 != 0) return ital_fail(-22, "ital_gp_append: ldx must be a multiple of 16");
+    ital::StageArgs sa = {a->rows, a->lb, a->XT + (int64_t)m * a->ldx, a->XTn + m, a->ybuf};
+    ITAL_LAUNCH(ital::chol_append_kernel, dim3(1), dim3(1024), 0, stream, a->XT, a->XTn, a->ldx, a->L, a->ldl, a->alpha,
+                a->ybuf, m, c, a->var, -2.0 * a->length_scale * a->length_scale, a->noise, a->status, sa);
+    const int rc = ital_check_launch("ital_gp_append(chol)");
+    if (rc) return rc;
+    const double* L21 = a->L + (int64_t)m * a->ldl;
+    return ital_whiten_append(a->X, a->xnorm, a->n, a->ldx, a->XT + (int64_t)m * a->ldx, a->XTn + m, c, L21, a->ldl, L21 + m,
+                              a->alpha + m, a->V, a->ldv, m, a->var, a->length_scale, a->mu, a->s2, stream);
 }

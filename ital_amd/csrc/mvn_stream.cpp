@@ -135,3 +135,15 @@ extern "C" int ital_mvn_generic_tables(int nmax, long long* jump1, double* vk_al
     }
     return 0;
 }
+
+extern "C" int ital_mvn_round_seeds(int state[6], int64_t n_cand, int k, int seeds[][6]) {
+    if (!state || !seeds || k < 1 || k > ITAL_MAX_T || n_cand < k)
+        return ital_fail(-22, "ital_mvn_round_seeds: bad arguments");
+    int64_t n_alive = n_cand;
+    for (int t = 1; t <= k; t++, n_alive--) {
+        for (int j = 0; j < 6; j++) seeds[t][j] = state[j];
+        const int rc = ital_mvn_advance(state, n_alive * (2LL << t) * draws_per_call(t));
+        if (rc) return rc;
+    }
+    return 0;
+}

@@ -11,6 +11,7 @@ GPU, the row shard of X and the Cholesky-whitened block
 so an update appends c rows (rank-c Cholesky append) and N never appears squared.  All arithmetic runs in
 the HIP kernels of libital_hip.so; torch only owns the device buffers and the stream.
 """
+import ctypes
 import os
 
 import numpy as np
@@ -260,28 +261,30 @@ class GaussianProcess(object):
 
     def _append_staged(self, matrix, slots, y):
         """_append for up to 16 samples whose feature rows are rows `slots` of a replicated device matrix (the batch state
-        of the last fetch): one staging launch instead of gather, copies, norms and a label upload."""
-        lib, st = self._lib, _stream()
+        of the last fetch): ONE call (ital_gp_append: staging + Cholesky append in one launch, then the whitening sweep)
+        instead of gather, copies, norms, a label upload and three calls."""
         c = len(slots)
         if self.m + c > self.cap:
             self._alloc(max(2 * self.cap, self.m + c))
         if getattr(self, "_ybuf", None) is None:
             self._ybuf = torch.empty(16, dtype=torch.float64, device=self.device)
-        lb = _lib.ItalLabelBatch()
-        lb.c = c
+        d = getattr(self, "_append_desc", None)
+        key = (self.V.data_ptr(), self.mu.data_ptr(), self.cap)
+        if d is None or d[0] != key:          # the pointers only change when the labelled-set buffers are re-allocated
+            a = _lib.ItalAppendDesc()
+            a.ldx, a.X, a.xnorm, a.n = self.ldx, _ptr(self.Xd), _ptr(self.xnorm), self.n
+            a.XT, a.XTn, a.L, a.ldl, a.alpha, a.ybuf = _ptr(self.XT), _ptr(self.XTn), _ptr(self.L), self.cap, _ptr(self.alpha), \
+                _ptr(self._ybuf)
+            a.V, a.ldv, a.mu, a.s2, a.status = _ptr(self.V), self.ldv, _ptr(self.mu), _ptr(self.s2), _ptr(self.status)
+            self._append_desc = d = (key, a)
+        a = d[1]
+        a.rows, a.m = _ptr(matrix), self.m
+        a.var, a.length_scale, a.noise = float(self.var), float(self.length_scale), float(self.noise)
+        a.lb.c = c
         for j in range(c):
-            lb.slot[j] = int(slots[j])
-            lb.y[j] = float(y[j])
-        m = self.m
-        check(lib.ital_stage_labelled(_ptr(matrix), self.ldx, lb, _ptr(self.XT[m:]), _ptr(self.XTn[m:]), _ptr(self._ybuf), st))
-        check(lib.ital_chol_append(_ptr(self.XT), _ptr(self.XTn), self.ldx, _ptr(self.L), self.cap, _ptr(self.alpha),
-                                   _ptr(self._ybuf), m, c, float(self.var), float(self.length_scale), float(self.noise),
-                                   _ptr(self.status), st))
-        L21 = self.L[m:]
-        check(lib.ital_whiten_append(_ptr(self.Xd), _ptr(self.xnorm), self.n, self.ldx, _ptr(self.XT[m:m + c]),
-                                     _ptr(self.XTn[m:m + c]), c, _ptr(L21), self.cap, L21.data_ptr() + 8 * m,
-                                     _ptr(self.alpha[m:m + c]), _ptr(self.V), self.ldv, m, float(self.var),
-                                     float(self.length_scale), _ptr(self.mu), _ptr(self.s2), st))
+            a.lb.slot[j] = int(slots[j])
+            a.lb.y[j] = float(y[j])
+        check(self._lib.ital_gp_append(ctypes.byref(a), _stream()))
         self.m += c
 
     def _append(self, rows, y):

@@ -68,6 +68,7 @@ class ITAL(ActiveRetrievalBase):
         self.event_pool = []     # pre-created timing events (bench.py)
         self.profile = None      # list to receive (stage, t, size, start_event, end_event) per launch (bench.py)
         self._fetch_bufs = None
+        self.profile_steps = None      # round path: greedy steps whose lattice sums are bracketed by events (None: all)
         self.round_call = True        # one rank, up to 2^18 candidates: a whole round through ital_fetch_round (False: step by step from Python)
         self._dev_list = None         # the candidate list the device holds: (buffers, host array, picks flagged dead)
         self.select_in_scorer = True  # False: the selection of a greedy step always runs as a launch of its own (cross-check in tests)
@@ -370,12 +371,68 @@ class ITAL(ActiveRetrievalBase):
         self._last_batch = (b, list(ret))
         return [int(i) for i in ret]
 
+    def _round_signature(self, b, k):
+        gp = self.gp
+        return (id(b), k, gp.cap, gp.ldv, gp.V.data_ptr(), gp.mu.data_ptr(), float(self.noise), float(self.eps),
+                float(self.var), float(self.length_scale), self.label_estimation, self.qmc_work_bytes,
+                self.profile is not None, repr(self.profile_steps))
+
+    def _round_prepare(self, slot, b, k, n, m, begin, cur, state_before, n_prev=0):
+        """Fills round descriptor `slot` (one of two) for a round of k steps over n candidates with m labelled samples, the
+        candidate list in device buffer `cur` (begin = 2: compacted out of the other buffer, which holds n + k entries).
+        Nothing here depends on the picks of the round before: the descriptor of the NEXT round is prepared while the GPU
+        works on the current one, off the critical path of the retrieval loop."""
+        lib = _lib.lib()
+        gp = self.gp
+        dev = gp.device
+        lists = b["cand_lists"]
+        r = b["round_descs"][slot]
+        d = r.step
+        r.k, r.n_rows, r.var, r.length_scale = k, gp.n, float(self.var), float(self.length_scale)
+        r.begin, r.cand_prev, r.n_prev = begin, (_ptr(lists[cur ^ 1]) if begin == 2 else None), (n_prev if begin == 2 else 0)
+        d.n_cand = n
+        d.cand, d.alive, d.mu, d.s2 = _ptr(lists[cur]), _ptr(b["alive"]), _ptr(gp.mu), _ptr(gp.s2)
+        d.C, d.ldc, d.row_offset, d.pos_offset, d.gpos = _ptr(b["C"]), gp.ldv, gp.row0, 0, None
+        d.batch = b["batch"]
+        d.noise, d.eps, d.label_mode = float(self.noise), float(self.eps), _LABEL_MODES[self.label_estimation]
+        d.mi, d.status = _ptr(b["mi"]), _ptr(gp.status)
+        d.sel_X, d.sel_xnorm, d.sel_ldx = _ptr(gp.Xd), _ptr(gp.xnorm), gp.ldx
+        d.sel_V, d.sel_ldv, d.sel_m, d.sel_ldw, d.sel_rank = _ptr(gp.V), gp.ldv, m, gp.cap, gp.rank
+        d.sel_record, d.sel_ret = _ptr(b["rec"]), _ptr(b["ret"])
+        parts = b["sel_parts"]
+        d.sel_parts, d.sel_parts_len, d.sel_counter = _ptr(parts), parts.numel(), _ptr(b["sel_counter"])
+        r.mi_keep = None
+        events = []
+        if k >= 3:
+            work = self._qmc_workspace(b, k, n)
+            d.work, d.work_doubles = _ptr(work), work.numel()
+        for t in range(1, k + 1):
+            r.ev_start[t] = r.ev_stop[t] = None
+            if t >= 3:
+                if t not in b["jump"]:
+                    b["jump"][t] = torch.from_numpy(mvn_stream.jump_table(t, ITAL_JUMP_BITS)).to(dev)
+                    b["jumppat"][t] = torch.from_numpy(mvn_stream.jump_pattern_table(t)).to(dev)
+                    b["vk"][t] = torch.from_numpy(mvn_stream.korobov_vk(t)).to(dev)
+                r.jump[t], r.jumppat[t], r.vk[t] = _ptr(b["jump"][t]), _ptr(b["jumppat"][t]), _ptr(b["vk"][t])
+                if self.profile is not None and (self.profile_steps is None or t in self.profile_steps):
+                    k0, k1 = self._event(), self._event()
+                    r.ev_start[t], r.ev_stop[t] = k0.cuda_event, k1.cuda_event
+                    slabs = -(-n // max(work.numel() // int(lib.ital_score_workspace(t, 1)), 1))
+                    events.append(("qmc_main" if slabs == 1 else "qmc_slabs%d" % slabs, t, n - (t - 1), k0, k1))
+        # the reference's serial loop consumes n_alive * 2 * 2^t calls of mvndst's stream at step t: states before every step
+        st6 = (ctypes.c_int * 6)(*state_before)
+        check(lib.ital_mvn_round_seeds(st6, n, k, ctypes.byref(r.seeds)))
+        draws = sum((n - (t - 1)) * (2 << t) * mvn_stream.draws_per_call(t) for t in range(3, k + 1))
+        return dict(slot=slot, k=k, n=n, m=m, begin=begin, cur=cur, state_before=tuple(state_before),
+                    state_after=tuple(int(v) for v in st6), draws=draws, events=events, sig=self._round_signature(b, k))
+
     def _select_round(self, k, candidates):
         """The one-rank path of _select as ONE call below the C ABI (ital_fetch_round): candidate-list upkeep, k scoring
         steps that end with their selection, k - 1 covariance columns -- enqueued from C (a Python host needs 10 - 17 us per
         launch, the first greedy steps are shorter than that).  The candidate list stays on the device between rounds: when
         the list is the previous one minus the previous batch (the retrieval loop: fetch, label the batch, fetch), it is
-        compacted there by its alive flags instead of being rebuilt and uploaded."""
+        compacted there by its alive flags instead of being rebuilt and uploaded; and the descriptor of such a next round
+        is filled in while the GPU still works on the current one."""
         lib = _lib.lib()
         gp = self.gp
         dev = gp.device
@@ -385,78 +442,55 @@ class ITAL(ActiveRetrievalBase):
             st = _stream()
             # ---- candidate list: two device buffers (the compaction reads one, writes the other)
             lists = b.get("cand_lists")
-            if lists is None or lists[0].numel() < n:
+            if lists is None or lists[0].numel() < n or b.get("alive") is None or b["alive"].numel() < n:
                 b["cand_lists"] = lists = [torch.empty(max(n, 1), dtype=torch.int32, device=dev) for _ in range(2)]
                 b["cand_cur"] = 0
-                self._dev_list = None
-            if b.get("alive") is None or b["alive"].numel() < n:
                 b["alive"] = torch.empty(n, dtype=torch.uint8, device=dev)
                 b["mi"] = torch.empty(n, dtype=torch.float64, device=dev)
-                self._dev_list = None
-            parts = b.get("sel_parts")
-            if parts is None or parts.numel() < 3 * (n // 32 + 64):
-                b["sel_parts"] = parts = torch.empty(3 * (n // 32 + 64), dtype=torch.float64, device=dev)
+                b["sel_parts"] = torch.empty(3 * (n // 32 + 64), dtype=torch.float64, device=dev)
                 b["sel_counter"] = torch.zeros(1, dtype=torch.int32, device=dev)
+                b["round_descs"] = [_lib.ItalRoundDesc(), _lib.ItalRoundDesc()]
+                b["round_next"] = None
+                self._dev_list = None
             dl = self._dev_list
             uc = getattr(self, "_unseen_cache", None)
-            prev_n = 0
-            if (dl is not None and dl["b"] is b and uc is not None and candidates is uc["array"] and uc["parent"] is dl["host"]
-                    and len(uc["removed"]) == len(dl["picks"]) and set(uc["removed"].tolist()) == set(dl["picks"])):
-                begin, prev = 2, lists[b["cand_cur"]]        # the device holds the parent list with exactly those picks flagged
-                prev_n = len(dl["host"])
-                b["cand_cur"] ^= 1
-                cand_d = lists[b["cand_cur"]]
-            else:
-                begin, prev = 1, None
-                cand_d = lists[b["cand_cur"]]
-                cand_d[:n].copy_(torch.from_numpy(np.asarray(candidates, dtype=np.int64).astype(np.int32)))
+            stream = mvn_stream.GLOBAL
+            follows = (dl is not None and dl["b"] is b and uc is not None and candidates is uc["array"]
+                       and uc["parent"] is dl["host"] and len(uc["removed"]) == len(dl["picks"])
+                       and set(uc["removed"].tolist()) == set(dl["picks"]))
             self._dev_list = None                              # re-published after the round's successful download
-            alive, mi = b["alive"], b["mi"]
-            r = b.get("round_desc")
-            if r is None:
-                r = b["round_desc"] = _lib.ItalRoundDesc()
-            d = r.step
-            r.k, r.n_rows, r.var, r.length_scale = k, gp.n, float(self.var), float(self.length_scale)
-            r.begin, r.cand_prev, r.n_prev = begin, _ptr(prev), prev_n
-            d.n_cand = n
-            d.cand, d.alive, d.mu, d.s2 = _ptr(cand_d), _ptr(alive), _ptr(gp.mu), _ptr(gp.s2)
-            d.C, d.ldc, d.row_offset, d.pos_offset, d.gpos = _ptr(b["C"]), gp.ldv, gp.row0, 0, None
-            d.batch = b["batch"]
-            d.noise, d.eps, d.label_mode = float(self.noise), float(self.eps), _LABEL_MODES[self.label_estimation]
-            d.mi, d.status = _ptr(mi), _ptr(gp.status)
-            d.sel_X, d.sel_xnorm, d.sel_ldx = _ptr(gp.Xd), _ptr(gp.xnorm), gp.ldx
-            d.sel_V, d.sel_ldv, d.sel_m, d.sel_ldw, d.sel_rank = _ptr(gp.V), gp.ldv, gp.m, gp.cap, gp.rank
-            d.sel_record, d.sel_ret = _ptr(b["rec"]), _ptr(b["ret"])
-            d.sel_parts, d.sel_parts_len, d.sel_counter = _ptr(parts), parts.numel(), _ptr(b["sel_counter"])
+            p = b["round_next"]
+            if (p is not None and follows and not self.keep_scores and p["k"] == k and p["n"] == n and p["m"] == gp.m
+                    and p["state_before"] == tuple(stream.state) and p["sig"] == self._round_signature(b, k)):
+                b["cand_cur"] = p["cur"]                       # the round the previous one prepared for
+            else:
+                if p is not None:                              # prepared for a round that did not come: its events go back
+                    for ev in p["events"]:
+                        self.event_pool += [ev[3], ev[4]]
+                n_prev = 0
+                if follows:
+                    begin, n_prev = 2, len(dl["host"])         # the device holds the parent list with exactly those picks flagged
+                    b["cand_cur"] ^= 1
+                else:
+                    begin = 1
+                    lists[b["cand_cur"]][:n].copy_(torch.from_numpy(np.asarray(candidates, dtype=np.int64).astype(np.int32)))
+                p = self._round_prepare(0, b, k, n, gp.m, begin, b["cand_cur"], stream.state, n_prev)
+            b["round_next"] = None
+            self.last_round = (p["begin"], p["slot"])          # diagnostics / tests: how the candidate list reached the device
+            r = b["round_descs"][p["slot"]]
             keep = None
             if self.keep_scores:
                 keep = torch.zeros((k, n), dtype=torch.float64, device=dev)
-            r.mi_keep = _ptr(keep)
-            stream = mvn_stream.GLOBAL
+                r.mi_keep = _ptr(keep)
             saved_stream = (stream.state, stream.draws)
-            if k >= 3:
-                work = self._qmc_workspace(b, k, n)
-                d.work, d.work_doubles = _ptr(work), work.numel()
-            n_alive = n
-            for t in range(1, k + 1):
-                r.ev_start[t] = r.ev_stop[t] = None
-                if t >= 3:
-                    if t not in b["jump"]:
-                        b["jump"][t] = torch.from_numpy(mvn_stream.jump_table(t, ITAL_JUMP_BITS)).to(dev)
-                        b["jumppat"][t] = torch.from_numpy(mvn_stream.jump_pattern_table(t)).to(dev)
-                        b["vk"][t] = torch.from_numpy(mvn_stream.korobov_vk(t)).to(dev)
-                    r.jump[t], r.jumppat[t], r.vk[t] = _ptr(b["jump"][t]), _ptr(b["jumppat"][t]), _ptr(b["vk"][t])
-                    for j in range(6):
-                        r.seeds[t][j] = stream.state[j]
-                    if self.profile is not None:
-                        k0, k1 = self._event(), self._event()
-                        r.ev_start[t], r.ev_stop[t] = k0.cuda_event, k1.cuda_event
-                        slabs = -(-n // max(work.numel() // int(lib.ital_score_workspace(t, 1)), 1))
-                        self.profile.append(("qmc_main" if slabs == 1 else "qmc_slabs%d" % slabs, t, n_alive, k0, k1))
-                # the reference's serial loop consumes this many uniforms of mvndst's stream at step t
-                stream.advance(n_alive * (2 << t) * mvn_stream.draws_per_call(t))
-                n_alive -= 1
             check(lib.ital_fetch_round(ctypes.byref(r), st))
+            stream.state, stream.draws = p["state_after"], stream.draws + p["draws"]
+            if self.profile is not None:
+                self.profile += p["events"]
+            # ---- while the GPU works: the descriptor of the round that follows in the retrieval loop (this batch labelled,
+            # then the next fetch of k): nothing in it depends on which samples this round picks
+            if n - k >= k and gp.m + k <= gp.cap and not self.keep_scores:
+                b["round_next"] = self._round_prepare(p["slot"] ^ 1, b, k, n - k, gp.m + k, 2, b["cand_cur"] ^ 1, stream.state, n)
             host = b["ret"].cpu().tolist()     # the only synchronisation of the round: the picks and the status word
             ret, status = host[:k], host[b["kmax"]]
             self.last_scores = [keep[t, :n] for t in range(k)] if keep is not None else []

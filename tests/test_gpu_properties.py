@@ -117,11 +117,11 @@ def test_device_candidate_list_follows_arbitrary_feedback(dev):
         def fetch(k):                                  # noqa: E306
             ret = L.fetch_unlabelled(k)
             log.append(ret)
-            reused.append(bool(L._fetch_bufs["round_desc"].begin == 2) if rounds_in_c else None)
+            reused.append(bool(L.last_round[0] == 2) if rounds_in_c else None)
             return ret
         r = fetch(4); L.update({i: lab(i) for i in r})                   # the loop of the reference: whole batch labelled
         r = fetch(4); L.update({i: lab(i) for i in r[:3]})               # one pick left without feedback: candidate again
-        r = fetch(3); L.update(dict({i: lab(i) for i in r}, **{17: 1}))  # feedback for a sample outside the batch
+        r = fetch(3); fb = {i: lab(i) for i in r}; fb[17] = 1; L.update(fb)   # feedback for a sample outside the batch
         r = fetch(4); L.update({r[0]: 0, r[1]: lab(r[1]), r[2]: lab(r[2]), r[3]: 0})   # unnameable: seen, not trained on
         r = fetch(4); L.update({i: lab(i) for i in r})
         r = fetch(2); L.update({i: lab(i) for i in r})
