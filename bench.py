@@ -181,7 +181,7 @@ def other_workloads(X, rel, device):
         if getattr(learner, "pair_counter", None) is not None:
             learner.pair_counter.zero_()                  # count the timed rounds only
         learner.profile = []
-        learner.event_pool = [torch.cuda.Event(enable_timing=True) for _ in range(32 * k * rounds)]
+        learner.event_pool = [torch.cuda.Event(enable_timing=True) for _ in range(6 * k * rounds + 16)]   # (a large pool of recorded events slows the first rounds down, see main())
         for ev in learner.event_pool:
             ev.record()
         torch.cuda.synchronize()
@@ -362,7 +362,7 @@ def scaling_workload(device, rank, world, group, rounds=3):
     L.update({0: 1})
     one_round()                                            # warm-up
     L.profile = []
-    L.event_pool = [torch.cuda.Event(enable_timing=True) for _ in range(16 * k * rounds)]
+    L.event_pool = [torch.cuda.Event(enable_timing=True) for _ in range(6 * k * rounds + 16)]
     for ev in L.event_pool:
         ev.record()
     scored = 0
@@ -482,17 +482,23 @@ def main():
     restart()
     barrier()
     t0 = time.perf_counter()
+    marks_u = []
     for _ in range(args.steps):
         one_round()
+        marks_u.append(time.perf_counter())
     barrier()
     dt_unfrozen = time.perf_counter() - t0
     restart()
     learner.profile = None if os.environ.get("ITAL_BENCH_NO_EVENTS") else []
     learner.profile_steps = {BATCH}      # events around the dominant kernel only (every record is a barrier packet in the queue)
-    # timing events are created before the timed region (only recorded inside it)
-    learner.event_pool = [torch.cuda.Event(enable_timing=True) for _ in range(8 * (2 * BATCH) * args.steps)]
+    # timing events are created before the timed region (only recorded inside it): one pair per round, around the dominant
+    # kernel.  Not more than needed: a pool of 1280 events (8 per greedy step), each recorded once to create its handle,
+    # slowed the first ~8 rounds of the timed loop down by up to 1 ms each (3.8, 3.2, 3.1 ... 2.7 ms; the runtime works
+    # through the pending signals), 0.13 ms on the average of 20 steps -- measured with and without any event being used
+    n_events = 0 if learner.profile is None else 2 * (args.steps + 2)
+    learner.event_pool = [torch.cuda.Event(enable_timing=True) for _ in range(n_events)]
     for ev in learner.event_pool:
-        ev.record()          # creates the handle (the library records some of them itself, around single kernels)
+        ev.record()          # creates the handle (the library records them itself, around single kernels)
     # a serving process freezes its start-up heap (ital_amd.serving_mode()): without this CPython's generation-2 collector
     # walks torch's ~10^5 objects once every few rounds (a 40 ms pause, measured: ten 3.4 ms rounds cost 73 ms), which has
     # nothing to do with the path under test; the figure without it is reported as ms_per_step_unfrozen_heap
@@ -504,12 +510,17 @@ def main():
     barrier()
     launches0 = _lib.lib().ital_launch_count()
     t0 = time.perf_counter()
+    marks = []
     for _ in range(args.steps):
         n_cand = n_total - len(learner.relevant_ids) - len(learner.irrelevant_ids)
         one_round()
         scored += sum(n_cand - t for t in range(BATCH))
+        marks.append(time.perf_counter())
     barrier()
     dt = time.perf_counter() - t0
+    if os.environ.get("ITAL_BENCH_STEP_TIMES"):
+        print("step ms (timed):    " + " ".join("%.2f" % ((b_ - a_) * 1e3) for a_, b_ in zip([t0] + marks[:-1], marks)), file=sys.stderr)
+        print("step ms (unfrozen): " + " ".join("%.2f" % ((b_ - a_) * 1e3) for a_, b_ in zip(marks_u[:-1], marks_u[1:])), file=sys.stderr)
     launches = (_lib.lib().ital_launch_count() - launches0) / args.steps
     if world > 1:
         import torch.distributed as dist
