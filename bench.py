@@ -257,6 +257,26 @@ def other_workloads(X, rel, device):
                                                        "note": "counters: profiles/r2_mcmi_pmc_summary.csv (tools/mcmi_bench.py, "
                                                                "launches of 1000 and 9273 candidates averaged)"})
     out["mcmi_min_subsample1000_k4"] = dict(r, roofline=roofs, config="MCMI_min, subsample 1000 (reference configs/usps.conf)")
+    # batches of 6 (reference configs/toy*.conf use batch_size = 6): the split scorer (preparation + workgroup per
+    # candidate and group of 8 label patterns)
+    k6 = 6
+    np.random.seed(0)
+    m6 = MCMI_min(X, length_scale=LENGTH_SCALE, subsample=1000, device=device)
+    r6, prof6 = timed(m6, 5, k6)
+    r6["candidates_per_s"] = k6 * 1000 / (r6["ms_per_round"] * 1e-3)
+    ms6 = prof6.get(("mcmi_score", k6), [])
+    roof6 = None
+    if ms6:
+        sec = float(np.mean([d for d, _ in ms6]))
+        nc = float(np.mean([c for _, c in ms6]))
+        terms = nc * nc * (2 ** k6)
+        ach = terms * FLOP_PER_MCMI_TERM / sec / 1e12
+        roof6 = {"kernel": "mcmi_prep_kernel<6> + mcmi_split_kernel<6>", "bound": "fp64-valu", "achieved": ach,
+                 "peak": FP64_VALU_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach / FP64_VALU_PEAK_TFLOPS,
+                 "avg_launch_ms": sec * 1e3, "terms_per_s": terms / sec, "traffic": None}
+    out["mcmi_min_subsample1000_k6"] = dict(r6, roofline=roof6, kernel_ms={"%s_t%d" % key: float(np.mean([d for d, _ in v])) * 1e3
+                                                                           for key, v in sorted(prof6.items())},
+                                            config="MCMI_min, subsample 1000, batch of 6")
     return out
 
 

@@ -344,12 +344,19 @@ typedef struct ital_mcmi_desc {
     ital_batch batch;       /* bgpos = block position of each member */
     double noise, eps;
     double* ce;             /* [n_i] out: min over label patterns of the summed conditional entropy */
+    double* work;           /* t >= 5: ital_mcmi_workspace(t, n_i) doubles of ZERO-INITIALISED device memory (left zeroed where
+                               it has to be): the step then runs as a preparation kernel (W per candidate) and one workgroup
+                               per (candidate, group of 2^(t-3) label patterns) -- occupancy 3 instead of 1, no scratch.
+                               NULL: the single-kernel form (all t) */
+    int64_t work_doubles;
 } ital_mcmi_desc;
 
 /* ce[i] = min_r sum_j [q log(q+eps) + (1-q) log(1-q+eps)], q = P(candidate j irrelevant | batch + i labelled r).
  * Replaces the Pool.map over AppendedConditionalEntropy.__call__, reference ital/mcmi.py:69-75, :101-124
  * (updated_prediction(..., cov_mode='diag') over all candidates, gp.py:295-344, and scipy.stats.norm.cdf). */
 int ital_mcmi_score_step(const ital_mcmi_desc* d, hipStream_t stream);
+/* Doubles of workspace for the split form of ital_mcmi_score_step (0 for t < 5). */
+int64_t ital_mcmi_workspace(int t, int64_t n_i);
 
 /* ---- general scorer: noisy user models, change-estimation subset ------------------------------------------- */
 typedef struct ital_gscore_desc {

@@ -71,7 +71,8 @@ class ItalGscoreDesc(ctypes.Structure):
 class ItalMcmiDesc(ctypes.Structure):
     _fields_ = [("t", c_int), ("n_i", c_int64), ("pos_offset", c_int64), ("n_all", c_int64), ("alive", c_void_p),
                 ("mu", c_void_p), ("s2", c_void_p), ("cov", c_void_p), ("ld_cov", c_int64), ("C", c_void_p),
-                ("ldc", c_int64), ("batch", ItalBatch), ("noise", c_double), ("eps", c_double), ("ce", c_void_p)]
+                ("ldc", c_int64), ("batch", ItalBatch), ("noise", c_double), ("eps", c_double), ("ce", c_void_p),
+                ("work", c_void_p), ("work_doubles", c_int64)]
 
 
 class ItalNpLegacyState(ctypes.Structure):
@@ -114,6 +115,7 @@ SIGNATURES = {
                                     c_void_p, c_int64, c_int, c_double, c_double, c_void_p, c_int64, c_int, c_void_p,
                                     c_void_p]),
     "ital_mcmi_score_step": (c_int, [ctypes.POINTER(ItalMcmiDesc), c_void_p]),
+    "ital_mcmi_workspace": (c_int64, [c_int, c_int64]),
     "ital_score_generic": (c_int, [ctypes.POINTER(ItalGscoreDesc), c_void_p]),
     "ital_select_local": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_void_p, c_int64, c_int, c_int, c_void_p,
                                   c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int64, c_int, c_int, c_void_p,

@@ -496,11 +496,205 @@ __global__ __launch_bounds__(256) void mcmi_score_kernel(McmiArgs a) {
     if (tid == 0) a.ce[li] = best;
 }
 
+// ---- batches of 5 .. 8: the same objective as three phases, each with registers of its own ------------------------------
+// The kernel above holds W (T^2), 32 pattern values and 32 accumulators per thread: from T = 5 on that is 256 VGPRs plus
+// 64 - 184 AGPRs at ONE wave per SIMD (T = 8: 1040 B of scratch on top).  Split (as the ITAL scorer was):
+//   mcmi_prep_kernel<T>        thread per candidate i: W = (Sigma_S + noise I)^-1 and the means of S -> workspace
+//   mcmi_split_kernel<T, TLR>  workgroup per (candidate i, group of high-order label bits): 2^TLR patterns in registers
+//                              (TLR = 3: 8 values + 8 accumulators), W read from LDS at use; the last workgroup of a
+//                              candidate (ticket counter) takes the minimum over the groups' partial minima
+// The u = W c products are recomputed by every group (T^2 + 2T FMAs per j against 2^TLR entropy terms of ~150
+// instructions: 11 % at T = 8, TLR = 3).  Sums over j are formed by the same threads in the same order as above: same bits.
+#ifndef ITAL_MCMI_TLR
+#define ITAL_MCMI_TLR 3
+#endif
+
 template <int T>
-static int launch_mcmi(const McmiArgs& a, hipStream_t stream) {
+struct McmiSplit {
+    static constexpr int TLR = ITAL_MCMI_TLR < T ? ITAL_MCMI_TLR : T;
+    static constexpr int NL = 1 << TLR, NHB = 1 << (T - TLR);
+    static constexpr int WDOUBLES = T * T + T;                  // W, then the means of S
+    static constexpr int64_t CAND_DOUBLES = WDOUBLES + NHB + 1;  // + partial minima + ticket counter
+};
+
+template <int T>
+__global__ __launch_bounds__(128) void mcmi_prep_kernel(McmiArgs a, double* __restrict__ wbuf) {
+    using M = McmiSplit<T>;
+    const int64_t li = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (li >= a.n_i || !a.alive[li]) return;
+    const int64_t gi = a.pos_offset + li;
+    double* out = wbuf + li * M::WDOUBLES;
+    double Sg[T][T];
+#pragma unroll
+    for (int p = 0; p < T - 1; p++) {
+        out[T * T + p] = a.b.bmu[p];
+#pragma unroll
+        for (int q = 0; q < T - 1; q++) Sg[p][q] = a.b.sig[p * a.b.kmax + q];
+        const double c = a.C[(int64_t)p * a.ldc + gi];
+        Sg[p][T - 1] = c;
+        Sg[T - 1][p] = c;
+    }
+    out[T * T + T - 1] = a.mu[gi];
+    Sg[T - 1][T - 1] = a.s2[gi];
+    // W = (Sigma + noise I)^-1 through the Cholesky factor (the arithmetic of mcmi_score_kernel, operation for operation)
+    double Lc[T][T], Li[T][T];
+#pragma unroll
+    for (int p = 0; p < T; p++)
+#pragma unroll
+        for (int q = 0; q <= p; q++) {
+            double v = Sg[p][q] + (p == q ? a.noise : 0.0);
+#pragma unroll
+            for (int r = 0; r < q; r++) v -= Lc[p][r] * Lc[q][r];
+            Lc[p][q] = (p == q) ? sqrt(v) : v / Lc[q][q];
+        }
+#pragma unroll
+    for (int q = 0; q < T; q++)
+#pragma unroll
+        for (int p = 0; p < T; p++) {
+            if (p < q) { Li[p][q] = 0; continue; }
+            double v = (p == q) ? 1.0 : 0.0;
+#pragma unroll
+            for (int r = q; r < p; r++) v -= Lc[p][r] * Li[r][q];
+            Li[p][q] = v / Lc[p][p];
+        }
+#pragma unroll
+    for (int p = 0; p < T; p++)
+#pragma unroll
+        for (int q = 0; q <= p; q++) {
+            double w = 0;
+#pragma unroll
+            for (int r = p; r < T; r++) w += Li[r][p] * Li[r][q];
+            out[p * T + q] = w;
+            out[q * T + p] = w;
+        }
+}
+
+template <int T>
+__global__ __launch_bounds__(256) void mcmi_split_kernel(McmiArgs a, const double* __restrict__ wbuf, double* __restrict__ parts,
+                                                         unsigned int* __restrict__ tickets) {
+    using M = McmiSplit<T>;
+    constexpr int TLR = M::TLR, NL = M::NL, NHB = M::NHB;
+    __shared__ double Wsh[T * T + T];
+    __shared__ double red[4][NL];
+    __shared__ int64_t mpos[T];
+    const int64_t li = blockIdx.x;
+    const int hi = blockIdx.y;
+    if (li >= a.n_i) return;
+    if (!a.alive[li]) return;
+    const int64_t gi = a.pos_offset + li;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (tid < T * T + T) Wsh[tid] = wbuf[li * M::WDOUBLES + tid];
+    if (tid < T) mpos[tid] = tid < T - 1 ? a.b.bgpos[tid] : gi;
+    __syncthreads();
+    double ms[T];
+#pragma unroll
+    for (int p = 0; p < T; p++) ms[p] = Wsh[T * T + p];
+    const double* Srow = a.S + li * a.lds_;
+#if ITAL_MCMI_HOTK
+    HotK kk;
+    kk.load();
+#else
+    const LitK kk;
+#endif
+    double acc[NL];
+#pragma unroll
+    for (int r = 0; r < NL; r++) acc[r] = 0.0;
+    for (int64_t j = tid; j < a.n_all; j += 256) {
+        bool member = false;
+#pragma unroll
+        for (int p = 0; p < T - 1; p++) member = member || (mpos[p] == j);
+        if (member) continue;  // already picked: no longer in learner.candidates (mcmi.py:79)
+        double c[T], u[T];
+#pragma unroll
+        for (int p = 0; p < T - 1; p++) c[p] = a.C[(int64_t)p * a.ldc + j];
+        c[T - 1] = Srow[j];
+        double quad = 0, base = a.mu[j];
+#pragma unroll
+        for (int p = 0; p < T; p++) {
+            __asm__ volatile("" ::: "memory");   // W is read from LDS row by row at use: hoisted out of the j loop its T^2
+                                                 // values would occupy 2 T^2 registers (what the split is there to avoid)
+            double v = 0;
+#pragma unroll
+            for (int q = 0; q < T; q++) v = fma(Wsh[p * T + q], c[q], v);
+            u[p] = v;
+            quad = fma(c[p], v, quad);
+            base = fma(-v, ms[p], base);
+        }
+        const double sv = fmax(0.0, a.s2[j] - quad);
+        // high-order variables: this workgroup's share of the label patterns
+#pragma unroll
+        for (int p = 0; p < T - TLR; p++) base += ((hi >> (T - TLR - 1 - p)) & 1) ? u[p] : -u[p];
+        double val[NL];
+        double lo = base;
+#pragma unroll
+        for (int p = T - TLR; p < T; p++) lo -= u[p];
+        val[0] = lo;
+#pragma unroll
+        for (int bit = 0; bit < TLR; bit++) {
+            const double two_u = 2.0 * u[T - 1 - bit];
+#pragma unroll
+            for (int r = 0; r < (1 << bit); r++) val[r | (1 << bit)] = val[r] + two_u;
+        }
+        if (sv > 0) {
+            const double inv_sd = 1.0 / sqrt(sv);
+#pragma unroll
+            for (int r = 0; r < NL; r++) acc[r] += entropy_term(-val[r] * inv_sd, a.eps, kk);
+        } else {
+            // norm.cdf(0, mean, 0) is NaN (scipy scale check): the whole sum becomes NaN
+#pragma unroll
+            for (int r = 0; r < NL; r++) acc[r] = __builtin_nan("");
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < NL; r++) {
+        const double v = wave_sum(acc[r]);
+        if (lane == 0) red[wave][r] = v;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        double best = 0.0;
+        for (int r = 0; r < NL; r++) {
+            const double v = (red[0][r] + red[1][r]) + (red[2][r] + red[3][r]);
+            if (r == 0 || v < best) best = v;
+        }
+        volatile double* pw = parts + li * NHB;
+        pw[hi] = best;
+        __threadfence();
+        const int last = atomicAdd(tickets + li, 1u) == (unsigned)(NHB - 1);
+        if (last) {
+            __threadfence();
+            // minimum over the groups in pattern order (`cur < ce`, mcmi.py:121-122: a NaN first value stays)
+            double ce = pw[0];
+            for (int h = 1; h < NHB; h++) {
+                const double v = pw[h];
+                if (v < ce) ce = v;
+            }
+            a.ce[li] = ce;
+            tickets[li] = 0;
+        }
+    }
+}
+
+template <int T>
+static int launch_mcmi(const McmiArgs& a, double* work, int64_t work_doubles, hipStream_t stream) {
+    using M = McmiSplit<T>;
+    if (T >= 5 && work) {
+        if (work_doubles < M::CAND_DOUBLES * a.n_i)
+            return ital_fail(-22, "ital_mcmi_score_step: workspace smaller than ital_mcmi_workspace(t, n_i)");
+        // ticket counters first (the same place for every t: zero once, every finishing workgroup leaves its counter at zero)
+        unsigned int* tickets = reinterpret_cast<unsigned int*>(work);
+        double* wbuf = work + a.n_i;
+        double* parts = wbuf + a.n_i * M::WDOUBLES;
+        ITAL_LAUNCH(mcmi_prep_kernel<T>, dim3((unsigned)((a.n_i + 127) / 128)), dim3(128), 0, stream, a, wbuf);
+        ITAL_LAUNCH((mcmi_split_kernel<T>), dim3((unsigned)a.n_i, (unsigned)M::NHB), dim3(256), 0, stream, a, wbuf, parts, tickets);
+        return ital_check_launch("ital_mcmi_score_step(split)");
+    }
     ITAL_LAUNCH(mcmi_score_kernel<T>, dim3((unsigned)a.n_i), dim3(256), 0, stream, a);
     return ital_check_launch("ital_mcmi_score_step");
 }
+
+template <int T>
+static int64_t mcmi_cand_doubles() { return McmiSplit<T>::CAND_DOUBLES; }
 
 }  // namespace ital
 
@@ -557,6 +751,17 @@ extern "C" int ital_cov_abs_rowsum(const double* Xa, const double* an, int64_t n
     return ital_check_launch("ital_cov_abs_rowsum");
 }
 
+extern "C" int64_t ital_mcmi_workspace(int t, int64_t n_i) {
+    if (n_i <= 0) return 0;
+    switch (t) {
+        case 5: return mcmi_cand_doubles<5>() * n_i;
+        case 6: return mcmi_cand_doubles<6>() * n_i;
+        case 7: return mcmi_cand_doubles<7>() * n_i;
+        case 8: return mcmi_cand_doubles<8>() * n_i;
+    }
+    return 0;
+}
+
 extern "C" int ital_mcmi_score_step(const ital_mcmi_desc* d, hipStream_t stream) {
     if (!d) return ital_fail(-22, "ital_mcmi_score_step: null descriptor");
     if (d->n_i <= 0) return 0;
@@ -568,14 +773,14 @@ extern "C" int ital_mcmi_score_step(const ital_mcmi_desc* d, hipStream_t stream)
     McmiArgs a = {d->n_i, d->pos_offset, d->n_all, d->alive, d->mu, d->s2, d->cov, d->C, d->ld_cov, d->ldc, d->batch,
                   d->noise, d->eps, d->ce};
     switch (d->t) {
-        case 1: return launch_mcmi<1>(a, stream);
-        case 2: return launch_mcmi<2>(a, stream);
-        case 3: return launch_mcmi<3>(a, stream);
-        case 4: return launch_mcmi<4>(a, stream);
-        case 5: return launch_mcmi<5>(a, stream);
-        case 6: return launch_mcmi<6>(a, stream);
-        case 7: return launch_mcmi<7>(a, stream);
-        case 8: return launch_mcmi<8>(a, stream);
+        case 1: return launch_mcmi<1>(a, d->work, d->work_doubles, stream);
+        case 2: return launch_mcmi<2>(a, d->work, d->work_doubles, stream);
+        case 3: return launch_mcmi<3>(a, d->work, d->work_doubles, stream);
+        case 4: return launch_mcmi<4>(a, d->work, d->work_doubles, stream);
+        case 5: return launch_mcmi<5>(a, d->work, d->work_doubles, stream);
+        case 6: return launch_mcmi<6>(a, d->work, d->work_doubles, stream);
+        case 7: return launch_mcmi<7>(a, d->work, d->work_doubles, stream);
+        case 8: return launch_mcmi<8>(a, d->work, d->work_doubles, stream);
     }
     return ital_fail(-22, "ital_mcmi_score_step: unsupported batch dimension");
 }

@@ -40,6 +40,7 @@ class MCMI_min(ActiveRetrievalBase):
         self.eps = 1e-12  # reference ital/mcmi.py:88
         self.candidates = []
         self.keep_scores = False
+        self.split_kernel = True      # batches of 5 .. 8 through the split scorer (False: the single kernel; cross-check in tests)
         self.last_scores = None
         self.profile = None
         self.event_pool = []
@@ -146,6 +147,14 @@ class MCMI_min(ActiveRetrievalBase):
                 desc.batch = b["batch"]
                 desc.noise, desc.eps = float(self.noise), float(self.eps)
                 desc.ce = _ptr(ce)
+                if t >= 5 and self.split_kernel and n_i:
+                    # batches of 5 .. 8: preparation kernel + one workgroup per (candidate, group of label patterns)
+                    want = int(lib.ital_mcmi_workspace(t, n_i))
+                    w = b.get("mcmi_work")
+                    if w is None or w.numel() < want:      # zero-initialised once: the ticket counters return to zero
+                        b["mcmi_work"] = w = torch.zeros(int(lib.ital_mcmi_workspace(ITAL_MAX_T, n_i)), dtype=torch.float64,
+                                                         device=dev)
+                    desc.work, desc.work_doubles = _ptr(w), w.numel()
                 ev0 = self._mark()
                 check(lib.ital_mcmi_score_step(ctypes.byref(desc), st))
                 self._mark("mcmi_score", t, nc - (t - 1), ev0)

@@ -148,6 +148,45 @@ def test_mcmi_against_oracle(dev, seed, n, d, k, sub):
         B.update(fb)
 
 
+@pytest.mark.parametrize("n,d,k,sub", [(90, 5, 8, None), (400, 12, 7, 300), (130, 7, 6, None), (1200, 16, 5, 1000)])
+def test_mcmi_split_scorer_equals_single_kernel(dev, n, d, k, sub):
+    """Batches of 5 .. 8 (three shipped configurations use batch_size = 6, reference configs/toy*.conf): the split form
+    (preparation kernel + one workgroup per candidate and group of label patterns) forms every sum over the candidates in
+    the order of the single kernel -- same bits, same picks; the small case is also checked against the oracle."""
+    from ital_amd import MCMI_min
+    rng = np.random.default_rng(10 + k)
+    X = rng.random((n, d))
+    ls = float(np.sqrt(d / 12.0))
+    labels = {int(i): (1 if X[i, 0] > 0.5 else -1) for i in rng.choice(n, 3, replace=False)}
+    out = []
+    for split in (True, False):
+        L = MCMI_min(X, length_scale=ls, subsample=sub, device=dev)
+        L.split_kernel = split
+        L.keep_scores = True
+        L.update(labels)
+        res = []
+        for _ in range(2):
+            np.random.seed(5)
+            ret = L.fetch_unlabelled(k)
+            res.append((ret, [s_.cpu().numpy().copy() for s_ in L.last_scores]))
+            L.update({i: (1 if X[i, 0] > 0.5 else -1) for i in ret})
+        out.append(res)
+    for (ra, sa), (rb, sb) in zip(*out):
+        assert ra == rb
+        for x, y in zip(sa, sb):
+            np.testing.assert_array_equal(x, y)
+    if n <= 100:
+        from oracle.ital import OracleMCMI
+        B = OracleMCMI(X, length_scale=ls, subsample=sub)
+        B.update(labels)
+        np.random.seed(5)
+        want = [int(i) for i in B.fetch_unlabelled(k)]
+        assert out[0][0][0] == want
+        pos = {c: i for i, c in enumerate(B.trace[0][0])}
+        for t, (cand, vals, _) in enumerate(B.trace):
+            np.testing.assert_allclose(out[0][0][1][t][[pos[c] for c in cand]], vals, rtol=CE_RTOL, atol=0)
+
+
 def test_mcmi_edge_cases(dev):
     from ital_amd import MCMI_min
     rng = np.random.default_rng(3)

@@ -230,7 +230,7 @@ def test_ctypes_structs_have_the_layout_of_the_header(tmp_path):
                                                        "sel_counter"]),
               "ital_gscore_desc": (_lib.ItalGscoreDesc, ["n_cand", "gpos", "nE", "ldE", "pick_pos", "label_prob", "clip_cov", "seed",
                                                          "draws_in", "dead_pos", "fb_samples", "draw_count", "status", "work_doubles", "pair_count"]),
-              "ital_mcmi_desc": (_lib.ItalMcmiDesc, ["t", "alive", "ld_cov", "batch", "ce"]),
+              "ital_mcmi_desc": (_lib.ItalMcmiDesc, ["t", "alive", "ld_cov", "batch", "ce", "work", "work_doubles"]),
               "ital_round_desc": (_lib.ItalRoundDesc, ["k", "step", "seeds", "jump", "vk", "ev_stop", "n_rows", "length_scale",
                                                        "mi_keep", "begin", "cand_prev", "n_prev"]),
               "ital_np_legacy_state": (_lib.ItalNpLegacyState, ["key", "pos", "has_gauss", "gauss"]),
