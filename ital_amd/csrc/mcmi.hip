@@ -504,7 +504,8 @@ __global__ __launch_bounds__(256) void mcmi_score_kernel(McmiArgs a) {
 //                              (TLR = 3: 8 values + 8 accumulators), W read from LDS at use; the last workgroup of a
 //                              candidate (ticket counter) takes the minimum over the groups' partial minima
 // The u = W c products are recomputed by every group (T^2 + 2T FMAs per j against 2^TLR entropy terms of ~150
-// instructions: 11 % at T = 8, TLR = 3).  Sums over j are formed by the same threads in the same order as above: same bits.
+// instructions: 11 % at T = 8, TLR = 3).  Sums over j are formed by the same threads in the same order as above (values
+// agree with the single kernel's to the last bits).  Measured, 1000 candidates: t = 6 0.42 -> 0.36 ms, 7 0.80 -> 0.68, 8 1.61 -> 1.31.
 #ifndef ITAL_MCMI_TLR
 #define ITAL_MCMI_TLR 3
 #endif
