@@ -11,7 +11,9 @@ LIB = os.path.join(HERE, "libital_hip.so")
 SOURCES = ["api.hip", "rbf.hip", "chol.hip", "score.hip", "select.hip", "mcmi.hip", "score_generic.hip", "topk.hip", "exchange.hip", "round.hip",
            "mvn_stream.cpp", "np_legacy.cpp"]    # .cpp: host-only translation units (no HIP), also built by tools/asan_host.sh
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-EXTRA = os.environ.get("ITAL_HIPCC_EXTRA", "").split()
+EXTRA = os.environ.get("ITAL_HIPCC_EXTRA", "").split()          # added to every .hip compile (kernel-variant experiments)
+HOST_EXTRA = os.environ.get("ITAL_HOST_EXTRA", "").split()      # added to the host-only .cpp compiles
+LINK_EXTRA = os.environ.get("ITAL_LINK_EXTRA", "").split()      # added to the link (e.g. -fsanitize=..., tools/asan_host.sh)
 LIB = os.environ.get("ITAL_HIP_LIB_OUT", LIB)
 FLAGS = EXTRA + ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-gpu-rdc",
          "-I", INCLUDE, "-I", CSRC, "-Wall", "-Wno-unused-function"]
@@ -38,7 +40,7 @@ def build(force=False, verbose=False):
         o = os.path.join(objdir, os.path.splitext(src)[0] + ".o")
         objs.append(o)
         if force or _newer(o, [s] + headers):
-            jobs.append([HIPCC] + (FLAGS if src.endswith(".hip") else HOST_FLAGS) + ["-c", s, "-o", o])
+            jobs.append([HIPCC] + (FLAGS if src.endswith(".hip") else HOST_FLAGS + HOST_EXTRA) + ["-c", s, "-o", o])
 
     def run(cmd):
         if verbose:
@@ -49,7 +51,7 @@ def build(force=False, verbose=False):
         with ThreadPoolExecutor(max_workers=4) as ex:
             list(ex.map(run, jobs))
     if jobs or force or _newer(LIB, objs):
-        run([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs + ["-ldl", "-lpthread"])
+        run([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + LINK_EXTRA + objs + ["-ldl", "-lpthread"])
     return LIB
 
 

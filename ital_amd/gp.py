@@ -175,6 +175,7 @@ class GaussianProcess(object):
         self.ind = []
         self.y = None
         self.m = 0
+        self.appends = []          # sizes of the update() calls that built the labelled set (state_dict / replay)
         self.mu = torch.zeros(max(self.n, 1), dtype=torch.float64, device=self.device)
         self.s2 = torch.full((max(self.n, 1),), float(self.var), dtype=torch.float64, device=self.device)
         self.mu_all = torch.zeros(self.n_total, dtype=torch.float64, device=self.device) if self.collective else self.mu[: self.n]
@@ -209,6 +210,7 @@ class GaussianProcess(object):
             self._append(self._gather_rows(ind), y)
         self.ind += ind
         self.y = y.copy() if self.y is None else np.concatenate((self.y, y))
+        self.appends.append(len(ind))
         self._replicate_mean()
         return self
 
@@ -222,6 +224,7 @@ class GaussianProcess(object):
         self._append(rows, y)
         self.ind += list(ind) if ind is not None else list(range(self.n_total + self.m - len(y), self.n_total + self.m))
         self.y = y.copy() if self.y is None else np.concatenate((self.y, y))
+        self.appends.append(-len(y))          # negative: feature vectors that are not rows of the data (queries)
         self._replicate_mean()
         return self
 

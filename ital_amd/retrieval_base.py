@@ -50,6 +50,51 @@ class ActiveRetrievalBase(object):
         else:
             self._fitted = False
 
+    # ------------------------------------------------------------------ checkpoint / resume (the
+    # reference has none: its state dies with the process)
+    def state_dict(self):
+        """Everything needed to continue a retrieval session in another process: the labelled set in insertion order with
+        the sizes of the update() calls that built it, the id sets, the round counter and the position of the replayed
+        mvndst stream.  Small (O(labelled samples)): the whitened block V is rebuilt on load, not stored."""
+        from . import mvn_stream
+        gp = self.gp
+        return dict(version=1, n=len(self.data), hyper=(float(self.length_scale), float(self.var), float(self.noise)),
+                    ind=[int(i) for i in gp.ind], y=(gp.y.copy() if gp.y is not None else np.zeros(0)),
+                    appends=list(gp.appends), relevant_ids=sorted(self.relevant_ids),
+                    irrelevant_ids=sorted(self.irrelevant_ids), unnameable_ids=sorted(self.unnameable_ids),
+                    rounds=int(self.rounds), mvn_stream=(tuple(mvn_stream.GLOBAL.state), int(mvn_stream.GLOBAL.draws)))
+
+    def load_state_dict(self, sd, restore_stream=True):
+        """Restores a session saved by state_dict() on a learner constructed over the same data (and queries) with the same
+        hyper-parameters: reset(), then the same sequence of appends to the GP (same kernels, same order: the predictive
+        means equal the saved session's to ~1e-15), the id sets, the round counter and -- unless told otherwise -- the
+        process-wide position of the mvndst stream.  Collective on several ranks, like update()."""
+        from . import mvn_stream
+        if sd.get("version") != 1 or sd["n"] != len(self.data):
+            raise ValueError("state_dict of another data set / version")
+        if tuple(sd["hyper"]) != (float(self.length_scale), float(self.var), float(self.noise)):
+            raise ValueError("state_dict was saved with other hyper-parameters: %r" % (sd["hyper"],))
+        self.reset()
+        at = self.gp.m                       # queries, if any, are back in place after reset()
+        ind, y = list(sd["ind"]), np.asarray(sd["y"], dtype=np.float64)
+        for c in sd["appends"]:
+            if c < 0:
+                continue                     # the queries' own append: done by reset()
+            if c:
+                self.gp.update(ind[at:at + c], y[at:at + c])
+            at += c
+        if self.gp.ind != ind:
+            raise ValueError("state_dict does not match this learner's queries")
+        self.relevant_ids = set(sd["relevant_ids"])
+        self.irrelevant_ids = set(sd["irrelevant_ids"])
+        self.unnameable_ids = set(sd["unnameable_ids"])
+        self.rounds = int(sd["rounds"])
+        self._fitted = self.gp.m > 0
+        self._unseen_cache = None
+        if restore_stream:
+            mvn_stream.GLOBAL.state, mvn_stream.GLOBAL.draws = tuple(sd["mvn_stream"][0]), int(sd["mvn_stream"][1])
+        return self
+
     @property
     def rel_mean(self):
         """Predictive mean of every sample (numpy; None before the first update, as reference retrieval_base.py:61).

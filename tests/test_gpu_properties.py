@@ -302,3 +302,35 @@ def test_labelled_set_capacity_growth_inside_a_session(dev):
         res.append((picks, L.rel_mean.copy(), L.gp.cap))
     assert res[0][0] == res[1][0] and res[0][2] >= 32 and res[1][2] >= 64
     np.testing.assert_allclose(res[0][1], res[1][1], rtol=0, atol=1e-12)
+
+
+def test_state_dict_resumes_a_session(dev):
+    """state_dict() / load_state_dict(): a session saved after two rounds and restored on a fresh learner continues with
+    the same batches (incl. the position of the replayed mvndst stream) and the same predictive means."""
+    import pickle
+    from ital_amd import ITAL, mvn_stream
+    rng = np.random.default_rng(12)
+    X = rng.random((500, 9))
+    lab = lambda i: 1.0 if X[i, 0] > 0.5 else -1.0   # noqa: E731
+    mvn_stream.GLOBAL.reset()
+    A = ITAL(X, length_scale=0.85, device=dev)
+    A.update({4: 1, 7: -1})
+    for _ in range(2):
+        r = A.fetch_unlabelled(4)
+        A.update({r[0]: lab(r[0]), r[1]: 0, r[2]: lab(r[2]), r[3]: lab(r[3])})      # one unnameable per round
+    blob = pickle.dumps(A.state_dict())
+    want = [A.fetch_unlabelled(4)]
+    A.update({i: lab(i) for i in want[0]})
+    want.append(A.fetch_unlabelled(3))
+    mean_a = np.asarray(A.rel_mean).copy()
+    mvn_stream.GLOBAL.reset()                          # "another process"
+    B = ITAL(X, length_scale=0.85, device=dev)
+    B.load_state_dict(pickle.loads(blob))
+    assert B.gp.ind == A.gp.ind[: len(B.gp.ind)] and B.rounds == 2 and len(B.unnameable_ids) == 2
+    got = [B.fetch_unlabelled(4)]
+    B.update({i: lab(i) for i in got[0]})
+    got.append(B.fetch_unlabelled(3))
+    assert got == want
+    np.testing.assert_allclose(np.asarray(B.rel_mean), mean_a, rtol=0, atol=1e-12)
+    with pytest.raises(ValueError):
+        ITAL(X, length_scale=0.5, device=dev).load_state_dict(pickle.loads(blob))

@@ -263,3 +263,13 @@ def test_score_workspace_size():
         assert lib.ital_score_workspace(t, 1000) == 1000 * per_cand
     assert lib.ital_score_workspace(2, 10) == 0 and lib.ital_score_workspace(9, 10) == 0
     assert lib.ital_topk_workspace() > 4096 * 8
+
+
+def test_host_side_under_address_and_ub_sanitizers():
+    """tools/asan_host.sh: the library's host code (argument validation of every entry point, descriptor handling, the
+    stream bookkeeping, the walker of numpy's generator, the RCCL lookup) built with -fsanitize=address,undefined and driven
+    by tests/host_asan_driver.cpp on the CPU.  (GPU ASan is not available on the pool; the device code is never launched.)"""
+    import subprocess
+    res = subprocess.run([os.path.join(ROOT, "tools", "asan_host.sh")], capture_output=True, text=True, timeout=900)
+    assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-4000:]
+    assert "OK host side under ASan + UBSan" in res.stdout
