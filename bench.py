@@ -495,35 +495,35 @@ def main():
         mvn_stream.GLOBAL.reset()
         learner.update({0: 1})
 
+    # a serving process freezes its start-up heap (ital_amd.serving_mode()): without this CPython's generation-2 collector
+    # walks torch's ~10^5 objects once every few rounds (a 40 ms pause, measured: ten 3.4 ms rounds cost 73 ms), which has
+    # nothing to do with the path under test; the figure without it is measured after the timed region
+    # (ms_per_step_unfrozen_heap).  Done BEFORE the warm-up: the collection itself takes ~0.1 s during which the GPU idles
+    # and drops its clocks -- between warm-up and timed loop it cost the first eight timed rounds 0.1 - 0.9 ms each
+    # (3.6, 3.2, 3.1, 3.0 ... 2.7 ms)
+    import ital_amd
+    ital_amd.serving_mode()
+    # timing events are created before the warm-up too (creating one costs ~0.3 ms on a loaded host: GPU idle time again) and
+    # only recorded inside the timed region: one pair per round, around the dominant kernel -- not more than needed (round 2's pool
+    # of 1280 events took 0.4 s to create)
+    use_events = not os.environ.get("ITAL_BENCH_NO_EVENTS")
+    pool = [torch.cuda.Event(enable_timing=True) for _ in range(2 * (args.steps + 2) if use_events else 0)]
+    for ev in pool:
+        ev.record()          # creates the handle (the library records them itself, around single kernels)
+    # the GPU has idled through the CPU baseline, the imports and the collection above and sits at low clocks: rounds of the
+    # workload until 0.1 s have passed bring them up (the ramp was measured to take ~8 rounds = 25 ms), then the W warm-up rounds
+    restart()
+    preheat, t_pre = 0, time.perf_counter()
+    while time.perf_counter() - t_pre < 0.1:
+        one_round()
+        preheat += 1
     restart()
     for _ in range(args.warmup):
         one_round()
-    # the same K steps once with the interpreter's heap as it is (reported next to the headline, not as the headline)
     restart()
-    barrier()
-    t0 = time.perf_counter()
-    marks_u = []
-    for _ in range(args.steps):
-        one_round()
-        marks_u.append(time.perf_counter())
-    barrier()
-    dt_unfrozen = time.perf_counter() - t0
-    restart()
-    learner.profile = None if os.environ.get("ITAL_BENCH_NO_EVENTS") else []
+    learner.profile = [] if use_events else None
     learner.profile_steps = {BATCH}      # events around the dominant kernel only (every record is a barrier packet in the queue)
-    # timing events are created before the timed region (only recorded inside it): one pair per round, around the dominant
-    # kernel.  Not more than needed: a pool of 1280 events (8 per greedy step), each recorded once to create its handle,
-    # slowed the first ~8 rounds of the timed loop down by up to 1 ms each (3.8, 3.2, 3.1 ... 2.7 ms; the runtime works
-    # through the pending signals), 0.13 ms on the average of 20 steps -- measured with and without any event being used
-    n_events = 0 if learner.profile is None else 2 * (args.steps + 2)
-    learner.event_pool = [torch.cuda.Event(enable_timing=True) for _ in range(n_events)]
-    for ev in learner.event_pool:
-        ev.record()          # creates the handle (the library records them itself, around single kernels)
-    # a serving process freezes its start-up heap (ital_amd.serving_mode()): without this CPython's generation-2 collector
-    # walks torch's ~10^5 objects once every few rounds (a 40 ms pause, measured: ten 3.4 ms rounds cost 73 ms), which has
-    # nothing to do with the path under test; the figure without it is reported as ms_per_step_unfrozen_heap
-    import ital_amd
-    ital_amd.serving_mode()
+    learner.event_pool = pool
     from ital_amd import _lib
     rows_local = learner.gp.n
     scored = 0
@@ -538,10 +538,24 @@ def main():
         marks.append(time.perf_counter())
     barrier()
     dt = time.perf_counter() - t0
+    launches_end = _lib.lib().ital_launch_count()
+    # the same K steps with the interpreter's heap as a process that never froze it has it (reported next to the headline)
+    prof_timed, learner.profile = learner.profile, None
+    gc.unfreeze()
+    restart()
+    barrier()
+    tu = time.perf_counter()
+    marks_u = []
+    for _ in range(args.steps):
+        one_round()
+        marks_u.append(time.perf_counter())
+    barrier()
+    dt_unfrozen = time.perf_counter() - tu
+    learner.profile = prof_timed
     if os.environ.get("ITAL_BENCH_STEP_TIMES"):
         print("step ms (timed):    " + " ".join("%.2f" % ((b_ - a_) * 1e3) for a_, b_ in zip([t0] + marks[:-1], marks)), file=sys.stderr)
-        print("step ms (unfrozen): " + " ".join("%.2f" % ((b_ - a_) * 1e3) for a_, b_ in zip(marks_u[:-1], marks_u[1:])), file=sys.stderr)
-    launches = (_lib.lib().ital_launch_count() - launches0) / args.steps
+        print("step ms (unfrozen): " + " ".join("%.2f" % ((b_ - a_) * 1e3) for a_, b_ in zip([tu] + marks_u[:-1], marks_u)), file=sys.stderr)
+    launches = (launches_end - launches0) / args.steps
     if world > 1:
         import torch.distributed as dist
         tt = torch.tensor([dt, dt_unfrozen], dtype=torch.float64, device=device)
@@ -619,7 +633,7 @@ def main():
                "roofline": roof, "roofline_hbm": hbm_stream_probe(device) if world == 1 else roof_hbm,
                "roofline_hbm_at_workload_size": roof_hbm,
                "kernel_ms": {"%s_t%d" % k: float(np.mean([d for d, _ in v])) * 1e3 for k, v in sorted(prof.items())},
-               "ms_per_step_unfrozen_heap": dt_unfrozen / args.steps * 1e3,
+               "ms_per_step_unfrozen_heap": dt_unfrozen / args.steps * 1e3, "preheat_rounds_before_warmup": preheat,
                "library_launches_per_step": launches, "round_gaps": round_gaps(),
                "scaling_workload": scale}
         if scale is not None:
