@@ -309,16 +309,22 @@ def k8_workload(device, n=25000, d=512, k=8):
            "config": "synthetic %d x %d, k=%d, perfect user, full 2^t enumeration (BASELINE.json configs[2], SURVEY 8d C3')" % (n, d, k),
            "kernel_ms": {"%s_t%d" % key: v[0] * 1e3 for key, v in sorted(prof.items())}}
     roofs = {}
-    for t in (7, 8):
-        if ("qmc_main", t) in prof:
-            sec, n_cand = prof[("qmc_main", t)]
-            pairs = qmc_pairs(t, n_cand)
-            ach = pairs * FLOP_PER_PAIR / sec / 1e12
-            roofs["qmc_main_kernel<%d>" % t] = dict(
-                {"bound": "fp64-valu", "achieved": ach, "peak": FP64_VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
-                 "frac": ach / FP64_VALU_PEAK_TFLOPS, "avg_launch_ms": sec * 1e3, "pairs_per_s": pairs / sec,
-                 "algorithmic_pairs_per_launch": pairs},
-                **pmc_fields("k8", "void ital::qmc_main_kernel<%d>" % t, sec))
+    for (name, t), (sec, n_cand) in sorted(prof.items()):
+        if t < 7 or not name.startswith("qmc_"):
+            continue
+        # the candidates of a step are walked in slabs of the 1 GiB workspace (150 KB of prepared calls per candidate at
+        # t = 8): the event pair spans first .. last lattice-sum launch of the step
+        slabs = int(name[len("qmc_slabs"):]) if name.startswith("qmc_slabs") else 1
+        pairs = qmc_pairs(t, n_cand)
+        ach = pairs * FLOP_PER_PAIR / sec / 1e12
+        pm = pmc_fields("k8", "void ital::qmc_main_kernel<%d>" % t, sec / slabs)
+        roofs["qmc_main_kernel<%d>" % t] = dict(
+            {"bound": "fp64-valu", "achieved": ach, "peak": FP64_VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
+             "frac": ach / FP64_VALU_PEAK_TFLOPS, "launches_per_step": slabs, "avg_launch_ms": sec * 1e3 / slabs,
+             "step_ms": sec * 1e3, "pairs_per_s": pairs / sec, "algorithmic_pairs_per_step": pairs,
+             "note": "time = first to last lattice-sum launch of the step (HIP events recorded by the library), incl. the "
+                     "preparation / combine launches between the slabs (~0.5 %); counters per launch from the committed pass"},
+            **pm)
     res["roofline"] = roofs
     del L
     gc.collect()
