@@ -232,7 +232,8 @@ typedef struct ital_score_desc {
     int sel_m, sel_ldw;
     int sel_rank;
     double* sel_record;     /* scratch: ITAL_REC_HEADER + ldx + ldw + kmax doubles */
-    int64_t* sel_ret;       /* [kmax + 1] as ital_select_fused */
+    int64_t* sel_ret;       /* [kmax + 1] as ital_select_fused; NULL: stop after the record (what ital_select_local leaves in
+                               sel_record: several ranks exchange it and call ital_select_resolve) */
     double* sel_parts;      /* scratch: 3 doubles per block of the step's scoring launches (t = 1: n_cand / 256, t = 2:
                                n_cand / 32, t >= 3: n_cand / 256 + one per slab, rounded up) */
     int64_t sel_parts_len;  /* doubles in sel_parts */

@@ -52,6 +52,19 @@ struct HotK {
     }
 };
 
+// Only the exp coefficients as register operands (every chain evaluates exp once per stage; the logarithm only runs in the
+// compacted tail branch of Phi^-1, once per stage and wave): 18 vector registers less than HotK.
+struct HotKE {
+    double e[10];
+    __device__ __forceinline__ void load() {
+        e[0] = opaque_v(2.5100375832561321544e-8); e[1] = opaque_v(2.7620075879983480862e-7);
+        e[2] = opaque_v(2.7557268480310025341e-6); e[3] = opaque_v(0.000024801521322368693026);
+        e[4] = opaque_v(0.00019841269863040545271); e[5] = opaque_v(0.0013888888917196719077);
+        e[6] = opaque_v(0.0083333333333300644495); e[7] = opaque_v(0.041666666666624161903);
+        e[8] = opaque_v(0.16666666666666667452); e[9] = opaque_v(0.50000000000000010211);
+    }
+};
+
 // The same coefficients as opaque SCALAR-register values: for the kernels that read their factor from LDS (T >= 7 of
 // the perfect-user scorer) the scalar file has room for them, and the 38 vector registers go to the chains instead
 // (one scalar operand per v_fma_f64 is what gfx9 encodes).
@@ -149,6 +162,7 @@ __device__ __forceinline__ double log_pos(double x) {
 }
 
 __device__ __forceinline__ double log_pos(double x, const LitK&) { return log_pos(x); }
+__device__ __forceinline__ double log_pos(double x, const HotKE&) { return log_pos(x); }
 template <class KT>
 __device__ __forceinline__ double log_pos(double x, const KT& k) {
     const double LN2_HI = 6.93147180369123816490e-01, LN2_LO = 1.90821492927058770002e-10;

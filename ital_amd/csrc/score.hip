@@ -44,6 +44,9 @@
 #ifndef ITAL_QMC_MAIN_PS
 #define ITAL_QMC_MAIN_PS(T) ((T) >= 7)   // lattice coordinates formed per stage (qmc_lane_sum_ps): T = 7, 8 spill otherwise
 #endif
+#ifndef ITAL_QMC_MAIN_KE
+#define ITAL_QMC_MAIN_KE(T) 0            // only the exp coefficients as register operands (log: literals)
+#endif
 #ifndef ITAL_QMC_MAIN_KS
 #define ITAL_QMC_MAIN_KS(T) 0            // exp / log coefficients as scalar-register operands (measured: +7 % at t = 8, dropped)
 #endif
@@ -218,7 +221,8 @@ struct Qmc {
     static constexpr bool PS = ITAL_QMC_MAIN_PS(T), CFL = PS && ITAL_QMC_MAIN_CFL(T);
     static constexpr int WAVE_DOUBLES = LAT + TAILQ + (CFL ? NCOR + T : 0);
     // exp / log coefficients: vector-register operands, or scalar ones where the factor does not occupy the scalar file
-    typedef typename std::conditional<(CFL && ITAL_QMC_MAIN_KS(T)), HotKS, HotK>::type Coef;
+    typedef typename std::conditional<(CFL && ITAL_QMC_MAIN_KS(T)), HotKS,
+                                      typename std::conditional<(ITAL_QMC_MAIN_KE(T)), HotKE, HotK>::type>::type Coef;
     static constexpr int64_t CAND_DOUBLES = (int64_t)NPAT * (REC + 1) + 3;   // records, terms, 6 ints of generator state
 };
 // meta word of a record: bit 0 evaluate the lattice sum; bit 1 prior probability == 1 (else 0) when not evaluated;
@@ -637,8 +641,8 @@ extern "C" int ital_score_step(const ital_score_desc* d, hipStream_t stream) {
     for (int i = 0; i < 6; i++) a.seed[i] = d->seed[i];
     if (d->sel_record) {
         // the selection of this step as the tail of its last scoring launch (what ital_select_fused does separately)
-        if (!d->sel_ret || !d->sel_parts || !d->sel_counter || !d->sel_X || !d->sel_xnorm || (d->sel_m > 0 && !d->sel_V))
-            return ital_fail(-22, "ital_score_step: fused selection needs sel_ret, sel_parts, sel_counter, sel_X, sel_xnorm, sel_V");
+        if (!d->sel_parts || !d->sel_counter || !d->sel_X || !d->sel_xnorm || (d->sel_m > 0 && !d->sel_V))
+            return ital_fail(-22, "ital_score_step: fused selection needs sel_parts, sel_counter, sel_X, sel_xnorm, sel_V");
         if (d->sel_m > d->sel_ldw || d->sel_ldx != d->batch.ldx || d->sel_ldw != d->batch.ldw)
             return ital_fail(-22, "ital_score_step: fused selection: batch layout mismatch");
         a.sel.rec = {d->cand, d->pos_offset, d->gpos, d->row_offset, d->sel_rank, 0, 0, d->mu, d->s2, d->sel_X, d->sel_xnorm,

@@ -180,7 +180,7 @@ struct SelectTail {
     int slot;
     ital_batch b;
     uint8_t* alive;
-    int64_t* ret;
+    int64_t* ret;            // nullptr: stop after the record (what ital_select_local does)
     double* parts;           // [3 * nparts] block partials
     unsigned int* counter;   // ticket counter, zero before the launch; reset by the finishing block
     int enabled;
@@ -213,6 +213,10 @@ static __device__ void select_tail(const SelectTail& s, Best v, int part, int np
     }
     w = block_best(w, s.rec.mode);
     record_body(s.rec, w);
+    if (!s.ret) {                       // several ranks: the record goes into the exchange, ital_select_resolve follows
+        if (threadIdx.x == 0) *s.counter = 0;
+        return;
+    }
     __threadfence_block();
     __syncthreads();
     const int rec_len = ITAL_REC_HEADER + s.rec.ldx + s.rec.ldw + s.rec.kmax;

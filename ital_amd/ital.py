@@ -307,25 +307,26 @@ class ITAL(ActiveRetrievalBase):
                         slabs = -(-n_loc // max(work.numel() // int(lib.ital_score_workspace(t, 1)), 1))
                         self.profile.append(("qmc_main" if slabs == 1 else "qmc_slabs%d" % slabs, t, n_alive, k0, k1))
                 fused = not gp.collective and 0 < n_loc <= _FUSED_SELECT_MAX
-                if fused and self.select_in_scorer:
-                    # one rank, small problem: the scoring launch ends with the selection itself (the block that finishes
-                    # last selects) -- no selection launch
+                tail = self.select_in_scorer and 0 < n_loc <= _FUSED_SELECT_MAX
+                if tail:
+                    # the scoring launch ends with the selection itself (the block that finishes last selects): one rank --
+                    # arg-max, record and batch bookkeeping, no selection launch at all; several ranks -- arg-max and record
+                    # (what ital_select_local does in a single-workgroup launch of its own), exchange and resolve follow
                     parts = b.get("sel_parts")
                     if parts is None or parts.numel() < 3 * (n_loc // 32 + 64):
                         b["sel_parts"] = parts = torch.empty(3 * (n_loc // 32 + 64), dtype=torch.float64, device=dev)
                         b["sel_counter"] = torch.zeros(1, dtype=torch.int32, device=dev)
                     desc.sel_X, desc.sel_xnorm, desc.sel_ldx = _ptr(gp.Xd), _ptr(gp.xnorm), gp.ldx
                     desc.sel_V, desc.sel_ldv, desc.sel_m, desc.sel_ldw, desc.sel_rank = _ptr(gp.V), gp.ldv, gp.m, gp.cap, gp.rank
-                    desc.sel_record, desc.sel_ret = _ptr(b["rec"]), _ptr(b["ret"])
+                    desc.sel_record, desc.sel_ret = _ptr(b["rec"]), (_ptr(b["ret"]) if fused else None)
                     desc.sel_parts, desc.sel_parts_len, desc.sel_counter = _ptr(parts), parts.numel(), _ptr(b["sel_counter"])
-                    fused = None
                 ev0 = self._mark() if t < 3 else None
                 check(lib.ital_score_step(ctypes.byref(desc), st))
                 if t < 3:
                     self._mark("score", t, n_alive, ev0)
                 if self.keep_scores:
                     self.last_scores.append(mi.clone())
-                if fused is None:
+                if tail and fused:
                     pass
                 elif fused:
                     check(lib.ital_select_fused(_ptr(mi), _ptr(cand_d), _ptr(alive), n_loc, pos_offset, _ptr(gpos_d), gp.row0,
@@ -333,10 +334,11 @@ class ITAL(ActiveRetrievalBase):
                                                 _ptr(gp.V), gp.ldv, gp.m, gp.cap, _ptr(b["C"]), gp.ldv, t - 1, t - 1, b["batch"],
                                                 _ptr(gp.status), _ptr(b["rec"]), _ptr(b["ret"]), st))
                 else:
-                    check(lib.ital_select_local(_ptr(mi), _ptr(cand_d), _ptr(alive), n_loc, pos_offset, _ptr(gpos_d), gp.row0,
-                                                gp.rank, 0, _ptr(gp.mu), _ptr(gp.s2), _ptr(gp.Xd), _ptr(gp.xnorm), gp.ldx,
-                                                _ptr(gp.V), gp.ldv, gp.m, gp.cap, _ptr(b["C"]), gp.ldv, t - 1, b["kmax"],
-                                                _ptr(gp.status), _ptr(b["work"]), _ptr(b["rec"]), st))
+                    if not tail:
+                        check(lib.ital_select_local(_ptr(mi), _ptr(cand_d), _ptr(alive), n_loc, pos_offset, _ptr(gpos_d), gp.row0,
+                                                    gp.rank, 0, _ptr(gp.mu), _ptr(gp.s2), _ptr(gp.Xd), _ptr(gp.xnorm), gp.ldx,
+                                                    _ptr(gp.V), gp.ldv, gp.m, gp.cap, _ptr(b["C"]), gp.ldv, t - 1, b["kmax"],
+                                                    _ptr(gp.status), _ptr(b["work"]), _ptr(b["rec"]), st))
                     if gp.collective:
                         ev0 = self._mark()
                         recs = sharding.gather_records(b["rec"], b["rec_all"], gp.group)
