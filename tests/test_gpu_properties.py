@@ -326,7 +326,7 @@ def test_state_dict_resumes_a_session(dev):
     mvn_stream.GLOBAL.reset()                          # "another process"
     B = ITAL(X, length_scale=0.85, device=dev)
     B.load_state_dict(pickle.loads(blob))
-    assert B.gp.ind == A.gp.ind[: len(B.gp.ind)] and B.rounds == 2 and len(B.unnameable_ids) == 2
+    assert B.gp.ind == A.gp.ind[: len(B.gp.ind)] and B.rounds == 3 and len(B.unnameable_ids) == 2
     got = [B.fetch_unlabelled(4)]
     B.update({i: lab(i) for i in got[0]})
     got.append(B.fetch_unlabelled(3))
