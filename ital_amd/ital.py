@@ -28,6 +28,7 @@ from .retrieval_base import ActiveRetrievalBase
 
 _LABEL_MODES = {"mean": 0, "optimistic": 1, "pessimistic": 2}
 _HOST_THREADS = max(1, min(16, os.cpu_count() or 1))   # host share of one GPU (Monte-Carlo pattern sampling)
+_MC_CHUNKS, _MC_CHUNK_MIN = 8, 4096   # pattern sampling: ranges per greedy step (host / GPU overlap) and their minimum size
 _FUSED_SELECT_MAX = 1 << 18   # one rank, up to this many candidates: arg-max + record + resolve in a single launch
 
 
@@ -597,9 +598,13 @@ class ITAL(ActiveRetrievalBase):
                         pick_pos = list(range(t - 1))
                         e_mu[: t - 1] = b["bmu"][: t - 1].cpu().numpy()
                         e_sig[: t - 1, : t - 1] = b["sig"].view(kmax, kmax)[: t - 1, : t - 1].cpu().numpy()
+                    # pattern sampling alone on a large shard: the step is scored in ranges of candidates, the SVDs of the
+                    # next range on the host under the lattice sums of the current one
+                    n_chunks = _MC_CHUNKS if (rel_mc and not fb_mc and not subset_mode and not clip_count and runs
+                                              and gpos_d is None and n_loc >= _MC_CHUNK_MIN * _MC_CHUNKS) else 0
                     mc = self._mc_samples(nr, npat, rel_mc, fb_mc, nfb, fb_mode, cand, picks, pos_of,
                                           E if subset_mode else picks, pick_pos, e_mu, e_sig, C, subset_mode, z_next,
-                                          (pos_offset, pos_offset + n_loc) if runs else None)
+                                          (pos_offset, pos_offset + n_loc) if runs else None, n_chunks)
                 z_next = None
                 desc = ItalGscoreDesc()
                 desc.n_cand = n_loc
@@ -650,11 +655,14 @@ class ITAL(ActiveRetrievalBase):
                         b["qmc_work"] = w = torch.empty(want, dtype=torch.float64, device=dev)
                     desc.work, desc.work_doubles = _ptr(w), w.numel()
                 total_draws = None
+                rel_ranges = None
                 if mc is None and self.keep_scores:
                     self.last_patterns.append(None)          # this step enumerates its patterns
                 if mc is not None:
                     rel_arr, fb_arr, draws_pp = mc          # per list position (dead positions hold zeros)
-                    if self.keep_scores:
+                    if rel_arr is not None and not isinstance(rel_arr, np.ndarray):
+                        rel_ranges, rel_arr = rel_arr, None     # generator of (lo, hi, rows): consumed at the launches below
+                    if self.keep_scores and rel_ranges is None:
                         self.last_patterns.append(rel_arr)
                     if gpos_d is None:
                         mine = slice(pos_offset, pos_offset + max(n_loc, 1))
@@ -698,7 +706,41 @@ class ITAL(ActiveRetrievalBase):
                     keep += [counts, t_off]
                     desc.draw_off = _ptr(t_off)
                 ev0 = self._mark()
-                check(lib.ital_score_generic(ctypes.byref(desc), st))
+                if rel_ranges is None:
+                    check(lib.ital_score_generic(ctypes.byref(desc), st))
+                else:
+                    # one call per range of candidates: patterns of range r + 1 are decomposed on the host (LAPACK, thread
+                    # pool) while the GPU integrates range r; the uploads go through page-locked memory on a stream of
+                    # their own (a pageable copy would wait for the scorer in front of it)
+                    if b.get("mc_pin") is None or b["mc_pin"].shape[0] < n_loc or b["mc_pin"].shape[1] < npat:
+                        b["mc_pin"] = torch.empty((n_loc, ITAL_GENERIC_MAX_REL), dtype=torch.int32).pin_memory()
+                        b["mc_dev"] = torch.empty((n_loc, ITAL_GENERIC_MAX_REL), dtype=torch.int32, device=dev)
+                        b["mc_stream"] = torch.cuda.Stream(device=dev)
+                    pin, t_rel, side = b["mc_pin"], b["mc_dev"], b["mc_stream"]
+                    main = torch.cuda.current_stream(dev)
+                    side.wait_stream(main)                   # earlier readers of the device buffer (the step before) are done
+                    kept = np.zeros((len(cand), npat), dtype=np.uint32) if self.keep_scores else None
+                    base = {f: getattr(desc, f) for f in ("cand", "alive", "mi", "draw_off", "pos_offset")}
+                    for lo, hi, rows in rel_ranges:
+                        a, e = lo - pos_offset, hi - pos_offset
+                        flat = pin.view(-1)[a * npat:e * npat]
+                        flat.copy_(torch.from_numpy(rows.view(np.int32).reshape(-1)))
+                        dflat = t_rel.view(-1)[a * npat:e * npat]
+                        with torch.cuda.stream(side):
+                            dflat.copy_(flat, non_blocking=True)
+                        up = torch.cuda.Event()
+                        up.record(side)
+                        main.wait_event(up)
+                        desc.n_cand = e - a
+                        desc.cand, desc.alive = base["cand"] + 4 * a, base["alive"] + a
+                        desc.mi, desc.draw_off = base["mi"] + 8 * a, base["draw_off"] + 8 * a
+                        desc.pos_offset = base["pos_offset"] + a
+                        desc.mc_rel, desc.rel_samples = npat, dflat.data_ptr()
+                        check(lib.ital_score_generic(ctypes.byref(desc), st))
+                        if kept is not None:
+                            kept[lo:hi] = rows
+                    if kept is not None:
+                        self.last_patterns.append(kept)
                 self._mark("score_generic", t, n_alive, ev0)
                 if self.keep_scores:
                     self.last_scores.append(mi.clone())
@@ -800,12 +842,15 @@ class ITAL(ActiveRetrievalBase):
         return z
 
     def _mc_samples(self, nr, npat, rel_mc, fb_mc, nfb, fb_mode, cand, picks, pos_of, E, pick_pos, e_mu, e_sig, C, subset_mode,
-                    z_rel=None, local=None):
+                    z_rel=None, local=None, chunks=0):
         """Sign patterns / feedback configurations of the Monte-Carlo switches, drawn from numpy's global RNG in the
         reference's serial order (per live candidate: one multivariate_normal.rvs, ital.py:297; per pattern one
         np.random.choice, ital.py:323-337).  `z_rel`: the standard normals of this step when the caller drew them ahead
         (pattern sampling only); `local`: list positions [lo, hi) whose patterns this rank reads.  Returns per list position: patterns [P, npat] uint32 (or None), feedback
-        [P, npat, nfb] uint32 (or None), uniforms of mvndst's stream consumed [P] int64."""
+        [P, npat, nfb] uint32 (or None), uniforms of mvndst's stream consumed [P] int64.
+        `chunks` > 0 (pattern sampling alone, `local` given): the patterns come back as a generator of (lo, hi, rows) over
+        `chunks` consecutive ranges of the local list positions -- the per-candidate decompositions of a range are only done
+        when it is asked for, so the caller can score one range on the GPU while the host prepares the next."""
         gp = self.gp
         P = len(cand)
         dead = np.zeros(P, dtype=bool)
@@ -919,6 +964,19 @@ class ITAL(ActiveRetrievalBase):
             else:
                 g0, z = z_rel                                       # drawn ahead for live ranks g0 .. g0 + len(z) - 1
                 z_loc = z[jl0 - g0:jl1 - g0]
+            if chunks > 0 and local is not None and jl1 > jl0:
+                draws = np.zeros(P, dtype=np.int64)
+                draws[live] = npat * (npre_draws[live] + nfb * d_full[live])
+
+                def ranges():
+                    cuts = np.unique(np.linspace(jl0, jl1, chunks + 1).astype(np.int64))
+                    for a, b_ in zip(cuts[:-1], cuts[1:]):
+                        lo = local[0] if a == jl0 else int(live[a])
+                        hi = local[1] if b_ == jl1 else int(live[b_])
+                        rows = np.zeros((hi - lo, npat), dtype=np.uint32)
+                        rows[live[a:b_] - lo] = draw_rel(int(a), int(b_), z_loc[a - jl0:b_ - jl0])
+                        yield lo, hi, rows
+                return ranges(), None, draws
             rel_live = np.zeros((L, npat), dtype=np.uint32)
             if jl1 > jl0:
                 rel_live[jl0:jl1] = draw_rel(jl0, jl1, z_loc)
