@@ -298,10 +298,11 @@ __device__ __forceinline__ double qmc_lane_sum_ps(const double* __restrict__ lat
 // LDS at use (`slab`: packed lower triangle with diagonal, then the limits -- the evaluator's record), the lattice
 // coordinates are formed per stage instead of up front; the conditioned values y (2 NH chains x T-1) stay in registers
 // because every index is a compile-time constant.
-template <int T, int NCB>
+template <int T, int NCB, class K>
 __device__ __forceinline__ double eval_chains_big(const int (&kk)[NCB], const int (&so)[NCB], const bool (&anti)[NCB],
                                                   const bool (&ok)[NCB], const double* __restrict__ lat,
-                                                  const double* __restrict__ slab, unsigned infi_c, double* tailq, int lane) {
+                                                  const double* __restrict__ slab, unsigned infi_c, double* tailq, int lane,
+                                                  const K& coef) {
     constexpr int NDIM = T - 1, NCOV = T * (T + 1) / 2;
     double yy[NCB][NDIM], ff[NCB];
 #pragma unroll
@@ -324,7 +325,7 @@ __device__ __forceinline__ double eval_chains_big(const int (&kk)[NCB], const in
         double pin[NCB];
 #pragma unroll
         for (int c = 0; c < NCB; c++) {
-            const double ph = mvn_phi(lmi - sc[c]);
+            const double ph = mvn_phi(lmi - sc[c], coef);
             const double d = lower ? ph : 0.0;
             const double w = lower ? 1.0 - ph : ph;
             ff[c] *= w;
@@ -337,7 +338,7 @@ __device__ __forceinline__ double eval_chains_big(const int (&kk)[NCB], const in
         }
         if (i < T - 1) {
             double out[NCB];
-            phinv_wave<NCB>(pin, out, tailq, lane);
+            phinv_wave<NCB>(pin, out, tailq, lane, coef);
 #pragma unroll
             for (int c = 0; c < NCB; c++) yy[c][i] = out[c];
         }
@@ -350,9 +351,9 @@ __device__ __forceinline__ double eval_chains_big(const int (&kk)[NCB], const in
 
 // NCB chains per lane and round: whole lattice items (a point and its antithetic partner on the same lane) first; with an
 // odd NCB the last chain of lanes 2i and 2i + 1 is the point and the partner of one more item (32 NCB items per round).
-template <int T, int NCB>
+template <int T, int NCB, class K = LitK>
 __device__ __forceinline__ double qmc_lane_sum_big(const double* __restrict__ lat, const double* __restrict__ slab,
-                                                   unsigned infi_c, double* __restrict__ tailq, int lane) {
+                                                   unsigned infi_c, double* __restrict__ tailq, int lane, const K& coef = K()) {
     constexpr int NDIM = T - 1, PRIME = P_TAB[(NDIM < 10 ? NDIM : 10) - 1];
     constexpr int NITEM = 8 * PRIME, PER_ROUND = 32 * NCB;
     double acc = 0.0;
@@ -370,7 +371,7 @@ __device__ __forceinline__ double qmc_lane_sum_big(const double* __restrict__ la
             kk[c] = it - sft * PRIME + 1;
             so[c] = sft * NDIM;
         }
-        acc += eval_chains_big<T, NCB>(kk, so, anti, ok, lat, slab, infi_c, tailq, lane);
+        acc += eval_chains_big<T, NCB>(kk, so, anti, ok, lat, slab, infi_c, tailq, lane, coef);
     }
     return acc;
 }

@@ -55,6 +55,9 @@
 // 15 / 16: two (three spill 63 / 76 registers: +3 % / +20 %)
 #define ITAL_GEN_BIG_NCB(T) ((T) <= 10 ? 4 : (T) <= 14 ? 3 : 2)
 #endif
+#ifndef ITAL_GEN_BIG_HOTK
+#define ITAL_GEN_BIG_HOTK 1
+#endif
 #ifndef ITAL_GEN_FIXED_NH
 // lattice items per lane and round of the pipeline's evaluator for 3 .. 6 variables: three (six chains) at 5 and 6
 // variables, which then run at two waves per SIMD (per step at 40 000 x 512: 13.6 -> 11.3 ms, 26.5 -> 20.5 ms; four items
@@ -1174,8 +1177,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(ITAL_GEN_MA
         double value;
         if (T >= 7) {
             constexpr int TB = T >= 7 ? T : 7, NDIMB = TB - 1;
+#if ITAL_GEN_BIG_HOTK
+            HotK kk;      // exp / log coefficients as vector-register operands (device_math.h), as in the perfect-user kernel
+            kk.load();
+            value = wave_sum(qmc_lane_sum_big<TB, ITAL_GEN_BIG_NCB(TB), HotK>(rec + g.lat, rec, infi, tailq, lane, kk)) /
+                    (16.0 * P_TAB[(NDIMB < 10 ? NDIMB : 10) - 1]);
+#else
             value = wave_sum(qmc_lane_sum_big<TB, ITAL_GEN_BIG_NCB(TB)>(rec + g.lat, rec, infi, tailq, lane)) /
                     (16.0 * P_TAB[(NDIMB < 10 ? NDIMB : 10) - 1]);
+#endif
         } else if (T > 0) {
             constexpr int TF = T > 0 && T < 7 ? T : 3;
             value = qmc_eval_fixed_inl<TF, ITAL_GEN_FIXED_NH(TF)>(rec, infi, rec + g.lat, lane, tailq);

@@ -28,7 +28,18 @@ from .retrieval_base import ActiveRetrievalBase
 
 _LABEL_MODES = {"mean": 0, "optimistic": 1, "pessimistic": 2}
 _HOST_THREADS = max(1, min(16, os.cpu_count() or 1))   # host share of one GPU (Monte-Carlo pattern sampling)
-_MC_CHUNKS, _MC_CHUNK_MIN = 8, 4096   # pattern sampling: ranges per greedy step (host / GPU overlap) and their minimum size
+# pattern sampling: ranges of candidates per greedy step (host / GPU overlap), their minimum size, and the number of
+# variables from which a step is split at all (below, the step's lattice sums are shorter than the host's decompositions:
+# measured at 125 000 x 512, nothing to hide behind)
+_MC_CHUNKS, _MC_CHUNK_MIN, _MC_CHUNK_FROM = 4, 8192, 10
+_POOL = None
+
+
+def _host_pool():
+    global _POOL
+    if _POOL is None:
+        _POOL = ThreadPoolExecutor(_HOST_THREADS)
+    return _POOL
 _FUSED_SELECT_MAX = 1 << 18   # one rank, up to this many candidates: arg-max + record + resolve in a single launch
 
 
@@ -601,7 +612,8 @@ class ITAL(ActiveRetrievalBase):
                     # pattern sampling alone on a large shard: the step is scored in ranges of candidates, the SVDs of the
                     # next range on the host under the lattice sums of the current one
                     n_chunks = _MC_CHUNKS if (rel_mc and not fb_mc and not subset_mode and not clip_count and runs
-                                              and gpos_d is None and n_loc >= _MC_CHUNK_MIN * _MC_CHUNKS) else 0
+                                              and gpos_d is None and nr >= _MC_CHUNK_FROM
+                                              and n_loc >= _MC_CHUNK_MIN * _MC_CHUNKS) else 0
                     mc = self._mc_samples(nr, npat, rel_mc, fb_mc, nfb, fb_mode, cand, picks, pos_of,
                                           E if subset_mode else picks, pick_pos, e_mu, e_sig, C, subset_mode, z_next,
                                           (pos_offset, pos_offset + n_loc) if runs else None, n_chunks)
@@ -721,7 +733,12 @@ class ITAL(ActiveRetrievalBase):
                     side.wait_stream(main)                   # earlier readers of the device buffer (the step before) are done
                     kept = np.zeros((len(cand), npat), dtype=np.uint32) if self.keep_scores else None
                     base = {f: getattr(desc, f) for f in ("cand", "alive", "mi", "draw_off", "pos_offset")}
+                    dbg = os.environ.get("ITAL_MC_TIMING")
+                    tq = time.perf_counter()
                     for lo, hi, rows in rel_ranges:
+                        if dbg:
+                            t_rows = time.perf_counter() - tq
+                            tq = time.perf_counter()
                         a, e = lo - pos_offset, hi - pos_offset
                         flat = pin.view(-1)[a * npat:e * npat]
                         flat.copy_(torch.from_numpy(rows.view(np.int32).reshape(-1)))
@@ -737,6 +754,10 @@ class ITAL(ActiveRetrievalBase):
                         desc.pos_offset = base["pos_offset"] + a
                         desc.mc_rel, desc.rel_samples = npat, dflat.data_ptr()
                         check(lib.ital_score_generic(ctypes.byref(desc), st))
+                        if dbg:
+                            print("t=%d range %d..%d: patterns %.1f ms, upload + launch %.1f ms" % (
+                                t, lo, hi, t_rows * 1e3, (time.perf_counter() - tq) * 1e3), flush=True)
+                            tq = time.perf_counter()
                         if kept is not None:
                             kept[lo:hi] = rows
                     if kept is not None:
@@ -892,22 +913,27 @@ class ITAL(ActiveRetrievalBase):
             else:
                 s2_all, rows_l = gp._full(gp.s2), rows
                 cpick = np.stack([gp._full(C[b]) for b in pp]) if pp else np.zeros((0, gp.n_total))
-            mean = np.empty((len(rows), nr))
-            cov = np.empty((len(rows), nr, nr))
-            mean[:, : nr - 1] = e_mu[pp][None, :] if pp else 0
-            cov[:, : nr - 1, : nr - 1] = e_sig[np.ix_(pp, pp)][None] if pp else 0
-            mean[:, nr - 1] = mu_all[rows]
-            cov[:, nr - 1, nr - 1] = s2_all[rows_l]
-            if pp:
-                cov[:, : nr - 1, nr - 1] = cpick[:, rows_l].T
-                cov[:, nr - 1, : nr - 1] = cpick[:, rows_l].T
-            if subset_mode:
-                for j in np.flatnonzero(in_e[live[jl0:jl1]] >= 0):  # members of the base set: covariances from E itself
-                    idx = pp + [int(in_e[live[jl0 + j]])]
-                    mean[j] = e_mu[idx]
-                    cov[j] = e_sig[np.ix_(idx, idx)]
-            elif nr == 1:
-                cov[:, 0, 0] = np.maximum(0, cov[:, 0, 0])         # first step: predict_stored(cov_mode='diag') (ital.py:558)
+
+            def moments(j0, j1):
+                """Mean [n, nr] and covariance [n, nr, nr] of (members so far, candidate) for live candidates j0 .. j1-1."""
+                rw, rl = rows[j0 - jl0:j1 - jl0], rows_l[j0 - jl0:j1 - jl0]
+                mean = np.empty((len(rw), nr))
+                cov = np.empty((len(rw), nr, nr))
+                mean[:, : nr - 1] = e_mu[pp][None, :] if pp else 0
+                cov[:, : nr - 1, : nr - 1] = e_sig[np.ix_(pp, pp)][None] if pp else 0
+                mean[:, nr - 1] = mu_all[rw]
+                cov[:, nr - 1, nr - 1] = s2_all[rl]
+                if pp:
+                    cov[:, : nr - 1, nr - 1] = cpick[:, rl].T
+                    cov[:, nr - 1, : nr - 1] = cov[:, : nr - 1, nr - 1]
+                if subset_mode:
+                    for j in np.flatnonzero(in_e[live[j0:j1]] >= 0):    # members of the base set: covariances from E itself
+                        idx = pp + [int(in_e[live[j0 + j]])]
+                        mean[j] = e_mu[idx]
+                        cov[j] = e_sig[np.ix_(idx, idx)]
+                elif nr == 1:
+                    cov[:, 0, 0] = np.maximum(0, cov[:, 0, 0])     # first step: predict_stored(cov_mode='diag') (ital.py:558)
+                return mean, cov
         weights = (1 << np.arange(nr - 1, -1, -1)).astype(np.uint32)   # variable v at bit nr-1-v
         if fb_mc:
             if fb_mode == 1:
@@ -921,8 +947,9 @@ class ITAL(ActiveRetrievalBase):
             cdf /= cdf[-1]
 
         def transform(z, j0, j1):
-            _, sv, vt = np.linalg.svd(cov[j0 - jl0:j1 - jl0])
-            x = z @ (np.sqrt(sv)[:, :, None] * vt) + mean[j0 - jl0:j1 - jl0, None, :]
+            mean, cov = moments(j0, j1)
+            _, sv, vt = np.linalg.svd(cov)
+            x = z @ (np.sqrt(sv)[:, :, None] * vt) + mean[:, None, :]
             return ((x > 0) * weights).sum(axis=2).astype(np.uint32)
 
         def draw_rel(j0, j1, z=None):
@@ -936,10 +963,9 @@ class ITAL(ActiveRetrievalBase):
             workers = min(_HOST_THREADS, n * nr * nr // 65536)
             if workers < 2:
                 return transform(z, j0, j1)
-            cuts = np.linspace(0, n, 4 * workers + 1).astype(np.int64)
-            with ThreadPoolExecutor(workers) as pool:
-                parts = list(pool.map(lambda ab: transform(z[ab[0]:ab[1]], j0 + ab[0], j0 + ab[1]),
-                                      zip(cuts[:-1], cuts[1:])))
+            cuts = np.linspace(0, n, 2 * workers + 1).astype(np.int64)
+            parts = list(_host_pool().map(lambda ab: transform(z[ab[0]:ab[1]], j0 + ab[0], j0 + ab[1]),
+                                          zip(cuts[:-1], cuts[1:])))
             return np.concatenate(parts)
 
         def draw_fb(pats):
