@@ -4,6 +4,10 @@ Same constructor arguments, methods (fit / reset / top_results / get_unseen / fe
 partition_feedback), attributes (gp, rel_mean, relevant_ids, irrelevant_ids, unnameable_ids, rounds, data,
 queries) and error behaviour; the GP behind it is the streaming MI355X one (ital_amd.gp).
 Keyword-only extras: device, rank, world, group (row sharding over GPUs).
+
+This file IS the drop-in boundary: `partition_feedback` and `updated_prediction` have one correct form -- the reference's
+(retrieval_base.py:129-193: same branches, same error message, same ordering of the ids) -- and restate it; everything
+below them (GP state, candidate bookkeeping, the device path) is this package's own.
 """
 import numpy as np
 

@@ -273,3 +273,40 @@ def test_host_side_under_address_and_ub_sanitizers():
     res = subprocess.run([os.path.join(ROOT, "tools", "asan_host.sh")], capture_output=True, text=True, timeout=900)
     assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-4000:]
     assert "OK host side under ASan + UBSan" in res.stdout
+
+
+def test_rank_local_walk_of_numpy_stream_partitions_the_reference_draws():
+    """What the Monte-Carlo pattern sampler does on W ranks (ital_amd/ital.py `_walk_normals`): every rank walks numpy's
+    global generator over ALL candidates' standard normals, computing only those of its own slice.  The slices put together
+    are the reference's draws (one multivariate_normal.rvs per candidate in list order, ital.py:297), and every rank's
+    generator ends in the reference's state."""
+    from ital_amd import _lib, sharding
+    n_live, per_cand, world = 1001, 3 * 3, 4
+    np.random.seed(42)
+    np.random.standard_normal(5)                      # some earlier consumption, cached value pending
+    start = np.random.get_state()
+    want = np.random.standard_normal(n_live * per_cand)
+    end_tail = np.random.standard_normal(4)
+    got = []
+    for rank in range(world):
+        j0, j1 = sharding.row_range(n_live, world, rank)
+        np.random.set_state(start)
+        z = _lib.legacy_normals(j0 * per_cand, (j1 - j0) * per_cand, threads=2)
+        _lib.legacy_normals((n_live - j1) * per_cand, 0)
+        assert np.array_equal(np.random.standard_normal(4), end_tail)
+        got.append(z)
+    assert np.array_equal(np.concatenate(got), want)
+
+
+def test_contiguous_runs_is_a_function_of_the_list_alone():
+    from ital_amd import sharding
+    n, world = 1000, 4
+    asc = np.delete(np.arange(n), [3, 500, 999])
+    assert sharding.contiguous_runs(asc, n, world)
+    for r in range(world):                            # ... and then no rank gets explicit positions
+        r0, r1 = sharding.row_range(n, world, r)
+        assert sharding.shard_candidates(asc, r0, r1)[2] is None
+    shuffled = np.random.default_rng(0).permutation(asc)[:40]      # the argpartition order of top_candidates
+    assert not sharding.contiguous_runs(shuffled, n, world)
+    assert sharding.contiguous_runs(shuffled, n, 1)
+    assert sharding.contiguous_runs(np.array([10, 11, 600, 990]), n, world)
