@@ -50,7 +50,7 @@ VALU_PER_PAIR_CHAIN = 47 + 0.85 * 45 + 0.15 * 121      # vector instructions of 
 FLOP_PER_MCMI_TERM = 53 + 2 * 44 + 6
 # committed counter summaries (rocprofv3 --pmc passes of this very command, tools/profile_gpu.sh + tools/pmc_summary.py):
 # HBM traffic and instruction counts per launch are read from these files and the file is named in the output
-PMC_FILES = {"headline": "profiles/r3_headline_pmc_summary.csv", "general": "profiles/r2_general_pmc_summary.csv",
+PMC_FILES = {"headline": "profiles/r3_headline_pmc_summary.csv", "general": "profiles/r3_general_pmc_summary.csv",
              "k8": "profiles/r3_k8_pmc_summary.csv"}
 ROUND_GAPS_FILE = "profiles/r3_round_gaps.json"   # launches / busy fraction of a round out of a committed kernel trace
 CALIBRATION_FILE = "profiles/r2_oracle_calibration.json"
