@@ -37,6 +37,12 @@ __device__ __forceinline__ double fast_div(double n, double d) {
 // instructions.  HotK holds the coefficients of exp and log as opaque vector-register values instead: the steps become
 // three-operand `v_fma_f64 p, p, r, K` with no copy (same 20 + 18 registers the parked literals took).
 struct LitK {};
+// A literal that is materialised WHERE IT IS USED, in a scalar register pair (two s_mov_b32 next to the consumer, which takes
+// it as its one scalar operand).  For coefficients of rarely executed branches inside hot loops -- the log / sqrt tail of
+// Phi^-1 runs once per stage and wave: left to itself the compiler treats its 39 coefficients as loop invariants, finds the
+// scalar file full and parks them in 78 vector registers for the whole kernel (and copies each into the accumulator of a
+// two-address v_fmac: 27 v_mov_b64 per pass).
+__device__ __forceinline__ double lit_s(double k) { asm volatile("" : "+s"(k)); return k; }
 __device__ __forceinline__ double opaque_v(double k) { asm volatile("" : "+v"(k)); return k; }
 struct HotK {
     double e[10];   // exp_neg: q(r) of exp(r) = 1 + r + r^2 q(r)
@@ -233,6 +239,15 @@ __device__ __forceinline__ double mvn_phi(double z, const K& kk) {
 
 __device__ __forceinline__ double mvn_phi(double z) { return mvn_phi(z, LitK()); }
 
+#ifndef ITAL_TAIL_LIT_S
+#define ITAL_TAIL_LIT_S 1     // coefficients of the Phi^-1 tail branch as in-place scalars (lit_s above)
+#endif
+#if ITAL_TAIL_LIT_S
+#define TK(x) lit_s(x)
+#else
+#define TK(x) (x)
+#endif
+
 // PHINV (Wichura AS241 PPND16), split so that a wave can run the cheap central branch on every lane and the
 // log/sqrt tail branch only on the (compacted) lanes that need it.
 __device__ __forceinline__ bool phinv_is_central(double p) { return fabs(p - 0.5) <= 0.425; }
@@ -252,13 +267,42 @@ __device__ __forceinline__ double phinv_central_q(double q) {
 
 __device__ __forceinline__ double phinv_central(double p) { return phinv_central_q(p - 0.5); }
 
+// log(x) for the tail branch: the coefficients as in-place scalars (lit_s), whatever the caller's coefficient policy
+__device__ __forceinline__ double log_pos_tail(double x) {
+    const double LN2_HI = 6.93147180369123816490e-01, LN2_LO = 1.90821492927058770002e-10;
+    int e = __builtin_amdgcn_frexp_exp(x);
+    double m = __builtin_amdgcn_frexp_mant(x);  // [0.5, 1)
+    const bool lowm = m < 0.70710678118654752440;
+    m = lowm ? m + m : m;
+    e = lowm ? e - 1 : e;
+    const double f = m - 1.0;
+    const double s = fast_div(f, 2.0 + f);
+    const double z = s * s;
+    double p = lit_s(2.0 / 19.0);
+    p = fma(p, z, lit_s(2.0 / 17.0));
+    p = fma(p, z, lit_s(2.0 / 15.0));
+    p = fma(p, z, lit_s(2.0 / 13.0));
+    p = fma(p, z, lit_s(2.0 / 11.0));
+    p = fma(p, z, lit_s(2.0 / 9.0));
+    p = fma(p, z, lit_s(2.0 / 7.0));
+    p = fma(p, z, lit_s(2.0 / 5.0));
+    p = fma(p, z, lit_s(2.0 / 3.0));
+    const double lm = fma(s * z, p, s + s);
+    const double de = (double)e;
+    return fma(de, LN2_HI, fma(de, LN2_LO, lm));
+}
+
 template <class K>
 __device__ __forceinline__ double phinv_tail(double p, const K& kk) {
     const double q = p - 0.5;
     double r = fmin(p, 1 - p);
     double v;
     if (r > 0) {
+#if ITAL_TAIL_LIT_S
+        r = sqrt_pos(-log_pos_tail(r));
+#else
         r = sqrt_pos(-log_pos(r, kk));
+#endif
         if (r <= 5.0) {
             const double C0 = 1.42343711074968357734E0, C1 = 4.63033784615654529590E0, C2 = 5.76949722146069140550E0,
                          C3 = 3.64784832476320460504E0, C4 = 1.27045825245236838258E0, C5 = 2.41780725177450611770E-1,
@@ -266,8 +310,8 @@ __device__ __forceinline__ double phinv_tail(double p, const K& kk) {
                          D2 = 1.67638483018380384940E0, D3 = 6.89767334985100004550E-1, D4 = 1.48103976427480074590E-1,
                          D5 = 1.51986665636164571966E-2, D6 = 5.47593808499534494600E-4, D7 = 1.05075007164441684324E-9;
             r = r - 1.6;
-            v = fast_div(fma_k(fma_k(fma_k(fma_k(fma_k(fma_k(fma_k(C7, r, C6), r, C5), r, C4), r, C3), r, C2), r, C1), r, C0),
-                         fma(fma_k(fma_k(fma_k(fma_k(fma_k(fma_k(D7, r, D6), r, D5), r, D4), r, D3), r, D2), r, D1), r, 1.0));
+            v = fast_div(fma_k(fma_k(fma_k(fma_k(fma_k(fma_k(fma_k(TK(C7), r, TK(C6)), r, TK(C5)), r, TK(C4)), r, TK(C3)), r, TK(C2)), r, TK(C1)), r, TK(C0)),
+                         fma(fma_k(fma_k(fma_k(fma_k(fma_k(fma_k(TK(D7), r, TK(D6)), r, TK(D5)), r, TK(D4)), r, TK(D3)), r, TK(D2)), r, TK(D1)), r, 1.0));
         } else {
             const double E0 = 6.65790464350110377720E0, E1 = 5.46378491116411436990E0, E2 = 1.78482653991729133580E0,
                          E3 = 2.96560571828504891230E-1, E4 = 2.65321895265761230930E-2, E5 = 1.24266094738807843860E-3,
@@ -275,8 +319,8 @@ __device__ __forceinline__ double phinv_tail(double p, const K& kk) {
                          F2 = 1.36929880922735805310E-1, F3 = 1.48753612908506148525E-2, F4 = 7.86869131145613259100E-4,
                          F5 = 1.84631831751005468180E-5, F6 = 1.42151175831644588870E-7, F7 = 2.04426310338993978564E-15;
             r = r - 5.0;
-            v = fast_div(fma_k(fma_k(fma_k(fma_k(fma_k(fma_k(fma_k(E7, r, E6), r, E5), r, E4), r, E3), r, E2), r, E1), r, E0),
-                         fma(fma_k(fma_k(fma_k(fma_k(fma_k(fma_k(F7, r, F6), r, F5), r, F4), r, F3), r, F2), r, F1), r, 1.0));
+            v = fast_div(fma_k(fma_k(fma_k(fma_k(fma_k(fma_k(fma_k(TK(E7), r, TK(E6)), r, TK(E5)), r, TK(E4)), r, TK(E3)), r, TK(E2)), r, TK(E1)), r, TK(E0)),
+                         fma(fma_k(fma_k(fma_k(fma_k(fma_k(fma_k(TK(F7), r, TK(F6)), r, TK(F5)), r, TK(F4)), r, TK(F3)), r, TK(F2)), r, TK(F1)), r, 1.0));
         }
     } else {
         v = 9;

@@ -32,14 +32,19 @@
 #define ITAL_QMC_HOTK 1   // exp / log coefficients of the lattice loop as vector-register operands (device_math.h HotK)
 #endif
 #ifndef ITAL_QMC_MAIN_NH
-// lattice items per lane and round (x 2 chains): t = 4 at three waves per SIMD has no room for six chains; 25 000 x 512,
-// k = 8: 1.90 -> 1.84 s with six at t = 5, 6.  t = 7, 8: six chains spill whichever way the sum is written (52 / 152 B per lane
-// of scratch in round 2); four chains with per-stage coordinates and the factor in LDS run without scratch and faster
-// (25 000 x 256, k = 8, one round: 1.752 -> 1.659 s; t = 8 launches -7.6 %, t = 7 +1.5 %; profiles/r3_k8_variants.txt)
-#define ITAL_QMC_MAIN_NH(T) (((T) == 4 || (T) >= 7) ? 2 : 3)
+// lattice items per lane and round of the lattice sum (x 2 chains: a point and its antithetic partner): three = six chains
+// at every t.  More chains per lane fill the compacted tail branch of Phi^-1 better (15 % of the arguments: 58 of 64 lanes
+// with six chains, 38 with four).  Until round 3 four chains were all the register file took at t = 4 (three waves per
+// SIMD) and at t = 7, 8: the compiler kept the 39 coefficients of the tail branch in 78 vector registers for the whole
+// kernel; with them materialised in place (device_math.h `lit_s`) the t = 4 kernel needs 126 registers for six chains.
+// Measured (9298 x 256 / 25 000 x 256, `profiles/r3_chains_waves_variants.txt`): t = 4 2.10 -> 1.81 ms with six chains at
+// four waves per SIMD (four chains at four waves 2.03, eight chains at three 2.03), t = 3 0.44 -> 0.42.
+#define ITAL_QMC_MAIN_NH(T) 3
 #endif
 #ifndef ITAL_QMC_WAVES
-#define ITAL_QMC_WAVES(T) ((T) <= 4 ? 3 : 2)   // waves per SIMD the register allocation aims at (measured)
+// waves per SIMD the register allocation aims at: four up to t = 4 (126 registers), three at t = 5, 6 (145 / 167: per step
+// 24.8 -> 21.1 ms, 95 -> 80 ms at 25 000 candidates), two beyond
+#define ITAL_QMC_WAVES(T) ((T) <= 4 ? 4 : ((T) <= 6 ? 3 : 2))
 #endif
 #ifndef ITAL_QMC_MAIN_PS
 #define ITAL_QMC_MAIN_PS(T) ((T) >= 7)   // lattice coordinates formed per stage (qmc_lane_sum_ps): T = 7, 8 spill otherwise
@@ -213,9 +218,7 @@ struct Qmc {
     static constexpr int SLAB_RAW = NCOV + 2 * T + NDIM;      // prep scratch per thread: packed factor, limits, expected values, generators
     static constexpr int SLAB = SLAB_RAW | 1;                 // odd stride: conflict-free per-thread slabs
     static constexpr int PREP_THREADS = T <= 6 ? 256 : 128;
-    // lattice items per lane and round of the lattice-sum kernel (each with its antithetic partner): three at t = 3, where
-    // six chains still fit 168 registers (t = 3 launch 0.533 -> 0.505 ms: the tail branch of Phi^-1 then runs on 90 %
-    // full waves instead of 60 %); at t = 4 six chains spill at three waves per SIMD (4.3 ms) and lose at two (2.41 ms)
+    // lattice items per lane and round of the lattice-sum kernel (each with its antithetic partner), see ITAL_QMC_MAIN_NH
     static constexpr int NH = ITAL_QMC_MAIN_NH(T);
     static constexpr int TAILQ = 128 * NH;                    // compaction queue of the Phi^-1 tail branch (in place)
     static constexpr bool PS = ITAL_QMC_MAIN_PS(T), CFL = PS && ITAL_QMC_MAIN_CFL(T);
