@@ -53,7 +53,11 @@
 // (40 000 x 512, monte_carlo_num_rel = 1): 7 variables 57 -> 44 ms, 8: 122 -> 78, 9: 235 -> 160 (these ran two chains at
 // three waves per SIMD before), 10: 318 -> 282 (four chains), 11-14: three chains (-6 % .. -1 %; four lose 10 % at 12),
 // 15 / 16: two (three spill 63 / 76 registers: +3 % / +20 %)
-#define ITAL_GEN_BIG_NCB(T) ((T) <= 10 ? 4 : (T) <= 14 ? 3 : 2)
+// Round 3: with the coefficients of the Phi^-1 tail branch materialised in place (device_math.h lit_s) every instantiation
+// lost ~70 registers and all scratch; chains per lane raised to what 256 registers hold now -- six at 7, 8 variables, five
+// at 9, 10, four at 11, 12, three beyond (40 000 x 512, k = 16, monte_carlo_num_rel = 1: 5.80 -> 5.53 s per round;
+// profiles/r3_general_variants.txt)
+#define ITAL_GEN_BIG_NCB(T) ((T) <= 8 ? 6 : (T) <= 10 ? 5 : (T) <= 12 ? 4 : 3)
 #endif
 #ifndef ITAL_GEN_BIG_HOTK
 #define ITAL_GEN_BIG_HOTK 1
@@ -62,7 +66,8 @@
 // lattice items per lane and round of the pipeline's evaluator for 3 .. 6 variables: three (six chains) at 5 and 6
 // variables, which then run at two waves per SIMD (per step at 40 000 x 512: 13.6 -> 11.3 ms, 26.5 -> 20.5 ms; four items
 // lose again); two at 3 and 4, three waves per SIMD
-#define ITAL_GEN_FIXED_NH(T) ((T) == 5 || (T) == 6 ? 3 : 2)
+// Round 3 (registers freed by lit_s): three items = six chains at every dimension, see ITAL_GEN_MAIN_WAVES
+#define ITAL_GEN_FIXED_NH(T) 3
 #endif
 #ifndef ITAL_GEN_ONE_TRIP
 // dimensions whose lattice-sum launch runs one call per wave (grid = capacity of the list; waves beyond its length leave
@@ -75,7 +80,9 @@
 #define ITAL_GEN_TAILQ 384     // doubles per wave of the Phi^-1 tail queue of the pipeline's lattice sums: up to 6 chains per lane
 #endif
 #ifndef ITAL_GEN_MAIN_WAVES
-#define ITAL_GEN_MAIN_WAVES(T) ((T) > 0 && (T) < 5 ? 3 : 2)    // three waves per SIMD (168 registers) only up to 4 variables
+// waves per SIMD the lattice-sum kernels aim at: four up to 4 variables (120 registers with six chains), three at 5 and 6,
+// two beyond (noisy-user round 41.0 -> 36.5 ms with six chains at these occupancies; four chains at four waves: 38.1)
+#define ITAL_GEN_MAIN_WAVES(T) ((T) > 0 && (T) < 5 ? 4 : ((T) == 5 || (T) == 6 ? 3 : 2))
 #endif
 #ifndef ITAL_GEN_TFIX_MAX
 #define ITAL_GEN_TFIX_MAX 16   // largest dimension the pipeline takes (plain mode)
