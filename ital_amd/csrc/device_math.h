@@ -71,6 +71,17 @@ struct HotKE {
     }
 };
 
+// Six of the ten exp coefficients as register operands, the other four materialised in place (lit_s): 8 vector registers
+// less than HotKE for 8 scalar moves per evaluation -- what lets the t = 8 lattice sums fit three waves per SIMD without scratch.
+struct HotKE6 {
+    double e[6];
+    __device__ __forceinline__ void load() {
+        e[0] = opaque_v(2.5100375832561321544e-8); e[1] = opaque_v(2.7620075879983480862e-7);
+        e[2] = opaque_v(2.7557268480310025341e-6); e[3] = opaque_v(0.000024801521322368693026);
+        e[4] = opaque_v(0.00019841269863040545271); e[5] = opaque_v(0.0013888888917196719077);
+    }
+};
+
 // The same coefficients as opaque SCALAR-register values: for the kernels that read their factor from LDS (T >= 7 of
 // the perfect-user scorer) the scalar file has room for them, and the 38 vector registers go to the chains instead
 // (one scalar operand per v_fma_f64 is what gfx9 encodes).
@@ -141,6 +152,23 @@ __device__ __forceinline__ double exp_neg(double x, const KT& k) {
     return ldexp(p, (int)n);
 }
 
+__device__ __forceinline__ double exp_neg(double x, const HotKE6& k) {
+    const double LOG2E = 1.4426950408889634074, LN2_HI = 6.93147180369123816490e-01, LN2_LO = 1.90821492927058770002e-10;
+    const double n = rint(x * LOG2E);
+    double r = fma(-n, LN2_HI, x);
+    r = fma(-n, LN2_LO, r);
+    double p = k.e[0];
+#pragma unroll
+    for (int i = 1; i < 6; i++) p = fma(p, r, k.e[i]);
+    p = fma(p, r, lit_s(0.0083333333333300644495));
+    p = fma(p, r, lit_s(0.041666666666624161903));
+    p = fma(p, r, lit_s(0.16666666666666667452));
+    p = fma(p, r, lit_s(0.50000000000000010211));
+    p = fma(p, r, 1.0);
+    p = fma(p, r, 1.0);
+    return ldexp(p, (int)n);
+}
+
 // log(x) for finite x > 0: x = 2^e * m, m in [sqrt(1/2), sqrt(2)), log m = 2 atanh(s), s = (m-1)/(m+1), odd series to s^19
 // (|s| <= 0.1716: truncation < 3e-17 relative).  ~30 VALU instructions against ~98 for the library routine.
 __device__ __forceinline__ double log_pos(double x) {
@@ -169,6 +197,7 @@ __device__ __forceinline__ double log_pos(double x) {
 
 __device__ __forceinline__ double log_pos(double x, const LitK&) { return log_pos(x); }
 __device__ __forceinline__ double log_pos(double x, const HotKE&) { return log_pos(x); }
+__device__ __forceinline__ double log_pos(double x, const HotKE6&) { return log_pos(x); }
 template <class KT>
 __device__ __forceinline__ double log_pos(double x, const KT& k) {
     const double LN2_HI = 6.93147180369123816490e-01, LN2_LO = 1.90821492927058770002e-10;

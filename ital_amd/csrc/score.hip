@@ -39,18 +39,26 @@
 // kernel; with them materialised in place (device_math.h `lit_s`) the t = 4 kernel needs 126 registers for six chains.
 // Measured (9298 x 256 / 25 000 x 256, `profiles/r3_chains_waves_variants.txt`): t = 4 2.10 -> 1.81 ms with six chains at
 // four waves per SIMD (four chains at four waves 2.03, eight chains at three 2.03), t = 3 0.44 -> 0.42.
-#define ITAL_QMC_MAIN_NH(T) 3
+// t = 7, 8: four chains -- what fits THREE waves per SIMD (168 registers, per-stage coordinates, factor in LDS): occupancy
+// is worth more there than fuller tail waves (25 000 x 512, `profiles/r3_k8_occupancy_variants.txt`: t = 8 steps 1216 ms
+// with six chains at two waves, 1249 with four at two, 1068 with four at three; t = 7 341 / 304)
+#define ITAL_QMC_MAIN_NH(T) ((T) >= 7 ? 2 : 3)
 #endif
 #ifndef ITAL_QMC_WAVES
 // waves per SIMD the register allocation aims at: four up to t = 4 (126 registers), three at t = 5, 6 (145 / 167: per step
-// 24.8 -> 21.1 ms, 95 -> 80 ms at 25 000 candidates), two beyond
-#define ITAL_QMC_WAVES(T) ((T) <= 4 ? 4 : ((T) <= 6 ? 3 : 2))
+// 24.8 -> 21.1 ms, 95 -> 80 ms at 25 000 candidates) and at t = 7, 8 (168 each with four chains)
+#define ITAL_QMC_WAVES(T) ((T) <= 4 ? 4 : 3)
 #endif
 #ifndef ITAL_QMC_MAIN_PS
 #define ITAL_QMC_MAIN_PS(T) ((T) >= 7)   // lattice coordinates formed per stage (qmc_lane_sum_ps): T = 7, 8 spill otherwise
 #endif
+#ifndef ITAL_QMC_MAIN_KE6
+#define ITAL_QMC_MAIN_KE6(T) ((T) == 8)  // six of the ten exp coefficients in registers, four in place: t = 8 at three waves, no scratch
+#endif
 #ifndef ITAL_QMC_MAIN_KE
-#define ITAL_QMC_MAIN_KE(T) 0            // only the exp coefficients as register operands (log: literals)
+#define ITAL_QMC_MAIN_KE(T) 1            // only the exp coefficients as register operands: the logarithm of the tail branch
+                                         // takes its own in place (lit_s), HotK's nine log coefficients would sit in 18
+                                         // vector registers unused
 #endif
 #ifndef ITAL_QMC_MAIN_KS
 #define ITAL_QMC_MAIN_KS(T) 0            // exp / log coefficients as scalar-register operands (measured: +7 % at t = 8, dropped)
@@ -225,7 +233,8 @@ struct Qmc {
     static constexpr int WAVE_DOUBLES = LAT + TAILQ + (CFL ? NCOR + T : 0);
     // exp / log coefficients: vector-register operands, or scalar ones where the factor does not occupy the scalar file
     typedef typename std::conditional<(CFL && ITAL_QMC_MAIN_KS(T)), HotKS,
-                                      typename std::conditional<(ITAL_QMC_MAIN_KE(T)), HotKE, HotK>::type>::type Coef;
+                typename std::conditional<(ITAL_QMC_MAIN_KE6(T)), HotKE6,
+                    typename std::conditional<(ITAL_QMC_MAIN_KE(T)), HotKE, HotK>::type>::type>::type Coef;
     static constexpr int64_t CAND_DOUBLES = (int64_t)NPAT * (REC + 1) + 3;   // records, terms, 6 ints of generator state
 };
 // meta word of a record: bit 0 evaluate the lattice sum; bit 1 prior probability == 1 (else 0) when not evaluated;

@@ -232,9 +232,9 @@ def test_one_million_candidates(dev):
 def test_general_scorer_pipeline_equals_its_single_kernel(dev, kw, n, k):
     """Plain mode of ital_score_generic: three kernels on internal streams (prepare / lattice sums / combine, slabs of the
     workspace) against the one kernel that does everything per candidate -- same calls, same stream offsets, same order of
-    the terms; up to 4 variables even the same evaluator with the same number of chains per lane (bit-identical scores),
-    beyond that more chains per lane / the compile-time evaluator against the runtime one (last-bit differences: the lanes'
-    partial sums are formed in another order)."""
+    the terms.  The lattice sums run with more chains per lane in the pipeline (six up to 8 variables since round 3; the
+    single kernel keeps four / the runtime evaluator): last-bit differences, the lanes' partial sums are formed in another
+    order."""
     from ital_amd import ITAL, mvn_stream
     rng = np.random.default_rng(17)
     X = rng.random((n, 9))
@@ -255,8 +255,8 @@ def test_general_scorer_pipeline_equals_its_single_kernel(dev, kw, n, k):
         np.testing.assert_array_equal(a, b)
     for t, (a, b) in enumerate(zip(out[0][1], out[2][1])):
         live = np.isfinite(b)
-        if t + 1 <= 4:
-            np.testing.assert_array_equal(a[live], b[live])
+        if t + 1 <= 2:
+            np.testing.assert_array_equal(a[live], b[live])         # closed forms: the same code
         else:
             np.testing.assert_allclose(a[live], b[live], rtol=1e-12, atol=0)
 
