@@ -57,10 +57,18 @@
 // lost ~70 registers and all scratch; chains per lane raised to what 256 registers hold now -- six at 7, 8 variables, five
 // at 9, 10, four at 11, 12, three beyond (40 000 x 512, k = 16, monte_carlo_num_rel = 1: 5.80 -> 5.53 s per round;
 // profiles/r3_general_variants.txt)
-#define ITAL_GEN_BIG_NCB(T) ((T) <= 8 ? 6 : (T) <= 10 ? 5 : (T) <= 12 ? 4 : 3)
+// ... and then traded against occupancy where three waves per SIMD (168 registers) hold at least two chains without
+// scratch: per step at 40 000 x 512 (profiles/r3_general_variants.txt, second block) 8 variables 67.1 ms (six chains, two
+// waves) -> 59.7 (four chains, three waves), 10: 274.8 -> 250.8 (three), 13: 714.6 -> 691.9 (two), 14: 834.8 -> 816.2;
+// 11, 12 and 15, 16 stay at two waves (four / three chains: three waves would spill or lose)
+#define ITAL_GEN_BIG_NCB(T) ((T) <= 8 ? 4 : (T) <= 10 ? 3 : (T) <= 12 ? 4 : (T) <= 14 ? 2 : 3)
 #endif
 #ifndef ITAL_GEN_BIG_HOTK
 #define ITAL_GEN_BIG_HOTK 1
+#endif
+#ifndef ITAL_GEN_BIG_COEF
+#define ITAL_GEN_BIG_COEF HotKE6     // six exp coefficients in registers, four in place (the logarithm of the tail branch takes
+                                    // its own in place anyway): what the three-wave instantiations need to stay without scratch
 #endif
 #ifndef ITAL_GEN_FIXED_NH
 // lattice items per lane and round of the pipeline's evaluator for 3 .. 6 variables: three (six chains) at 5 and 6
@@ -82,7 +90,7 @@
 #ifndef ITAL_GEN_MAIN_WAVES
 // waves per SIMD the lattice-sum kernels aim at: four up to 4 variables (120 registers with six chains), three at 5 and 6,
 // two beyond (noisy-user round 41.0 -> 36.5 ms with six chains at these occupancies; four chains at four waves: 38.1)
-#define ITAL_GEN_MAIN_WAVES(T) ((T) > 0 && (T) < 5 ? 4 : ((T) == 5 || (T) == 6 ? 3 : 2))
+#define ITAL_GEN_MAIN_WAVES(T) ((T) > 0 && (T) < 5 ? 4 : (((T) >= 5 && (T) <= 10) || (T) == 13 || (T) == 14 ? 3 : 2))
 #endif
 #ifndef ITAL_GEN_TFIX_MAX
 #define ITAL_GEN_TFIX_MAX 16   // largest dimension the pipeline takes (plain mode)
@@ -1185,9 +1193,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(ITAL_GEN_MA
         if (T >= 7) {
             constexpr int TB = T >= 7 ? T : 7, NDIMB = TB - 1;
 #if ITAL_GEN_BIG_HOTK
-            HotK kk;      // exp / log coefficients as vector-register operands (device_math.h), as in the perfect-user kernel
+            ITAL_GEN_BIG_COEF kk;      // exp coefficients as vector-register operands (device_math.h), as in the perfect-user kernel
             kk.load();
-            value = wave_sum(qmc_lane_sum_big<TB, ITAL_GEN_BIG_NCB(TB), HotK>(rec + g.lat, rec, infi, tailq, lane, kk)) /
+            value = wave_sum(qmc_lane_sum_big<TB, ITAL_GEN_BIG_NCB(TB), ITAL_GEN_BIG_COEF>(rec + g.lat, rec, infi, tailq, lane, kk)) /
                     (16.0 * P_TAB[(NDIMB < 10 ? NDIMB : 10) - 1]);
 #else
             value = wave_sum(qmc_lane_sum_big<TB, ITAL_GEN_BIG_NCB(TB)>(rec + g.lat, rec, infi, tailq, lane)) /
