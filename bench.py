@@ -517,12 +517,11 @@ def main():
     for ev in pool:
         ev.record()          # creates the handle (the library records them itself, around single kernels)
     # the GPU has idled through the CPU baseline, the imports and the collection above and sits at low clocks: rounds of the
-    # workload until 0.1 s have passed bring them up (the ramp was measured to take ~8 rounds = 25 ms), then the W warm-up rounds
+    # workload for ~0.1 s bring them up (the ramp was measured to take ~8 rounds = 25 ms), then the W warm-up rounds
     restart()
-    preheat, t_pre = 0, time.perf_counter()
-    while time.perf_counter() - t_pre < 0.1:
+    preheat = 36              # a fixed count (~0.1 s): with several ranks every round is collective, all must run the same number
+    for _ in range(preheat):
         one_round()
-        preheat += 1
     restart()
     for _ in range(args.warmup):
         one_round()

@@ -176,10 +176,12 @@ class ITAL(ActiveRetrievalBase):
     def _buffers(self, kmax):
         gp = self.gp
         b = self._fetch_bufs
-        if b is not None and b["kmax"] >= kmax and b["ldw"] == gp.cap:
+        if b is not None and b["kmax"] >= kmax and b["ldw"] == gp.cap and b["gp"] is gp:
             return b
         b = make_batch_buffers(gp.device, kmax, gp.ldx, gp.cap, gp.ldv, gp.world)
+        b["gp"] = gp              # fit() on an existing learner builds a new GP (other row count / dimension): new buffers
         self._fetch_bufs = b
+        self._dev_list = None
         return b
 
     def _candidate_list(self, candidates=None):

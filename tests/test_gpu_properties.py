@@ -334,3 +334,27 @@ def test_state_dict_resumes_a_session(dev):
     np.testing.assert_allclose(np.asarray(B.rel_mean), mean_a, rtol=0, atol=1e-12)
     with pytest.raises(ValueError):
         ITAL(X, length_scale=0.5, device=dev).load_state_dict(pickle.loads(blob))
+
+
+def test_fit_on_an_existing_learner_starts_over(dev):
+    """fit(data) on a learner that already fetched (reference retrieval_base.py:34-45: a new GP, reset()): batch buffers,
+    device candidate list and prepared round descriptors of the old data must not survive."""
+    from ital_amd import ITAL, mvn_stream
+    rng = np.random.default_rng(31)
+    X1, X2 = rng.random((300, 7)), rng.random((420, 21))
+    mvn_stream.GLOBAL.reset()
+    L = ITAL(X1, length_scale=0.8, device=dev)
+    L.update({0: 1})
+    r1 = L.fetch_unlabelled(3)
+    L.update({i: 1.0 for i in r1})
+    L.fetch_unlabelled(3)
+    L.fit(X2)
+    L.length_scale = 1.3
+    L.fit(X2)
+    mvn_stream.GLOBAL.reset()
+    L.update({5: 1, 6: -1})
+    got = L.fetch_unlabelled(4)
+    mvn_stream.GLOBAL.reset()
+    F = ITAL(X2, length_scale=1.3, device=dev)
+    F.update({5: 1, 6: -1})
+    assert got == F.fetch_unlabelled(4)
