@@ -48,18 +48,27 @@ struct CovArgs {
     double* out; int64_t ldo;
 };
 
+#ifndef ITAL_COV_SMALL
+#define ITAL_COV_SMALL 1           // blocks of fewer than ITAL_COV_SMALL_BELOW default tiles run with the small tile
+#endif
+#ifndef ITAL_COV_SMALL_BELOW
+#define ITAL_COV_SMALL_BELOW 512
+#endif
 #ifndef ITAL_COV_MI
 #define ITAL_COV_MI 2
 #endif
 #ifndef ITAL_COV_MJ
 #define ITAL_COV_MJ 4
 #endif
-constexpr int COV_MI = ITAL_COV_MI, COV_MJ = ITAL_COV_MJ;
+constexpr int COV_MI_D = ITAL_COV_MI, COV_MJ_D = ITAL_COV_MJ;   // register tile per wave: 16 MI rows x 16 MJ columns
 
 // ROWSUM: instead of storing the block, a workgroup walks the column tiles blockIdx.x, blockIdx.x + gridDim.x, ... and
 // keeps sum_j |Sigma_ij| of its rows; out[blockIdx.x * ldo + i] receives the partial sum of that column split (summed in
 // a fixed order by rowsum_reduce_kernel: no floating-point atomics, the result does not depend on scheduling).
-template <bool ROWSUM>
+// COV_MI / COV_MJ: the default 32 x 64 tile per wave (128 x 64 per workgroup), or 16 x 32 (64 x 32 per workgroup) for small
+// blocks -- the reference's MCMI subsample of 1000 candidates is 128 workgroups of the large tile on 256 CUs, 512 of the small.
+// Every output element accumulates its features in the same order whatever the tile: the same bits.
+template <bool ROWSUM, int COV_MI = COV_MI_D, int COV_MJ = COV_MJ_D>
 __global__ __launch_bounds__(256) void cov_block_kernel(CovArgs a) {
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
@@ -708,7 +717,7 @@ extern "C" int ital_cov_block(const double* Xa, const double* an, int64_t na, co
     if (ldx % 16 != 0) return ital_fail(-22, "ital_cov_block: ldx must be a multiple of 16");
     if (m < 0 || (m > 0 && (!Va || !Vb))) return ital_fail(-22, "ital_cov_block: whitened blocks missing");
     if (ldo < nb) return ital_fail(-22, "ital_cov_block: ldo smaller than nb");
-    const int64_t gx = (nb + 16 * COV_MJ - 1) / (16 * COV_MJ), gy = (na + 64 * COV_MI - 1) / (64 * COV_MI);
+    const int64_t gx = (nb + 16 * COV_MJ_D - 1) / (16 * COV_MJ_D), gy = (na + 64 * COV_MI_D - 1) / (64 * COV_MI_D);
     if (gy > 65535) return ital_fail(-22, "ital_cov_block: too many rows per call");
     CovArgs a = {Xa, an, na, Xb, bn, nb, ldx, Va, ldva, Vb, ldvb, m, var, -2.0 * length_scale * length_scale, out, ldo};
     if (ITAL_COV_LDS && ((na + CB_T - 1) / CB_T) * ((nb + CB_T - 1) / CB_T) >= ITAL_COV_LDS_MIN_TILES) {
@@ -718,6 +727,12 @@ extern "C" int ital_cov_block(const double* Xa, const double* an, int64_t na, co
         // (a grid dealt to the XCDs in 8 x 8-tile patches for L2 reuse was measured: 2-9 % slower than this plain sweep)
         ITAL_LAUNCH(cov_block_lds_kernel, dim3((unsigned)lx, (unsigned)ly), dim3(256), 0, stream, a);
         return ital_check_launch("ital_cov_block(lds)");
+    }
+    if (ITAL_COV_SMALL && gx * gy < ITAL_COV_SMALL_BELOW) {
+        // too few workgroups of the default tile to fill the chip: a quarter of the tile, four times the workgroups
+        const int64_t sx = (nb + 31) / 32, sy = (na + 63) / 64;
+        ITAL_LAUNCH((cov_block_kernel<false, 1, 2>), dim3((unsigned)sx, (unsigned)sy), dim3(256), 0, stream, a);
+        return ital_check_launch("ital_cov_block(small)");
     }
     ITAL_LAUNCH(cov_block_kernel<false>, dim3((unsigned)gx, (unsigned)gy), dim3(256), 0, stream, a);
     return ital_check_launch("ital_cov_block");
@@ -736,7 +751,7 @@ extern "C" int ital_cov_abs_rowsum(const double* Xa, const double* an, int64_t n
     if (ldx % 16 != 0) return ital_fail(-22, "ital_cov_abs_rowsum: ldx must be a multiple of 16");
     if (m < 0 || (m > 0 && (!Va || !Vb))) return ital_fail(-22, "ital_cov_abs_rowsum: whitened blocks missing");
     if (!work || work_len < na) return ital_fail(-22, "ital_cov_abs_rowsum: work area smaller than na doubles");
-    const int64_t ntile = (nb + 16 * COV_MJ - 1) / (16 * COV_MJ), gy = (na + 64 * COV_MI - 1) / (64 * COV_MI);
+    const int64_t ntile = (nb + 16 * COV_MJ_D - 1) / (16 * COV_MJ_D), gy = (na + 64 * COV_MI_D - 1) / (64 * COV_MI_D);
     if (gy > 65535) return ital_fail(-22, "ital_cov_abs_rowsum: too many rows per call");
     // column splits: enough workgroups to fill the 256 CUs several times over, as many as the work area holds
     int64_t nsplit = (4096 + gy - 1) / gy;
