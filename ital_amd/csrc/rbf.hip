@@ -24,6 +24,7 @@
 #include "device_math.h"
 #include "ital_hip.h"
 #include "ital_internal.h"
+#include "qmc_seed.h"
 
 namespace ital {
 
@@ -78,7 +79,7 @@ enum { MODE_RAW = 0, MODE_WHITEN = 1 };
 #endif
 constexpr int KU = ITAL_KCOLS_KU;   // feature steps per trip of the dot-product loop
 
-__global__ __launch_bounds__(256) void kcols_kernel(KcolsArgs a) {
+__device__ __forceinline__ void kcols_body(const KcolsArgs& a) {
     __shared__ double tile[4][16][17];  // per wave: R[j][i] transpose buffer for the whitening epilogue
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
@@ -185,6 +186,19 @@ __global__ __launch_bounds__(256) void kcols_kernel(KcolsArgs a) {
     }
 }
 
+__global__ __launch_bounds__(256) void kcols_kernel(KcolsArgs a) { kcols_body(a); }
+
+// The covariance column of the member just selected AND the generator states of the next greedy step's candidates in one
+// launch: both depend on nothing but that selection, both are short (10 us each at 9298 rows) -- the first `nk` workgroups
+// stream the column, the rest compute the seeds (qmc_seed.h) on other CUs at the same time.
+__global__ __launch_bounds__(256) void kcols_seed_kernel(KcolsArgs a, SeedArgs s, unsigned nk) {
+    if (blockIdx.x >= nk) {
+        qmc_seed_body(s, (int64_t)(blockIdx.x - nk) * 256 + threadIdx.x);
+        return;
+    }
+    kcols_body(a);
+}
+
 // gp.predict on external points (reference ital/gp.py:264-292): the test points are whitened against the labelled set
 // exactly as the data rows are -- 16 labelled points per sweep of kcols_kernel in MODE_WHITEN (-2 Xt XT^T on FP64 MFMA,
 // forward substitution against the Cholesky factor, mean += V^T alpha, var -= colsum(V^2)) -- which also leaves the
@@ -269,6 +283,23 @@ extern "C" int ital_cross_cov_cols(const double* X, const double* xnorm, int64_t
     a.W = W; a.ldw = ldw; a.V = V; a.ldv = ldv; a.m = m;
     a.var = var; a.s = -2.0 * length_scale * length_scale; a.mode = MODE_RAW; a.out = out; a.ldo = ldo;
     return launch_kcols(a, stream, "ital_cross_cov_cols");
+}
+
+// ital_cross_cov_cols with the seed computation of the next greedy step riding along (round driver, round.hip).
+int ital_cross_cov_cols_seed(const double* X, const double* xnorm, int64_t n, int ldx, const double* Xs, const double* sn, int c,
+                             const double* W, int ldw, const double* V, int64_t ldv, int m, double var, double length_scale,
+                             double* out, int64_t ldo, const ital::SeedArgs& seed, hipStream_t stream) {
+    KcolsArgs a = {};
+    a.X = X; a.xnorm = xnorm; a.n = n; a.ldx = ldx; a.Xs = Xs; a.sn = sn; a.c = c;
+    a.W = W; a.ldw = ldw; a.V = V; a.ldv = ldv; a.m = m;
+    a.var = var; a.s = -2.0 * length_scale * length_scale; a.mode = MODE_RAW; a.out = out; a.ldo = ldo;
+    if (a.n <= 0 || seed.slab_n <= 0) return ital_fail(-22, "ital_cross_cov_cols_seed: nothing to do");
+    if (a.ldx % 16 != 0) return ital_fail(-22, "kcols: ldx must be a multiple of 16");
+    if (a.c < 1 || a.c > 16) return ital_fail(-22, "kcols: c must be in 1..16");
+    if (a.m < 0 || (a.m > 0 && (!a.W || !a.V))) return ital_fail(-22, "kcols: W/V missing");
+    const int64_t nk = (a.n + 63) / 64, ns = (seed.slab_n + 255) / 256;
+    ITAL_LAUNCH(kcols_seed_kernel, dim3((unsigned)(nk + ns)), dim3(256), 0, stream, a, seed, (unsigned)nk);
+    return ital_check_launch("ital_cross_cov_cols_seed");
 }
 
 extern "C" int ital_whiten_append(const double* X, const double* xnorm, int64_t n, int ldx, const double* Xnew,

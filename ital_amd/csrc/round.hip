@@ -13,6 +13,13 @@
 
 #include "ital_hip.h"
 #include "ital_internal.h"
+#include "qmc_seed.h"
+
+// internal entry points of score.hip / rbf.hip
+int ital_score_step_internal(const ital_score_desc* d, hipStream_t stream, bool seeds_ready, ital::SeedArgs* seeds_only);
+int ital_cross_cov_cols_seed(const double* X, const double* xnorm, int64_t n, int ldx, const double* Xs, const double* sn, int c,
+                             const double* W, int ldw, const double* V, int64_t ldv, int m, double var, double length_scale,
+                             double* out, int64_t ldo, const ital::SeedArgs& seed, hipStream_t stream);
 
 namespace ital {
 
@@ -77,7 +84,7 @@ extern "C" int ital_fetch_round(const ital_round_desc* r, hipStream_t stream) {
         const int rc = ital_check_launch("ital_fetch_round(begin)");
         if (rc) return rc;
     }
-    for (int t = 1; t <= r->k; t++) {
+    auto step_desc = [&](int t) {
         ital_score_desc d = tpl;
         d.t = t;
         if (r->mi_keep) d.mi = r->mi_keep + (int64_t)(t - 1) * tpl.n_cand;
@@ -89,14 +96,33 @@ extern "C" int ital_fetch_round(const ital_round_desc* r, hipStream_t stream) {
         }
         d.ev_start = r->ev_start[t];
         d.ev_stop = r->ev_stop[t];
-        int rc = ital_score_step(&d, stream);
+        return d;
+    };
+    bool seeds_ready = false;
+    for (int t = 1; t <= r->k; t++) {
+        const ital_score_desc d = step_desc(t);
+        int rc = ital_score_step_internal(&d, stream, seeds_ready, nullptr);
         if (rc) return rc;
+        seeds_ready = false;
         if (t < r->k) {
             const int slot = t - 1;
-            rc = ital_cross_cov_cols(tpl.sel_X, tpl.sel_xnorm, r->n_rows, tpl.sel_ldx, tpl.batch.XB + (int64_t)slot * tpl.batch.ldx,
-                                     tpl.batch.XBn + slot, 1, tpl.batch.VB + (int64_t)slot * tpl.batch.ldw, tpl.batch.ldw,
-                                     tpl.sel_V, tpl.sel_ldv, tpl.sel_m, r->var, r->length_scale,
-                                     const_cast<double*>(tpl.C) + (int64_t)slot * tpl.ldc, tpl.ldc, stream);
+            const double* xb = tpl.batch.XB + (int64_t)slot * tpl.batch.ldx;
+            const double* vb = tpl.batch.VB + (int64_t)slot * tpl.batch.ldw;
+            double* col = const_cast<double*>(tpl.C) + (int64_t)slot * tpl.ldc;
+            // the generator states of step t + 1's candidates ride along with the column (both depend on the selection just
+            // made and on nothing else) when that step runs in one slab of its workspace
+            SeedArgs seed;
+            const ital_score_desc nx = step_desc(t + 1);
+            if (ital_score_step_internal(&nx, stream, false, &seed) == 0) {
+                rc = ital_cross_cov_cols_seed(tpl.sel_X, tpl.sel_xnorm, r->n_rows, tpl.sel_ldx, xb, tpl.batch.XBn + slot, 1, vb,
+                                              tpl.batch.ldw, tpl.sel_V, tpl.sel_ldv, tpl.sel_m, r->var, r->length_scale, col,
+                                              tpl.ldc, seed, stream);
+                seeds_ready = true;
+            } else {
+                rc = ital_cross_cov_cols(tpl.sel_X, tpl.sel_xnorm, r->n_rows, tpl.sel_ldx, xb, tpl.batch.XBn + slot, 1, vb,
+                                         tpl.batch.ldw, tpl.sel_V, tpl.sel_ldv, tpl.sel_m, r->var, r->length_scale, col, tpl.ldc,
+                                         stream);
+            }
             if (rc) return rc;
         }
     }

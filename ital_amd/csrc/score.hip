@@ -26,6 +26,7 @@
 #include "ital_hip.h"
 #include "ital_internal.h"
 #include "qmc_common.h"
+#include "qmc_seed.h"
 #include "select_common.h"
 
 #ifndef ITAL_QMC_HOTK
@@ -322,21 +323,14 @@ __device__ __forceinline__ int64_t list_position(const ScoreArgs& a, int64_t p) 
 
 // MVNUNI state at the first call of every candidate of the slab: the step's seed advanced by
 // (rank of the candidate among the live list positions) * ncalls calls -- one 3x3 matrix product mod m per set bit.
-__global__ __launch_bounds__(256) void qmc_seed_kernel(ScoreArgs a, int ncalls, int64_t slab_lo, int64_t slab_n,
-                                                       int* __restrict__ seeds) {
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= slab_n) return;
-    const int64_t p = slab_lo + i;
-    if (!a.alive[p]) return;
-    const int64_t gpos = list_position(a, p);
-    int64_t before = gpos;
-    for (int q = 0; q < a.t - 1; q++) before -= (a.b.bgpos[q] < gpos) ? 1 : 0;
-    uint64_t calls_before = (uint64_t)before * (uint64_t)ncalls;
-    MrgState rng = {a.seed[0], a.seed[1], a.seed[2], a.seed[3], a.seed[4], a.seed[5]};
-    for (int bit = 0; calls_before != 0; bit++, calls_before >>= 1)
-        if (calls_before & 1) mrg_apply(rng, a.jump + bit * 18);
-    int* sp = seeds + i * 6;
-    sp[0] = rng.x10; sp[1] = rng.x11; sp[2] = rng.x12; sp[3] = rng.x20; sp[4] = rng.x21; sp[5] = rng.x22;
+__global__ __launch_bounds__(256) void qmc_seed_kernel(SeedArgs s) {
+    qmc_seed_body(s, (int64_t)blockIdx.x * blockDim.x + threadIdx.x);
+}
+
+static SeedArgs seed_args(const ScoreArgs& a, int ncalls, int64_t slab_lo, int64_t slab_n, int* seeds) {
+    SeedArgs s = {a.alive, a.gpos, a.pos_offset, a.b.bgpos, a.t - 1, {a.seed[0], a.seed[1], a.seed[2], a.seed[3], a.seed[4], a.seed[5]},
+                  a.jump, ncalls, slab_lo, slab_n, seeds};
+    return s;
 }
 
 template <int T>
@@ -578,7 +572,7 @@ __global__ __launch_bounds__(256) void qmc_combine_kernel(const double* __restri
 
 template <int T>
 static int launch_qmc(const ScoreArgs& a, double* work, int64_t work_doubles, int64_t sel_parts_len, hipEvent_t ev0, hipEvent_t ev1,
-                      hipStream_t stream) {
+                      hipStream_t stream, bool seeds_ready, SeedArgs* seeds_only) {
     using Q = Qmc<T>;
     int64_t slab = work_doubles / Q::CAND_DOUBLES;
     if (slab < 1) return ital_fail(-12, "ital_score_step: workspace smaller than one candidate (see ital_score_workspace)");
@@ -594,13 +588,20 @@ static int launch_qmc(const ScoreArgs& a, double* work, int64_t work_doubles, in
     double* recs = work;
     double* terms = recs + slab * Q::NPAT * Q::REC;
     int* seeds = reinterpret_cast<int*>(terms + slab * Q::NPAT);
+    if (seeds_only) {
+        // only tell where the seeds of this step go (one slab: the caller computes them in another launch)
+        if (slab < a.n_cand) return 1;
+        *seeds_only = seed_args(a, Q::NCALLS, 0, a.n_cand, seeds);
+        return 0;
+    }
     int nparts = 0, part0 = 0;
     for (int64_t lo = 0; lo < a.n_cand; lo += slab) nparts += (int)(((a.n_cand - lo < slab ? a.n_cand - lo : slab) + 255) / 256);
     if (a.sel.enabled && 3 * (int64_t)nparts > sel_parts_len)
         return ital_fail(-22, "ital_score_step: sel_parts too small for the blocks of this step");
     for (int64_t lo = 0; lo < a.n_cand; lo += slab) {
         const int64_t n = a.n_cand - lo < slab ? a.n_cand - lo : slab;
-        ITAL_LAUNCH(qmc_seed_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, a, Q::NCALLS, lo, n, seeds);
+        if (!(seeds_ready && slab >= a.n_cand))
+            ITAL_LAUNCH(qmc_seed_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, seed_args(a, Q::NCALLS, lo, n, seeds));
         ITAL_LAUNCH(qmc_prep_kernel<T>, dim3((unsigned)((n + Q::PREP_THREADS - 1) / Q::PREP_THREADS), Q::NPAT),
                            dim3(Q::PREP_THREADS), lds_prep, stream, a, lo, n, seeds, recs);
         if (ev0 && lo == 0) (void)hipEventRecord(ev0, stream);
@@ -640,8 +641,12 @@ extern "C" int64_t ital_score_workspace(int t, int64_t n_cand) {
     return cand_doubles(t) * n_cand;
 }
 
-extern "C" int ital_score_step(const ital_score_desc* d, hipStream_t stream) {
+// seeds_ready: the generator states of the candidates are already in the workspace (the round driver computed them in the
+// launch of the covariance column before).  seeds_only != nullptr: nothing is launched -- the descriptor of the seed
+// computation of this step is returned (0), or 1 when the step needs several slabs (then the step seeds itself).
+int ital_score_step_internal(const ital_score_desc* d, hipStream_t stream, bool seeds_ready, ital::SeedArgs* seeds_only) {
     if (!d) return ital_fail(-22, "ital_score_step: null descriptor");
+    if (seeds_only && (d->n_cand <= 0 || d->t < 3 || d->t > ITAL_MAX_T || !d->work || !d->jump)) return 1;
     if (d->n_cand <= 0) return 0;
     if (d->t < 1 || d->t > ITAL_MAX_T) return ital_fail(-22, "ital_score_step: batch dimension outside 1..ITAL_MAX_T");
     if (d->t > d->batch.kmax) return ital_fail(-22, "ital_score_step: t exceeds the batch capacity");
@@ -684,12 +689,16 @@ extern "C" int ital_score_step(const ital_score_desc* d, hipStream_t stream) {
     if (!d->work) return ital_fail(-22, "ital_score_step: workspace missing for t >= 3 (see ital_score_workspace)");
     hipEvent_t ev0 = static_cast<hipEvent_t>(d->ev_start), ev1 = static_cast<hipEvent_t>(d->ev_stop);
     switch (d->t) {
-        case 3: return launch_qmc<3>(a, d->work, d->work_doubles, d->sel_parts_len, ev0, ev1, stream);
-        case 4: return launch_qmc<4>(a, d->work, d->work_doubles, d->sel_parts_len, ev0, ev1, stream);
-        case 5: return launch_qmc<5>(a, d->work, d->work_doubles, d->sel_parts_len, ev0, ev1, stream);
-        case 6: return launch_qmc<6>(a, d->work, d->work_doubles, d->sel_parts_len, ev0, ev1, stream);
-        case 7: return launch_qmc<7>(a, d->work, d->work_doubles, d->sel_parts_len, ev0, ev1, stream);
-        case 8: return launch_qmc<8>(a, d->work, d->work_doubles, d->sel_parts_len, ev0, ev1, stream);
+        case 3: return launch_qmc<3>(a, d->work, d->work_doubles, d->sel_parts_len, ev0, ev1, stream, seeds_ready, seeds_only);
+        case 4: return launch_qmc<4>(a, d->work, d->work_doubles, d->sel_parts_len, ev0, ev1, stream, seeds_ready, seeds_only);
+        case 5: return launch_qmc<5>(a, d->work, d->work_doubles, d->sel_parts_len, ev0, ev1, stream, seeds_ready, seeds_only);
+        case 6: return launch_qmc<6>(a, d->work, d->work_doubles, d->sel_parts_len, ev0, ev1, stream, seeds_ready, seeds_only);
+        case 7: return launch_qmc<7>(a, d->work, d->work_doubles, d->sel_parts_len, ev0, ev1, stream, seeds_ready, seeds_only);
+        case 8: return launch_qmc<8>(a, d->work, d->work_doubles, d->sel_parts_len, ev0, ev1, stream, seeds_ready, seeds_only);
     }
     return ital_fail(-22, "ital_score_step: unsupported batch dimension");
+}
+
+extern "C" int ital_score_step(const ital_score_desc* d, hipStream_t stream) {
+    return ital_score_step_internal(d, stream, false, nullptr);
 }
