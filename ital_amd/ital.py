@@ -242,7 +242,7 @@ class ITAL(ActiveRetrievalBase):
         if gp.world == 1:
             loc_rows, pos_offset, gpos = cand, 0, None          # every candidate is local, in list order
         else:
-            loc_rows, pos_offset, gpos = sharding.shard_candidates(cand, gp.row0, gp.row1)
+            loc_rows, pos_offset, gpos = sharding.shard_candidates(cand, gp.row0, gp.row1, self._ascending(candidates))
         n_loc = len(loc_rows)
         cand_d = torch.from_numpy((loc_rows - gp.row0).astype(np.int32)).to(dev) if n_loc else \
             torch.zeros(1, dtype=torch.int32, device=dev)
@@ -256,6 +256,12 @@ class ITAL(ActiveRetrievalBase):
         else:
             alive = torch.ones(max(n_loc, 1), dtype=torch.uint8, device=dev)
         return cand, n_loc, pos_offset, cand_d, gpos_d, alive
+
+    def _ascending(self, candidates):
+        """The candidate list is the cached get_unseen() array itself (ascending by construction): lets the sharding
+        arithmetic use binary searches instead of passes over a list of up to millions of entries."""
+        uc = getattr(self, "_unseen_cache", None)
+        return uc is not None and candidates is uc["array"]
 
     def _qmc_workspace(self, b, t, n_loc):
         """Workspace of the lattice scorer (prepared calls of a slab of candidates), grown on demand up to `qmc_work_bytes`."""
@@ -389,7 +395,9 @@ class ITAL(ActiveRetrievalBase):
 
     def _round_signature(self, b, k):
         gp = self.gp
-        return (id(b), k, gp.cap, gp.ldv, gp.V.data_ptr(), gp.mu.data_ptr(), float(self.noise), float(self.eps),
+        w = b.get("qmc_work")
+        return (id(b), k, gp.cap, gp.ldv, gp.V.data_ptr(), gp.mu.data_ptr(), 0 if w is None else w.data_ptr(),
+                float(self.noise), float(self.eps),
                 float(self.var), float(self.length_scale), self.label_estimation, self.qmc_work_bytes,
                 self.profile is not None, repr(self.profile_steps))
 
@@ -551,7 +559,7 @@ class ITAL(ActiveRetrievalBase):
             cand, n_loc, pos_offset, cand_d, gpos_d, alive = self._shard(candidates)
             # every rank's candidates one contiguous run of the list (the ascending get_unseen() order; not after the
             # argpartition order of top_candidates on several ranks)?  Decided from the list alone: the same on every rank
-            runs = sharding.contiguous_runs(cand, gp.n_total, gp.world)
+            runs = sharding.contiguous_runs(cand, gp.n_total, gp.world, self._ascending(candidates))
             pos_of = {int(c): i for i, c in enumerate(cand.tolist())}
             mi = torch.zeros(max(n_loc, 1), dtype=torch.float64, device=dev)
             if "jump1" not in b:

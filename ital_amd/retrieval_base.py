@@ -152,7 +152,9 @@ class ActiveRetrievalBase(object):
             if np.any(at >= len(arr)) or np.any(arr[np.minimum(at, len(arr) - 1)] != ids):
                 self._unseen_cache = None          # feedback for something that was not a candidate: rebuild next time
                 return
-            new = np.delete(arr, at)
+            cuts = [0] + (at + 1).tolist()          # the pieces between the removed entries, copied once
+            ends = at.tolist() + [len(arr)]
+            new = np.concatenate([arr[a:b] for a, b in zip(cuts, ends)])
         else:
             new = arr
         sizes = (len(self.relevant_ids), len(self.irrelevant_ids), len(self.unnameable_ids))

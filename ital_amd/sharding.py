@@ -26,8 +26,9 @@ class ShardedRows(object):
         return self.n_total
 
 
-def shard_candidates(candidates, row0, row1):
+def shard_candidates(candidates, row0, row1, ascending=False):
     """Positions of the global candidate list that fall into this rank's rows.
+    `ascending`: the list is known to be sorted (the plain get_unseen() order): two binary searches instead of a pass over it.
 
     Returns (global data indices of the local positions, list position of the first one, explicit list positions or
     None).  With the ascending `get_unseen()` order the local positions are one contiguous run of the list and
@@ -35,6 +36,9 @@ def shard_candidates(candidates, row0, row1):
     reference ital/ital.py:111-117) they are not, and the third value carries the list position of every local one.
     The arg-max tie-break and the replay of the mvndst stream are keyed on list positions either way."""
     cand = np.asarray(candidates, dtype=np.int64)
+    if ascending:
+        lo, hi = int(np.searchsorted(cand, row0)), int(np.searchsorted(cand, row1))
+        return cand[lo:hi], (lo if hi > lo else 0), None
     mine = np.flatnonzero((cand >= row0) & (cand < row1))
     first = int(mine[0]) if len(mine) else 0
     if len(mine) and not np.array_equal(mine, np.arange(first, first + len(mine))):
@@ -42,10 +46,10 @@ def shard_candidates(candidates, row0, row1):
     return cand[mine], first, None
 
 
-def contiguous_runs(candidates, n_total, world):
+def contiguous_runs(candidates, n_total, world, ascending=False):
     """True when the list positions of EVERY rank's candidates form one contiguous run of the list (then
     `shard_candidates` returns no explicit positions on any rank).  A function of the list alone: all ranks agree."""
-    if world == 1:
+    if world == 1 or ascending:
         return True
     cand = np.asarray(candidates, dtype=np.int64)
     bounds = np.array([row_range(n_total, world, r)[1] for r in range(world)], dtype=np.int64)
