@@ -249,7 +249,7 @@ int ital_score_step(const ital_score_desc* d, hipStream_t stream);
 /* Doubles of workspace that let ital_score_step(t >= 3) handle n_cand candidates in one slab (0 for t < 3). */
 int64_t ital_score_workspace(int t, int64_t n_cand);
 
-/* One whole round of the one-rank path -- fetch_unlabelled(k), reference ital/ital.py:98-134 -- enqueued by ONE call:
+/* One whole round of the perfect-user path -- fetch_unlabelled(k), reference ital/ital.py:98-134 -- enqueued by ONE call:
  * candidate-list upkeep, then for t = 1 .. k ital_score_step (ending with the selection inside its last launch: `step.sel_*`
  * must be set) and, for t < k, the new member's cross-covariance column (ital_cross_cov_cols out of the batch state into
  * C[t - 1]).  Nothing synchronises; the picks are ret[0 .. k), the status word ret[kmax].  At most 2^18 candidates. */
@@ -273,6 +273,17 @@ typedef struct ital_round_desc {
     int begin;
     const int32_t* cand_prev;
     int64_t n_prev;
+    /* Several ranks (world > 1, or one rank driven through the exchange: world == 1 with a transport set): step.cand is this
+     * rank's share of the list (list positions step.pos_offset + local position), every step ends with the rank's record
+     * (the scoring launch's last workgroup), the exchange and ital_select_resolve; the candidate-list upkeep works on the
+     * rank's own share (the survivors are the share without the picks that lay in this rank's rows).  The transport is
+     * ital_select_exchange on nccl_comm, or the host's own `exchange` (same contract: records_all[w][rec_len] <- the record
+     * of rank w on every rank, enqueued on / ordered with `stream`; return 0).  world == 0: one rank, no exchange. */
+    int world;
+    double* records_all;            /* [world][ITAL_REC_HEADER + step.sel_ldx + step.sel_ldw + step.batch.kmax] */
+    void* nccl_comm;
+    int (*exchange)(void* ctx, const double* record, double* records_all, int rec_len, hipStream_t stream);
+    void* exchange_ctx;
 } ital_round_desc;
 int ital_fetch_round(const ital_round_desc* r, hipStream_t stream);
 

@@ -47,12 +47,19 @@ class ItalScoreDesc(ctypes.Structure):
                 ("sel_ret", c_void_p), ("sel_parts", c_void_p), ("sel_parts_len", c_int64), ("sel_counter", c_void_p)]
 
 
+#: int exchange(void* ctx, const double* record, double* records_all, int rec_len, hipStream_t stream): a host's own transport
+#: for the record exchange of ital_fetch_round (device pointers as integers)
+EXCHANGE_FN = ctypes.CFUNCTYPE(c_int, c_void_p, c_void_p, c_void_p, c_int, c_void_p)
+
+
 class ItalRoundDesc(ctypes.Structure):
     _fields_ = [("k", c_int), ("step", ItalScoreDesc), ("seeds", (c_int * 6) * (ITAL_MAX_T + 1)),
                 ("jump", c_void_p * (ITAL_MAX_T + 1)), ("jumppat", c_void_p * (ITAL_MAX_T + 1)),
                 ("vk", c_void_p * (ITAL_MAX_T + 1)), ("ev_start", c_void_p * (ITAL_MAX_T + 1)),
                 ("ev_stop", c_void_p * (ITAL_MAX_T + 1)), ("n_rows", c_int64), ("var", c_double), ("length_scale", c_double),
-                ("mi_keep", c_void_p), ("begin", c_int), ("cand_prev", c_void_p), ("n_prev", c_int64)]
+                ("mi_keep", c_void_p), ("begin", c_int), ("cand_prev", c_void_p), ("n_prev", c_int64),
+                ("world", c_int), ("records_all", c_void_p), ("nccl_comm", c_void_p), ("exchange", EXCHANGE_FN),
+                ("exchange_ctx", c_void_p)]
 
 
 class ItalGscoreDesc(ctypes.Structure):

@@ -1,5 +1,6 @@
-// One fetch_unlabelled(k) round of the one-rank path as ONE call below the C ABI (reference ital/ital.py:98-134): candidate
-// list upkeep, then per greedy step the scorer (ending with the selection inside its last launch) and the new member's
+// One fetch_unlabelled(k) round of the perfect-user path as ONE call below the C ABI (reference ital/ital.py:98-134): candidate
+// list upkeep, then per greedy step the scorer (ending with the selection inside its last launch; several ranks: with the
+// rank's record, followed by the record exchange -- ncclAllGather -- and the resolve launch) and the new member's
 // cross-covariance column.  Nothing here computes anything new -- it is ital_score_step / ital_cross_cov_cols enqueued in a
 // C loop: at 9298 candidates the first two greedy steps are 10 - 25 us kernels and a Python host needs 10 - 17 us per launch
 // (descriptor marshalling through ctypes), the GPU idles in between; from C the launches are ~3 us apart.
@@ -71,7 +72,11 @@ extern "C" int ital_fetch_round(const ital_round_desc* r, hipStream_t stream) {
     if (!r) return ital_fail(-22, "ital_fetch_round: null descriptor");
     const ital_score_desc& tpl = r->step;
     if (r->k < 1 || r->k > ITAL_MAX_T || r->k > tpl.batch.kmax) return ital_fail(-22, "ital_fetch_round: k outside 1..min(ITAL_MAX_T, kmax)");
-    if (tpl.n_cand < r->k) return ital_fail(-22, "ital_fetch_round: fewer candidates than greedy steps");
+    const bool ranks = r->world > 0;
+    if (ranks && (!r->records_all || (!r->nccl_comm && !r->exchange)))
+        return ital_fail(-22, "ital_fetch_round: several ranks need records_all and a transport (nccl_comm or exchange)");
+    if (ranks ? tpl.n_cand < 1 : tpl.n_cand < r->k)
+        return ital_fail(-22, "ital_fetch_round: fewer candidates than greedy steps (several ranks: none on this rank)");
     if (tpl.n_cand > (1 << 18)) return ital_fail(-22, "ital_fetch_round: more than 2^18 candidates (use the per-step entry points)");
     if (!tpl.sel_record || !tpl.sel_ret) return ital_fail(-22, "ital_fetch_round: the round selects inside the scorer: sel_* missing");
     if (r->begin < 0 || r->begin > 2) return ital_fail(-22, "ital_fetch_round: begin must be 0, 1 or 2");
@@ -96,14 +101,24 @@ extern "C" int ital_fetch_round(const ital_round_desc* r, hipStream_t stream) {
         }
         d.ev_start = r->ev_start[t];
         d.ev_stop = r->ev_stop[t];
+        if (ranks) d.sel_ret = nullptr;      // the scoring launch stops after this rank's record
         return d;
     };
+    const int rec_len = ITAL_REC_HEADER + tpl.sel_ldx + tpl.sel_ldw + tpl.batch.kmax;
     bool seeds_ready = false;
     for (int t = 1; t <= r->k; t++) {
         const ital_score_desc d = step_desc(t);
         int rc = ital_score_step_internal(&d, stream, seeds_ready, nullptr);
         if (rc) return rc;
         seeds_ready = false;
+        if (ranks) {
+            rc = r->exchange ? r->exchange(r->exchange_ctx, tpl.sel_record, r->records_all, rec_len, stream)
+                             : ital_select_exchange(tpl.sel_record, r->records_all, rec_len, r->nccl_comm, stream);
+            if (rc) return r->exchange ? ital_fail(rc, "ital_fetch_round: the host's exchange failed") : rc;
+            rc = ital_select_resolve(r->records_all, r->world, rec_len, tpl.sel_rank, 0, t - 1, tpl.batch,
+                                     const_cast<uint8_t*>(tpl.alive), tpl.sel_ret, stream);
+            if (rc) return rc;
+        }
         if (t < r->k) {
             const int slot = t - 1;
             const double* xb = tpl.batch.XB + (int64_t)slot * tpl.batch.ldx;

@@ -278,7 +278,7 @@ class ITAL(ActiveRetrievalBase):
         if self._needs_generic():      # sample ids with rows of the batch buffers)
             self._dev_list = None
             return self._fetch_generic(k, candidates)
-        if self.round_call and self.select_in_scorer and not gp.collective and k <= len(candidates) <= _FUSED_SELECT_MAX:
+        if self.round_call and self.select_in_scorer and self._round_possible(k, candidates):
             return self._select_round(k, candidates)
         self._dev_list = None
         lib = _lib.lib()
@@ -325,7 +325,8 @@ class ITAL(ActiveRetrievalBase):
                         desc.ev_start, desc.ev_stop = k0.cuda_event, k1.cuda_event
                         # several slabs: the pair spans first .. last lattice sum incl. the launches between them
                         slabs = -(-n_loc // max(work.numel() // int(lib.ital_score_workspace(t, 1)), 1))
-                        self.profile.append(("qmc_main" if slabs == 1 else "qmc_slabs%d" % slabs, t, n_alive, k0, k1))
+                        self.profile.append(("qmc_main" if slabs == 1 else "qmc_slabs%d" % slabs, t,
+                                             n_alive if not gp.collective else n_loc, k0, k1))
                 fused = not gp.collective and 0 < n_loc <= _FUSED_SELECT_MAX
                 tail = self.select_in_scorer and 0 < n_loc <= _FUSED_SELECT_MAX
                 if tail:
@@ -393,6 +394,65 @@ class ITAL(ActiveRetrievalBase):
         self._last_batch = (b, list(ret))
         return [int(i) for i in ret]
 
+    def _round_possible(self, k, candidates):
+        """Can this round run as one ital_fetch_round call?  One rank: up to 2^18 candidates.  Several ranks: the ascending
+        get_unseen() list (every rank's share one run of it), at least one and at most 2^18 candidates on every rank, and a
+        transport for the per-step record exchange.  Decided from the list and the process group alone: the same on every rank."""
+        gp = self.gp
+        n = len(candidates)
+        if n < k:
+            return False
+        if not gp.collective:
+            return n <= _FUSED_SELECT_MAX
+        if not self._ascending(candidates) or self._round_transport() is None:
+            return False
+        bounds = [sharding.row_range(gp.n_total, gp.world, r)[0] for r in range(gp.world)] + [gp.n_total]
+        sizes = np.diff(np.searchsorted(candidates, bounds))
+        return bool(sizes.min() >= 1 and sizes.max() <= _FUSED_SELECT_MAX)
+
+    def _round_transport(self):
+        """How ital_fetch_round exchanges the ranks' records: ("nccl", ncclComm_t of the process group -- the communicator
+        torch.distributed itself uses, ProcessGroupNCCL._comm_ptr) over RCCL, ("host", None) through torch.distributed from
+        a callback (backends that move host memory: the gloo rehearsals and tests), or None (the round is enqueued step by
+        step with torch.distributed's all-gather between the launches)."""
+        gp = self.gp
+        cached = getattr(self, "_transport", None)
+        if cached is not None and cached[0] is gp.group:
+            return cached[1]
+        kind = None
+        import torch.distributed as dist
+        if gp.group is not None and dist.is_initialized():
+            if dist.get_backend(gp.group) == "nccl":
+                comm = sharding.raw_comm(gp.group, gp.device)      # None: the step path (torch.distributed between launches)
+                kind = ("nccl", comm) if comm else None
+            else:
+                kind = ("host", None)
+        if os.environ.get("ITAL_ROUND_TRANSPORT") == "none":
+            kind = None
+        elif os.environ.get("ITAL_ROUND_TRANSPORT") == "host" and kind is not None:
+            kind = ("host", None)
+        if kind is not None:
+            self._transport = (gp.group, kind)
+        return kind
+
+    def _host_exchange(self, b):
+        """The record exchange as a callback of ital_fetch_round (transport "host"): torch.distributed's all-gather of this
+        rank's record buffer, issued from inside the C call at the place the RCCL transport issues ncclAllGather."""
+        cb = b.get("exchange_cb")
+        if cb is None:
+            group = self.gp.group
+
+            def exchange(ctx, record, records_all, rec_len, stream):
+                try:
+                    sharding.gather_records(b["rec"], b["rec_all"], group)
+                    return 0
+                except Exception:      # noqa: BLE001 -- must not unwind through the C frames
+                    import traceback
+                    traceback.print_exc()
+                    return -5
+            b["exchange_cb"] = cb = _lib.EXCHANGE_FN(exchange)
+        return cb
+
     def _round_signature(self, b, k):
         gp = self.gp
         w = b.get("qmc_work")
@@ -401,9 +461,10 @@ class ITAL(ActiveRetrievalBase):
                 float(self.var), float(self.length_scale), self.label_estimation, self.qmc_work_bytes,
                 self.profile is not None, repr(self.profile_steps))
 
-    def _round_prepare(self, slot, b, k, n, m, begin, cur, state_before, n_prev=0):
+    def _round_prepare(self, slot, b, k, n, m, begin, cur, state_before, n_prev=0, n_loc=None, pos_offset=0):
         """Fills round descriptor `slot` (one of two) for a round of k steps over n candidates with m labelled samples, the
-        candidate list in device buffer `cur` (begin = 2: compacted out of the other buffer, which holds n + k entries).
+        candidate list in device buffer `cur` (begin = 2: compacted out of the other buffer, which holds n_prev entries).
+        Several ranks: n_loc of the n candidates are this rank's, the first of them at list position pos_offset.
         Nothing here depends on the picks of the round before: the descriptor of the NEXT round is prepared while the GPU
         works on the current one, off the critical path of the retrieval loop."""
         lib = _lib.lib()
@@ -414,9 +475,18 @@ class ITAL(ActiveRetrievalBase):
         d = r.step
         r.k, r.n_rows, r.var, r.length_scale = k, gp.n, float(self.var), float(self.length_scale)
         r.begin, r.cand_prev, r.n_prev = begin, (_ptr(lists[cur ^ 1]) if begin == 2 else None), (n_prev if begin == 2 else 0)
-        d.n_cand = n
+        n_loc = n if n_loc is None else n_loc
+        d.n_cand = n_loc
         d.cand, d.alive, d.mu, d.s2 = _ptr(lists[cur]), _ptr(b["alive"]), _ptr(gp.mu), _ptr(gp.s2)
-        d.C, d.ldc, d.row_offset, d.pos_offset, d.gpos = _ptr(b["C"]), gp.ldv, gp.row0, 0, None
+        d.C, d.ldc, d.row_offset, d.pos_offset, d.gpos = _ptr(b["C"]), gp.ldv, gp.row0, pos_offset, None
+        r.world, r.records_all, r.nccl_comm, r.exchange = 0, None, None, _lib.EXCHANGE_FN(0)
+        if gp.collective:
+            kind, comm = self._round_transport()
+            r.world, r.records_all = gp.world, _ptr(b["rec_all"])
+            if kind == "nccl":
+                r.nccl_comm = comm
+            else:
+                r.exchange = self._host_exchange(b)
         d.batch = b["batch"]
         d.noise, d.eps, d.label_mode = float(self.noise), float(self.eps), _LABEL_MODES[self.label_estimation]
         d.mi, d.status = _ptr(b["mi"]), _ptr(gp.status)
@@ -428,7 +498,7 @@ class ITAL(ActiveRetrievalBase):
         r.mi_keep = None
         events = []
         if k >= 3:
-            work = self._qmc_workspace(b, k, n)
+            work = self._qmc_workspace(b, k, n_loc)
             d.work, d.work_doubles = _ptr(work), work.numel()
         for t in range(1, k + 1):
             r.ev_start[t] = r.ev_stop[t] = None
@@ -441,13 +511,16 @@ class ITAL(ActiveRetrievalBase):
                 if self.profile is not None and (self.profile_steps is None or t in self.profile_steps):
                     k0, k1 = self._event(), self._event()
                     r.ev_start[t], r.ev_stop[t] = k0.cuda_event, k1.cuda_event
-                    slabs = -(-n // max(work.numel() // int(lib.ital_score_workspace(t, 1)), 1))
-                    events.append(("qmc_main" if slabs == 1 else "qmc_slabs%d" % slabs, t, n - (t - 1), k0, k1))
+                    slabs = -(-n_loc // max(work.numel() // int(lib.ital_score_workspace(t, 1)), 1))
+                    # (candidates the bracketed launches score: the whole list on one rank; this rank's share otherwise --
+                    # which rank the earlier picks of the round come from is not known when the descriptor is built)
+                    events.append(("qmc_main" if slabs == 1 else "qmc_slabs%d" % slabs, t,
+                                   n - (t - 1) if not gp.collective else n_loc, k0, k1))
         # the reference's serial loop consumes n_alive * 2 * 2^t calls of mvndst's stream at step t: states before every step
         st6 = (ctypes.c_int * 6)(*state_before)
         check(lib.ital_mvn_round_seeds(st6, n, k, ctypes.byref(r.seeds)))
         draws = sum((n - (t - 1)) * (2 << t) * mvn_stream.draws_per_call(t) for t in range(3, k + 1))
-        return dict(slot=slot, k=k, n=n, m=m, begin=begin, cur=cur, state_before=tuple(state_before),
+        return dict(slot=slot, k=k, n=n, n_loc=n_loc, m=m, begin=begin, cur=cur, state_before=tuple(state_before),
                     state_after=tuple(int(v) for v in st6), draws=draws, events=events, sig=self._round_signature(b, k))
 
     def _select_round(self, k, candidates):
@@ -461,17 +534,24 @@ class ITAL(ActiveRetrievalBase):
         gp = self.gp
         dev = gp.device
         n = len(candidates)
+        if gp.collective:
+            # this rank's share of the ascending list: one run of it, list positions lo .. hi
+            lo, hi = int(np.searchsorted(candidates, gp.row0)), int(np.searchsorted(candidates, gp.row1))
+        else:
+            lo, hi = 0, n
+        n_loc = hi - lo
         with torch.cuda.device(dev):
             b = self._buffers(k)
             st = _stream()
             # ---- candidate list: two device buffers (the compaction reads one, writes the other)
             lists = b.get("cand_lists")
-            if lists is None or lists[0].numel() < n or b.get("alive") is None or b["alive"].numel() < n:
-                b["cand_lists"] = lists = [torch.empty(max(n, 1), dtype=torch.int32, device=dev) for _ in range(2)]
+            if lists is None or lists[0].numel() < n_loc or b.get("alive") is None or b["alive"].numel() < n_loc \
+                    or b["sel_parts"].numel() < 3 * (n_loc // 32 + 64):
+                b["cand_lists"] = lists = [torch.empty(max(n_loc, 1), dtype=torch.int32, device=dev) for _ in range(2)]
                 b["cand_cur"] = 0
-                b["alive"] = torch.empty(n, dtype=torch.uint8, device=dev)
-                b["mi"] = torch.empty(n, dtype=torch.float64, device=dev)
-                b["sel_parts"] = torch.empty(3 * (n // 32 + 64), dtype=torch.float64, device=dev)
+                b["alive"] = torch.empty(n_loc, dtype=torch.uint8, device=dev)
+                b["mi"] = torch.empty(n_loc, dtype=torch.float64, device=dev)
+                b["sel_parts"] = torch.empty(3 * (n_loc // 32 + 64), dtype=torch.float64, device=dev)
                 b["sel_counter"] = torch.zeros(1, dtype=torch.int32, device=dev)
                 b["round_descs"] = [_lib.ItalRoundDesc(), _lib.ItalRoundDesc()]
                 b["round_next"] = None
@@ -487,24 +567,32 @@ class ITAL(ActiveRetrievalBase):
             if (p is not None and follows and not self.keep_scores and p["k"] == k and p["n"] == n and p["m"] == gp.m
                     and p["state_before"] == tuple(stream.state) and p["sig"] == self._round_signature(b, k)):
                 b["cand_cur"] = p["cur"]                       # the round the previous one prepared for
+                if gp.collective:
+                    # prepared before the picks were known: how many of them lay in this rank's rows and before them
+                    d = b["round_descs"][p["slot"]].step
+                    d.n_cand, d.pos_offset = n_loc, lo
+                    p["n_loc"] = n_loc
+                    for i, ev in enumerate(p["events"]):
+                        p["events"][i] = ev[:2] + (n_loc,) + ev[3:]
             else:
                 if p is not None:                              # prepared for a round that did not come: its events go back
                     for ev in p["events"]:
                         self.event_pool += [ev[3], ev[4]]
                 n_prev = 0
                 if follows:
-                    begin, n_prev = 2, len(dl["host"])         # the device holds the parent list with exactly those picks flagged
+                    begin, n_prev = 2, dl["n_loc"]             # the device holds the parent list with exactly those picks flagged
                     b["cand_cur"] ^= 1
                 else:
                     begin = 1
-                    lists[b["cand_cur"]][:n].copy_(torch.from_numpy(np.asarray(candidates, dtype=np.int64).astype(np.int32)))
-                p = self._round_prepare(0, b, k, n, gp.m, begin, b["cand_cur"], stream.state, n_prev)
+                    lists[b["cand_cur"]][:n_loc].copy_(torch.from_numpy(
+                        (np.asarray(candidates[lo:hi], dtype=np.int64) - gp.row0).astype(np.int32)))
+                p = self._round_prepare(0, b, k, n, gp.m, begin, b["cand_cur"], stream.state, n_prev, n_loc, lo)
             b["round_next"] = None
             self.last_round = (p["begin"], p["slot"])          # diagnostics / tests: how the candidate list reached the device
             r = b["round_descs"][p["slot"]]
             keep = None
             if self.keep_scores:
-                keep = torch.zeros((k, n), dtype=torch.float64, device=dev)
+                keep = torch.zeros((k, n_loc), dtype=torch.float64, device=dev)
                 r.mi_keep = _ptr(keep)
             saved_stream = (stream.state, stream.draws)
             check(lib.ital_fetch_round(ctypes.byref(r), st))
@@ -514,10 +602,12 @@ class ITAL(ActiveRetrievalBase):
             # ---- while the GPU works: the descriptor of the round that follows in the retrieval loop (this batch labelled,
             # then the next fetch of k): nothing in it depends on which samples this round picks
             if n - k >= k and gp.m + k <= gp.cap and not self.keep_scores:
-                b["round_next"] = self._round_prepare(p["slot"] ^ 1, b, k, n - k, gp.m + k, 2, b["cand_cur"] ^ 1, stream.state, n)
+                # (several ranks: this rank's share of that list is known only with the picks -- patched in when the round comes)
+                b["round_next"] = self._round_prepare(p["slot"] ^ 1, b, k, n - k, gp.m + k, 2, b["cand_cur"] ^ 1, stream.state,
+                                                      n_loc, n_loc if gp.collective else n - k, lo)
             host = b["ret"].cpu().tolist()     # the only synchronisation of the round: the picks and the status word
             ret, status = host[:k], host[b["kmax"]]
-            self.last_scores = [keep[t, :n] for t in range(k)] if keep is not None else []
+            self.last_scores = [keep[t, :n_loc] for t in range(k)] if keep is not None else []
             if status & 8:
                 raise RuntimeError("ital_amd: the candidate list kept on the device lost track of the host's (internal error)")
             if status & 6:
@@ -528,7 +618,7 @@ class ITAL(ActiveRetrievalBase):
         if status:
             gp.check_status(status)
         self._last_batch = (b, list(ret))
-        self._dev_list = dict(b=b, host=candidates, picks=[int(i) for i in ret])
+        self._dev_list = dict(b=b, host=candidates, picks=[int(i) for i in ret], n_loc=n_loc)
         return [int(i) for i in ret]
 
     # ------------------------------------------------------------------ general scorer (noisy users, estimation subset)

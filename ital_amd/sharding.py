@@ -64,6 +64,35 @@ def _host_staged(t, group):
     return t.is_cuda and dist.get_backend(group) == "gloo"
 
 
+_RAW_COMMS = {}
+
+
+def raw_comm(group, device):
+    """This rank's ncclComm_t of an "nccl" (RCCL) process group as an integer -- the communicator torch.distributed itself
+    uses (ProcessGroupNCCL._comm_ptr) -- or None: other backends, a torch without that accessor, a communicator that is not
+    connected yet, ITAL_RAW_COMM=0.  With it the library issues ncclAllGather itself, on the caller's stream
+    (ital_select_exchange, ital_fetch_round): no trip through torch.distributed's Python and stream hand-over per exchange.
+    Operations on the communicator stay ordered: torch's own collectives wait for the current stream and the current
+    stream waits for them (async_op=False everywhere in this package)."""
+    import os
+    import torch
+    import torch.distributed as dist
+    if group is None or not dist.is_initialized() or os.environ.get("ITAL_RAW_COMM") == "0":
+        return None
+    key = (id(group), str(device))
+    if key not in _RAW_COMMS:
+        comm = None
+        try:
+            if dist.get_backend(group) == "nccl":
+                comm = int(group._get_backend(torch.device(device))._comm_ptr()) or None
+        except Exception:      # noqa: BLE001
+            comm = None
+        if comm is None:
+            return None        # (not cached: the communicator may connect with the first collective)
+        _RAW_COMMS[key] = (group, comm)      # the group is kept alive with its entry: ids are not reused under it
+    return _RAW_COMMS[key][1]
+
+
 def gather_records(record, out, group=None):
     """ONE collective per greedy step: every rank contributes its fixed-size record, all ranks receive all of them.
     `record` [R], `out` [world, R] (same dtype/device)."""
@@ -72,6 +101,15 @@ def gather_records(record, out, group=None):
     if world == 1 and (group is None or not dist.is_initialized()):
         out[0].copy_(record)
         return out
+    if record.is_cuda and record.dtype.itemsize == 8 and record.is_contiguous() and out.is_contiguous() \
+            and record.numel() < (1 << 31):
+        comm = raw_comm(group if group is not None else dist.group.WORLD, record.device)
+        if comm is not None:
+            import torch
+            from . import _lib
+            _lib.check(_lib.lib().ital_select_exchange(record.data_ptr(), out.data_ptr(), record.numel(), comm,
+                                                       torch.cuda.current_stream(record.device).cuda_stream))
+            return out
     if _host_staged(record, group):
         host = [torch_like_cpu(record) for _ in range(world)]
         dist.all_gather(host, record.cpu(), group=group)

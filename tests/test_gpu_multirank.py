@@ -180,6 +180,103 @@ def test_rccl_code_path_on_a_one_rank_group(name):
     np.testing.assert_allclose(r0[1], z["final_rel_mean"], rtol=0, atol=1e-9)
 
 
+def _round_worker(rank, world, port, backend, round_call, X, k, rounds, out):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    group = None
+    if backend is not None:
+        torch.cuda.set_device(0)
+        if backend == "nccl":
+            os.environ["ITAL_FORCE_COLLECTIVES"] = "1"
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", 0))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
+        group = dist.group.WORLD
+    try:
+        from ital_amd import ITAL, mvn_stream
+        mvn_stream.GLOBAL.reset()
+        L = ITAL(X, length_scale=float(np.sqrt(X.shape[1] / 12.0)), device="cuda:0", rank=rank, world=world, group=group)
+        L.round_call = round_call
+        L.update({0: 1, len(X) - 1: -1})
+        picks, how, scores = [], [], []
+        for r in range(rounds):
+            L.keep_scores = r == rounds - 1            # the last round also hands back its score vectors
+            L.last_round = None
+            ret = L.fetch_unlabelled(k)
+            picks.append(ret)
+            how.append(L.last_round)
+            L.update({int(i): (1.0 if X[i, 0] > 0.5 else -1.0) for i in ret})
+        scores = [s_.cpu().numpy().copy() for s_ in L.last_scores]
+        transport = L._round_transport() if L.gp.collective else None
+        out[rank] = (picks, how, scores, (L.gp.row0, L.gp.row1), transport and transport[0], mvn_stream.GLOBAL.draws,
+                     np.asarray(L.rel_mean).copy())
+    finally:
+        if backend is not None:
+            dist.destroy_process_group()
+
+
+def _run_round_workers(world, backend, round_call, X, k, rounds):
+    port = _free_port()
+    with mp.Manager() as mgr:
+        out = mgr.dict()
+        mp.spawn(_round_worker, args=(world, port, backend, round_call, X, k, rounds, out), nprocs=world, join=True)
+        return dict(out)
+
+
+@pytest.mark.parametrize("n,d,k", [(700, 16, 4), (90, 6, 5)])
+def test_round_as_one_call_on_two_ranks(n, d, k):
+    """ital_fetch_round with several ranks: every rank enqueues its whole round -- list upkeep on its own share, scoring
+    launches ending with the rank's record, exchange, resolve, covariance column -- in one call; the exchange is the host's
+    callback here (gloo moves host memory; RCCL's ncclAllGather sits at the same place, next test).  Picks, stream
+    position, score vectors and means equal the step-by-step path's and the one-rank run's over five rounds -- first
+    round from an uploaded list, the following ones compacted on the device out of the previous share, with the
+    descriptor prepared before the picks were known."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    X = np.random.default_rng(77).random((n, d))
+    rounds = 5
+    one = _run_round_workers(1, None, True, X, k, rounds)[0]
+    two_round = _run_round_workers(2, "gloo", True, X, k, rounds)
+    two_steps = _run_round_workers(2, "gloo", False, X, k, rounds)
+    for res in (two_round, two_steps):
+        assert res[0][0] == res[1][0] == one[0]
+        assert res[0][5] == res[1][5] == one[5]
+        np.testing.assert_allclose(res[0][6], one[6], rtol=0, atol=1e-12)
+    for rank in (0, 1):
+        assert two_round[rank][4] == "host"
+        # how the candidate list reached the device: uploaded once, then compacted there (speculative descriptor: slot flips)
+        assert [h[0] for h in two_round[rank][1]] == [1] + [2] * (rounds - 1)
+        assert all(h is None for h in two_steps[rank][1])
+        for a, b_ in zip(two_round[rank][2], two_steps[rank][2]):
+            live = a != 0                 # (members picked earlier in the round: zero here, the stale score there)
+            assert live.sum() >= len(a) - k
+            np.testing.assert_array_equal(a[live], b_[: len(a)][live])
+    # the shares' score vectors are the one-rank vector cut at the share boundary (last round; dead entries excepted)
+    lo_hi = [two_round[r][3] for r in (0, 1)]
+    assert lo_hi[0][1] == lo_hi[1][0]
+    for t in range(k):
+        both = np.concatenate([two_round[0][2][t], two_round[1][2][t]])
+        assert both.shape == one[2][t].shape
+        np.testing.assert_allclose(both, one[2][t], rtol=1e-12, atol=0)
+
+
+def test_round_as_one_call_through_rccl():
+    """The same call with the transport of a real multi-GPU run: ncclAllGather on the process group's own communicator
+    (ProcessGroupNCCL._comm_ptr) from inside ital_fetch_round -- on a one-rank group, all a one-GPU box can host."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    X = np.random.default_rng(78).random((600, 12))
+    one = _run_round_workers(1, None, True, X, 4, 4)[0]
+    res = _run_round_workers(1, "nccl", True, X, 4, 4)[0]
+    assert res[4] == "nccl"
+    assert [h[0] for h in res[1]] == [1, 2, 2, 2]
+    assert res[0] == one[0] and res[5] == one[5]
+    for a, b_ in zip(res[2], one[2]):
+        np.testing.assert_array_equal(a, b_)
+    np.testing.assert_allclose(res[6], one[6], rtol=0, atol=1e-12)
+
+
 def test_record_exchange_below_the_c_abi_through_rccl():
     """ital_select_exchange: the per-step all-gather as a non-Python host would drive it -- a raw ncclComm_t (here a
     one-rank communicator created through RCCL's own C API) and a HIP stream; no torch.distributed involved."""

@@ -232,7 +232,8 @@ def test_ctypes_structs_have_the_layout_of_the_header(tmp_path):
                                                          "draws_in", "dead_pos", "fb_samples", "draw_count", "status", "work_doubles", "pair_count"]),
               "ital_mcmi_desc": (_lib.ItalMcmiDesc, ["t", "alive", "ld_cov", "batch", "ce", "work", "work_doubles"]),
               "ital_round_desc": (_lib.ItalRoundDesc, ["k", "step", "seeds", "jump", "vk", "ev_stop", "n_rows", "length_scale",
-                                                       "mi_keep", "begin", "cand_prev", "n_prev"]),
+                                                       "mi_keep", "begin", "cand_prev", "n_prev", "world", "records_all", "nccl_comm", "exchange",
+                                                       "exchange_ctx"]),
               "ital_np_legacy_state": (_lib.ItalNpLegacyState, ["key", "pos", "has_gauss", "gauss"]),
               "ital_append_desc": (_lib.ItalAppendDesc, ["rows", "lb", "X", "n", "ldl", "ybuf", "ldv", "m", "noise", "status"])}
     lines = []
