@@ -458,9 +458,13 @@ __global__ __launch_bounds__(Qmc<T>::PREP_THREADS) void qmc_prep_kernel(ScoreArg
     if (verdict == 2) meta |= META_PRIOR_ONE;
     if (evaluate) {
         meta |= META_EVAL | ((long long)infi << 8);
+        // (ITAL_QMC_FLIP: the record holds the call with every variable bounded above -- a variable bounded below enters
+        // negated: its limit, its row and its column of the factor change sign; the lattice sum moves its shifts by 1/2)
+        const unsigned fl = ITAL_QMC_FLIP ? infi : 0u;
         for (int v = 1; v < T; v++)
-            for (int j = 0; j < v; j++) rec[v * (v - 1) / 2 + j] = cov[pidx(v, j)];
-        for (int v = 0; v < T; v++) rec[Q::R_LIM + v] = lim[v];
+            for (int j = 0; j < v; j++)
+                rec[v * (v - 1) / 2 + j] = (((fl >> v) ^ (fl >> j)) & 1u) ? -cov[pidx(v, j)] : cov[pidx(v, j)];
+        for (int v = 0; v < T; v++) rec[Q::R_LIM + v] = ((fl >> v) & 1u) ? -lim[v] : lim[v];
         // The call's 8 randomly shifted lattices.  A call draws 8*(2*NDIM-1) uniforms from MVNUNI whether it is evaluated or
         // not: per shift NDIM-1 for DKSMRC's random transposition of the generator vector (the transpositions accumulate
         // from shift to shift), then NDIM shifts.  The prior call of pattern r is call 2r of the candidate.
@@ -504,12 +508,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(ITAL_QMC_WA
     if (meta & META_EVAL) {
         double* lat = lds_all + (size_t)wid * Q::WAVE_DOUBLES;
         double* tailq = lat + Q::LAT;
+        const unsigned flips = ITAL_QMC_FLIP ? (unsigned)(meta >> 8) & ((1u << T) - 1u) : 0u;   // variables bounded below
         {   // unpack the lattices: generator = vk[index], shift = integer * 1/(m1 + 1) exactly as MVNUNI forms it
             const unsigned int* shifts = reinterpret_cast<const unsigned int*>(rec + Q::R_LAT);
             const unsigned char* perm = reinterpret_cast<const unsigned char*>(rec + Q::R_LAT + 4 * Q::NDIM);
             for (int q = lane; q < 8 * Q::NDIM; q += 64) {
                 lat[q] = vk[perm[q]];
-                lat[8 * Q::NDIM + q] = (double)shifts[q] * MRG_INVMP1;
+                lat[8 * Q::NDIM + q] = (double)shifts[q] * MRG_INVMP1 + (((flips >> (q % Q::NDIM)) & 1u) ? 0.5 : 0.0);
             }
         }
         double cf[Q::NCOR > 0 ? Q::NCOR : 1], lm[T];
@@ -522,7 +527,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(ITAL_QMC_WA
 #pragma unroll
             for (int q = 0; q < T; q++) lm[q] = uniform_f64(rec[Q::R_LIM + q]);
         }
-        const unsigned infi = (unsigned)(meta >> 8);
+        const unsigned infi = ITAL_QMC_FLIP ? 0u : (unsigned)(meta >> 8);
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");

@@ -1186,8 +1186,29 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(ITAL_GEN_MA
         const unsigned infi = (unsigned)((m >> 16) & 0xffffffu);
         const double* src = g.recs + (size_t)item * g.R;
         const int ns = n * (n + 1) / 2 + n;
-        for (int q = lane; q < ns; q += 64) rec[q] = src[q];
-        for (int q = lane; q < 16 * (n - 1); q += 64) rec[g.lat + q] = src[g.lat + q];
+        // the compile-time evaluators take every variable as bounded above (ITAL_QMC_FLIP, qmc_common.h): the signs go in here
+        const unsigned fl = (T > 0 && ITAL_QMC_FLIP) ? infi : 0u;
+        for (int q = lane; q < ns; q += 64) {
+            double v = src[q];
+            if (fl) {
+                int row = q - n * (n + 1) / 2, col = row;                        // a limit
+                if (row < 0) {                                                    // packed lower triangle with diagonal
+                    row = 0;
+                    while ((row + 1) * (row + 2) / 2 <= q) row++;
+                    col = q - row * (row + 1) / 2;
+                    if (((fl >> row) ^ (fl >> col)) & 1u) v = -v;
+                } else if ((fl >> row) & 1u) {
+                    v = -v;
+                }
+            }
+            rec[q] = v;
+        }
+        for (int q = lane; q < 16 * (n - 1); q += 64) {
+            double v = src[g.lat + q];
+            if (fl && q >= 8 * (n - 1) && ((fl >> (q % (n - 1))) & 1u)) v += 0.5;   // the shifts of a negated variable
+            rec[g.lat + q] = v;
+        }
+        const unsigned infi_e = (T > 0 && ITAL_QMC_FLIP) ? 0u : infi;
         wave_sync();
         double value;
         if (T >= 7) {
@@ -1195,15 +1216,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(ITAL_GEN_MA
 #if ITAL_GEN_BIG_HOTK
             ITAL_GEN_BIG_COEF kk;      // exp coefficients as vector-register operands (device_math.h), as in the perfect-user kernel
             kk.load();
-            value = wave_sum(qmc_lane_sum_big<TB, ITAL_GEN_BIG_NCB(TB), ITAL_GEN_BIG_COEF>(rec + g.lat, rec, infi, tailq, lane, kk)) /
+            value = wave_sum(qmc_lane_sum_big<TB, ITAL_GEN_BIG_NCB(TB), ITAL_GEN_BIG_COEF>(rec + g.lat, rec, infi_e, tailq, lane, kk)) /
                     (16.0 * P_TAB[(NDIMB < 10 ? NDIMB : 10) - 1]);
 #else
-            value = wave_sum(qmc_lane_sum_big<TB, ITAL_GEN_BIG_NCB(TB)>(rec + g.lat, rec, infi, tailq, lane)) /
+            value = wave_sum(qmc_lane_sum_big<TB, ITAL_GEN_BIG_NCB(TB)>(rec + g.lat, rec, infi_e, tailq, lane)) /
                     (16.0 * P_TAB[(NDIMB < 10 ? NDIMB : 10) - 1]);
 #endif
         } else if (T > 0) {
             constexpr int TF = T > 0 && T < 7 ? T : 3;
-            value = qmc_eval_fixed_inl<TF, ITAL_GEN_FIXED_NH(TF)>(rec, infi, rec + g.lat, lane, tailq);
+            value = qmc_eval_fixed_inl<TF, ITAL_GEN_FIXED_NH(TF)>(rec, infi_e, rec + g.lat, lane, tailq);
         }
         else value = qmc_eval<ITAL_GENERIC_MAX_DIM, 1>(n, rec, infi, (unsigned)((m >> 40) & 0xffffffu), rec + g.lat, lane, tailq);
         if (lane == 0) meta[1] = value;
