@@ -82,6 +82,20 @@ struct HotKE6 {
     }
 };
 
+// N of the ten exp coefficients (the leading ones) as register operands, the rest in place: where HotKE6 still spills.
+template <int N>
+struct HotKEn {
+    double e[N > 0 ? N : 1];
+    __device__ __forceinline__ void load() {
+        const double c[10] = {2.5100375832561321544e-8, 2.7620075879983480862e-7, 2.7557268480310025341e-6,
+                              0.000024801521322368693026, 0.00019841269863040545271, 0.0013888888917196719077,
+                              0.0083333333333300644495, 0.041666666666624161903, 0.16666666666666667452,
+                              0.50000000000000010211};
+#pragma unroll
+        for (int i = 0; i < N; i++) e[i] = opaque_v(c[i]);
+    }
+};
+
 // The same coefficients as opaque SCALAR-register values: for the kernels that read their factor from LDS (T >= 7 of
 // the perfect-user scorer) the scalar file has room for them, and the 38 vector registers go to the chains instead
 // (one scalar operand per v_fma_f64 is what gfx9 encodes).
@@ -169,6 +183,24 @@ __device__ __forceinline__ double exp_neg(double x, const HotKE6& k) {
     return ldexp(p, (int)n);
 }
 
+template <int N>
+__device__ __forceinline__ double exp_neg(double x, const HotKEn<N>& k) {
+    const double LOG2E = 1.4426950408889634074, LN2_HI = 6.93147180369123816490e-01, LN2_LO = 1.90821492927058770002e-10;
+    const double c[10] = {2.5100375832561321544e-8, 2.7620075879983480862e-7, 2.7557268480310025341e-6,
+                          0.000024801521322368693026, 0.00019841269863040545271, 0.0013888888917196719077,
+                          0.0083333333333300644495, 0.041666666666624161903, 0.16666666666666667452,
+                          0.50000000000000010211};
+    const double n = rint(x * LOG2E);
+    double r = fma(-n, LN2_HI, x);
+    r = fma(-n, LN2_LO, r);
+    double p = N > 0 ? k.e[0] : lit_s(c[0]);
+#pragma unroll
+    for (int i = 1; i < 10; i++) p = fma(p, r, i < N ? k.e[i < N ? i : 0] : lit_s(c[i]));
+    p = fma(p, r, 1.0);
+    p = fma(p, r, 1.0);
+    return ldexp(p, (int)n);
+}
+
 // log(x) for finite x > 0: x = 2^e * m, m in [sqrt(1/2), sqrt(2)), log m = 2 atanh(s), s = (m-1)/(m+1), odd series to s^19
 // (|s| <= 0.1716: truncation < 3e-17 relative).  ~30 VALU instructions against ~98 for the library routine.
 __device__ __forceinline__ double log_pos(double x) {
@@ -198,6 +230,8 @@ __device__ __forceinline__ double log_pos(double x) {
 __device__ __forceinline__ double log_pos(double x, const LitK&) { return log_pos(x); }
 __device__ __forceinline__ double log_pos(double x, const HotKE&) { return log_pos(x); }
 __device__ __forceinline__ double log_pos(double x, const HotKE6&) { return log_pos(x); }
+template <int N>
+__device__ __forceinline__ double log_pos(double x, const HotKEn<N>&) { return log_pos(x); }
 template <class KT>
 __device__ __forceinline__ double log_pos(double x, const KT& k) {
     const double LN2_HI = 6.93147180369123816490e-01, LN2_LO = 1.90821492927058770002e-10;
@@ -236,7 +270,14 @@ __device__ __forceinline__ double sqrt_pos(double a) {
 
 // MVNPHI (Hart 5666).  The far-tail continued fraction z + 1/(z + 2/(z + 3/(z + 4/(z + 0.65)))) is evaluated as the
 // ratio of its convergents' numerators N1/N2 (one division instead of six).
-template <class K>
+//
+// CF = false (the lattice loops, mvn_phi_lat below): the rational on the whole range |z| <= 37.  MVNPHI itself is a 1e-9
+// RELATIVE approximation out there (vs the exact tail: rational +2.9e-9 at the cut-off 7.07, its continued fraction -3.6e-9,
+// -8.7e-9 at 8); beyond the cut-off the rational drifts to +4e-8 at |z| = 10, +3.5e-6 at 37 -- on values below 7.7e-13, an
+// absolute difference to MVNPHI below 5e-21 (Phi(z) for z > 0 is 1 - p: unchanged to the last bit).  The reference adds
+// eps = 1e-12 to every probability before its logarithms (ital.py:208-222).  In a wave of 64 chains some |z| lies beyond
+// the cut-off often enough that the branch cost 3.5 % (t = 4) to 4.6 % (t = 8) of the lattice sums.
+template <class K, bool CF = true>
 __device__ __forceinline__ double mvn_phi(double z, const K& kk) {
     const double P0 = 220.2068679123761, P1 = 221.2135961699311, P2 = 112.0792914978709, P3 = 33.91286607838300,
                  P4 = 6.373962203531650, P5 = .7003830644436881, P6 = .03526249659989109;
@@ -249,7 +290,7 @@ __device__ __forceinline__ double mvn_phi(double z, const K& kk) {
         p = 0.0;
     } else {
         const double expntl = exp_neg(-zabs * zabs / 2, kk);
-        if (zabs < CUTOFF) {
+        if (!CF || zabs < CUTOFF) {
             const double num = fma_k(fma_k(fma_k(fma_k(fma_k(fma_k(P6, zabs, P5), zabs, P4), zabs, P3), zabs, P2), zabs, P1), zabs, P0);
             const double den = fma_k(fma_k(fma_k(fma_k(fma_k(fma_k(fma_k(Q7, zabs, Q6), zabs, Q5), zabs, Q4), zabs, Q3), zabs, Q2), zabs, Q1), zabs, Q0);
             p = fast_div(expntl * num, den);
@@ -267,6 +308,12 @@ __device__ __forceinline__ double mvn_phi(double z, const K& kk) {
 }
 
 __device__ __forceinline__ double mvn_phi(double z) { return mvn_phi(z, LitK()); }
+
+#ifndef ITAL_LATTICE_PHI_CF
+#define ITAL_LATTICE_PHI_CF 0
+#endif
+template <class K>
+__device__ __forceinline__ double mvn_phi_lat(double z, const K& kk) { return mvn_phi<K, ITAL_LATTICE_PHI_CF != 0>(z, kk); }
 
 #ifndef ITAL_TAIL_LIT_S
 #define ITAL_TAIL_LIT_S 1     // coefficients of the Phi^-1 tail branch as in-place scalars (lit_s above)

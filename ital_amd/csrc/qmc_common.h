@@ -98,7 +98,7 @@ __device__ __forceinline__ double eval_chains(const double (&xx)[NCB][(T - 1 > 0
             double sc = 0;
 #pragma unroll
             for (int j = 0; j < i; j++) sc = fma(cf[i * (i - 1) / 2 + j], yy[c][j], sc);
-            const double ph = mvn_phi(lm[i] - sc, kk);
+            const double ph = mvn_phi_lat(lm[i] - sc, kk);
             const double d = lower ? ph : 0.0;
             const double w = lower ? 1.0 - ph : ph;
             ff[c] *= w;
@@ -241,7 +241,7 @@ __device__ __forceinline__ double eval_items_ps(const int (&kq)[NI], const int (
 #pragma unroll
             for (int a = 0; a < 2; a++) {
                 const int c = 2 * h + a;
-                const double ph = mvn_phi(lmi - sc[c], kk);
+                const double ph = mvn_phi_lat(lmi - sc[c], kk);
                 const double d = lower ? ph : 0.0;
                 const double w = lower ? 1.0 - ph : ph;
                 ff[c] *= w;
@@ -335,7 +335,7 @@ __device__ __forceinline__ double eval_chains_big(const int (&kk)[NCB], const in
         double pin[NCB];
 #pragma unroll
         for (int c = 0; c < NCB; c++) {
-            const double ph = mvn_phi(lmi - sc[c], coef);
+            const double ph = mvn_phi_lat(lmi - sc[c], coef);
             const double d = lower ? ph : 0.0;
             const double w = lower ? 1.0 - ph : ph;
             ff[c] *= w;

@@ -56,6 +56,10 @@
 #ifndef ITAL_QMC_MAIN_KE6
 #define ITAL_QMC_MAIN_KE6(T) ((T) == 8)  // six of the ten exp coefficients in registers, four in place: t = 8 at three waves, no scratch
 #endif
+#ifndef ITAL_QMC_MAIN_KEN
+#define ITAL_QMC_MAIN_KEN(T) ((T) == 7 ? 2 : -1)   // >= 0: that many of the exp coefficients in registers (HotKEn), the others
+                                                  // in place: t = 7 spills 21 registers with all ten, 12 with six, none with two
+#endif
 #ifndef ITAL_QMC_MAIN_KE
 #define ITAL_QMC_MAIN_KE(T) 1            // only the exp coefficients as register operands: the logarithm of the tail branch
                                          // takes its own in place (lit_s), HotK's nine log coefficients would sit in 18
@@ -234,8 +238,9 @@ struct Qmc {
     static constexpr int WAVE_DOUBLES = LAT + TAILQ + (CFL ? NCOR + T : 0);
     // exp / log coefficients: vector-register operands, or scalar ones where the factor does not occupy the scalar file
     typedef typename std::conditional<(CFL && ITAL_QMC_MAIN_KS(T)), HotKS,
+                typename std::conditional<(ITAL_QMC_MAIN_KEN(T) >= 0), HotKEn<(ITAL_QMC_MAIN_KEN(T) >= 0 ? ITAL_QMC_MAIN_KEN(T) : 0)>,
                 typename std::conditional<(ITAL_QMC_MAIN_KE6(T)), HotKE6,
-                    typename std::conditional<(ITAL_QMC_MAIN_KE(T)), HotKE, HotK>::type>::type>::type Coef;
+                    typename std::conditional<(ITAL_QMC_MAIN_KE(T)), HotKE, HotK>::type>::type>::type>::type Coef;
     static constexpr int64_t CAND_DOUBLES = (int64_t)NPAT * (REC + 1) + 3;   // records, terms, 6 ints of generator state
 };
 // meta word of a record: bit 0 evaluate the lattice sum; bit 1 prior probability == 1 (else 0) when not evaluated;
