@@ -173,15 +173,17 @@ def other_workloads(X, rel, device):
     from ital_amd import ITAL, MCMI_min, mvn_stream
     out = {}
 
-    def timed(learner, rounds, k, warm=2):
+    def timed(learner, rounds, k, warm=2, sample_rounds=0):
+        """sample_rounds > 0: the timed rounds run without kernel events (a learner that enqueues its whole round in one
+        call below the C ABI only does so unprofiled); the per-kernel times come from that many extra rounds afterwards."""
         learner.update({0: 1})
         for _ in range(warm):                             # warm-up rounds (the second one still loads code: lazily
             ret = learner.fetch_unlabelled(k)             # initialised torch kernels of the update path, 12-50 ms once)
             learner.update({int(i): float(rel[i]) for i in ret})
         if getattr(learner, "pair_counter", None) is not None:
             learner.pair_counter.zero_()                  # count the timed rounds only
-        learner.profile = []
-        learner.event_pool = [torch.cuda.Event(enable_timing=True) for _ in range(6 * k * rounds + 16)]   # (a large pool of recorded events slows the first rounds down, see main())
+        learner.profile = None if sample_rounds else []
+        learner.event_pool = [torch.cuda.Event(enable_timing=True) for _ in range(6 * k * (sample_rounds or rounds) + 16)]   # (a large pool of recorded events slows the first rounds down, see main())
         for ev in learner.event_pool:
             ev.record()
         torch.cuda.synchronize()
@@ -194,6 +196,12 @@ def other_workloads(X, rel, device):
             scored += sum(n_c - t for t in range(k))
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
+        if sample_rounds:
+            learner.profile = []
+            for _ in range(sample_rounds):
+                ret = learner.fetch_unlabelled(k)
+                learner.update({int(i): float(rel[i]) for i in ret})
+            torch.cuda.synchronize()
         prof = {}
         for name, t, n_c, e0, e1 in learner.profile:
             prof.setdefault((name, t), []).append((e0.elapsed_time(e1) * 1e-3, n_c))
@@ -229,7 +237,7 @@ def other_workloads(X, rel, device):
     out["ital_k8_25000x512"] = k8_workload(device)
     np.random.seed(0)
     m = MCMI_min(X, length_scale=LENGTH_SCALE, subsample=1000, device=device)
-    r, prof = timed(m, 20, BATCH)
+    r, prof = timed(m, 20, BATCH, sample_rounds=5)
     r["candidates_per_s"] = BATCH * 1000 / (r["ms_per_round"] * 1e-3)
     roofs = {}
     cb = prof.get(("cov_block", 0), [])
@@ -262,7 +270,7 @@ def other_workloads(X, rel, device):
     k6 = 6
     np.random.seed(0)
     m6 = MCMI_min(X, length_scale=LENGTH_SCALE, subsample=1000, device=device)
-    r6, prof6 = timed(m6, 5, k6)
+    r6, prof6 = timed(m6, 5, k6, sample_rounds=3)
     r6["candidates_per_s"] = k6 * 1000 / (r6["ms_per_round"] * 1e-3)
     ms6 = prof6.get(("mcmi_score", k6), [])
     roof6 = None

@@ -323,6 +323,15 @@ int ital_select_fused(const double* mi, const int32_t* cand, uint8_t* alive, int
 
 /* ---- MCMI[min] (pairwise objective) ---------------------------------------------------------------------- */
 
+/* The candidate block of a fetch gathered out of this rank's rows in one launch: for j < nc and global sample index
+ * cand[j] (device array) -- Xc[j][:] = X[cand[j] - row0][:], Vc[r][j] = V[r][cand[j] - row0] (r < m), xnc / muc / s2c[j] =
+ * xnorm / mu / s2 of that row; a sample outside [row0, row0 + n_rows) contributes zeros (several ranks: the blocks are
+ * summed).  Replaces the index arithmetic around self.candidates, reference ital/mcmi.py:57-66, :101-115 (the reference
+ * indexes K_all / rel_mean with the candidate list). */
+int ital_gather_block(const int64_t* cand, int64_t nc, int64_t row0, int64_t n_rows, const double* X, const double* xnorm,
+                      int ldx, const double* V, int64_t ldv, int m, const double* mu, const double* s2, double* Xc,
+                      double* Vc, int64_t ldc, double* xnc, double* muc, double* s2c, hipStream_t stream);
+
 /* Dense posterior covariance block out[i][j] = k(a_i, b_j) - Va[:,i].Vb[:,j] between na and nb points (FP64 MFMA).
  * Replaces K_all[np.ix_(pred, ...)] - k_test^T K_inv k_test, reference ital/gp.py:226, :334-336, for the candidate
  * block MCMI_min scores against (reference ital/mcmi.py:115). */
@@ -369,6 +378,30 @@ typedef struct ital_mcmi_desc {
 int ital_mcmi_score_step(const ital_mcmi_desc* d, hipStream_t stream);
 /* Doubles of workspace for the split form of ital_mcmi_score_step (0 for t < 5). */
 int64_t ital_mcmi_workspace(int t, int64_t n_i);
+
+/* One whole MCMI_min.fetch_unlabelled(k) round on ONE rank after the block is gathered -- reference ital/mcmi.py:66-79 --
+ * enqueued by one call: [alive flags re-armed, ret[kmax] cleared,] the covariance of the candidates with the block
+ * (ital_cov_block into step.cov), then for t = 1 .. k ital_mcmi_score_step, ital_select_fused (arg-min; `step.alive` is
+ * written) and, for t < k, the picked member's covariance column (ital_cross_cov_cols into step.C[t - 1]).  Nothing
+ * synchronises; the picks (block positions) are ret[0 .. k), the status word ret[kmax].  Several ranks drive the steps
+ * themselves (record exchange between ital_select_local and ital_select_resolve). */
+typedef struct ital_mcmi_round_desc {
+    int k;
+    ital_mcmi_desc step;        /* t is filled in per step; pos_offset must be 0 and n_i == n_all (one rank) */
+    const double* Xc;           /* [n_all][ldx] feature rows of the block, xnc their squared norms (ital_gather_block) */
+    const double* xnc;
+    int ldx;
+    const double* Vc;           /* [m][ldv] whitened columns of the block */
+    int64_t ldv;
+    int m, ldw;                 /* labelled samples; row stride of the batch state's VB */
+    double var, length_scale;
+    const int32_t* pos;         /* [n_all] 0, 1, 2, ...: block position of each candidate */
+    const int* status;
+    double* record;             /* scratch: ITAL_REC_HEADER + ldx + ldw + kmax doubles */
+    int64_t* ret;               /* [kmax + 1] */
+    int begin;                  /* 1: alive[0 .. n_i) = 1 and ret[kmax] = 0 first */
+} ital_mcmi_round_desc;
+int ital_mcmi_round(const ital_mcmi_round_desc* r, hipStream_t stream);
 
 /* ---- general scorer: noisy user models, change-estimation subset ------------------------------------------- */
 typedef struct ital_gscore_desc {

@@ -82,6 +82,12 @@ class ItalMcmiDesc(ctypes.Structure):
                 ("work", c_void_p), ("work_doubles", c_int64)]
 
 
+class ItalMcmiRoundDesc(ctypes.Structure):
+    _fields_ = [("k", c_int), ("step", ItalMcmiDesc), ("Xc", c_void_p), ("xnc", c_void_p), ("ldx", c_int), ("Vc", c_void_p),
+                ("ldv", c_int64), ("m", c_int), ("ldw", c_int), ("var", c_double), ("length_scale", c_double),
+                ("pos", c_void_p), ("status", c_void_p), ("record", c_void_p), ("ret", c_void_p), ("begin", c_int)]
+
+
 class ItalNpLegacyState(ctypes.Structure):
     _fields_ = [("key", ctypes.c_uint32 * 624), ("pos", ctypes.c_int32), ("has_gauss", ctypes.c_int32), ("gauss", c_double)]
 
@@ -131,6 +137,9 @@ SIGNATURES = {
                                   c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int64, c_int, c_int, c_void_p,
                                   c_int64, c_int, c_int, ItalBatch, c_void_p, c_void_p, c_void_p, c_void_p]),
     "ital_select_exchange": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p]),
+    "ital_mcmi_round": (c_int, [ctypes.POINTER(ItalMcmiRoundDesc), c_void_p]),
+    "ital_gather_block": (c_int, [c_void_p, c_int64, c_int64, c_int64, c_void_p, c_void_p, c_int, c_void_p, c_int64, c_int,
+                                  c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p]),
     "ital_select_resolve": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, ItalBatch, c_void_p, c_void_p,
                                     c_void_p]),
 }

@@ -708,7 +708,52 @@ static int64_t mcmi_cand_doubles() { return McmiSplit<T>::CAND_DOUBLES; }
 
 }  // namespace ital
 
+namespace ital {
+
+// The candidate block of a fetch (reference mcmi.py:57-66: the candidates MCMI_min scores against each other) gathered out
+// of the rank's rows in ONE launch: feature rows, whitened columns, squared norms, mean and variance of the listed samples;
+// a sample that lives on another rank contributes zeros (the ranks' blocks are summed afterwards).  Workgroup per
+// candidate: the feature row is a coalesced copy, the m whitened values are a strided read of V's column.
+__global__ __launch_bounds__(128) void gather_block_kernel(const int64_t* __restrict__ cand, int64_t nc, int64_t row0,
+                                                           int64_t n_rows, const double* __restrict__ X,
+                                                           const double* __restrict__ xnorm, int ldx,
+                                                           const double* __restrict__ V, int64_t ldv, int m,
+                                                           const double* __restrict__ mu, const double* __restrict__ s2,
+                                                           double* __restrict__ Xc, double* __restrict__ Vc, int64_t ldc,
+                                                           double* __restrict__ xnc, double* __restrict__ muc,
+                                                           double* __restrict__ s2c) {
+    const int64_t j = blockIdx.x;
+    if (j >= nc) return;
+    const int64_t loc = cand[j] - row0;
+    const bool own = loc >= 0 && loc < n_rows;
+    const double* src = X + (own ? loc : 0) * (int64_t)ldx;
+    double* dst = Xc + j * (int64_t)ldx;
+    for (int q = threadIdx.x; q < ldx; q += blockDim.x) dst[q] = own ? src[q] : 0.0;
+    for (int r = threadIdx.x; r < m; r += blockDim.x) Vc[(int64_t)r * ldc + j] = own ? V[(int64_t)r * ldv + loc] : 0.0;
+    if (threadIdx.x == 0) {
+        xnc[j] = own ? xnorm[loc] : 0.0;
+        muc[j] = own ? mu[loc] : 0.0;
+        s2c[j] = own ? s2[loc] : 0.0;
+    }
+}
+
+}  // namespace ital
+
 using namespace ital;
+
+extern "C" int ital_gather_block(const int64_t* cand, int64_t nc, int64_t row0, int64_t n_rows, const double* X,
+                                 const double* xnorm, int ldx, const double* V, int64_t ldv, int m, const double* mu,
+                                 const double* s2, double* Xc, double* Vc, int64_t ldc, double* xnc, double* muc,
+                                 double* s2c, hipStream_t stream) {
+    if (nc <= 0) return 0;
+    if (!cand || !X || !xnorm || !mu || !s2 || !Xc || !xnc || !muc || !s2c || (m > 0 && (!V || !Vc)))
+        return ital_fail(-22, "ital_gather_block: null argument");
+    if (ldx <= 0 || m < 0 || ldc < nc || n_rows < 0) return ital_fail(-22, "ital_gather_block: bad sizes");
+    if (nc > 0x7fffffff) return ital_fail(-22, "ital_gather_block: too many candidates per call");
+    ITAL_LAUNCH(gather_block_kernel, dim3((unsigned)nc), dim3(128), 0, stream, cand, nc, row0, n_rows, X, xnorm, ldx, V, ldv, m,
+                mu, s2, Xc, Vc, ldc, xnc, muc, s2c);
+    return ital_check_launch("ital_gather_block");
+}
 
 extern "C" int ital_cov_block(const double* Xa, const double* an, int64_t na, const double* Xb, const double* bn,
                               int64_t nb, int ldx, const double* Va, int64_t ldva, const double* Vb, int64_t ldvb, int m,

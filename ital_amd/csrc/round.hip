@@ -143,3 +143,41 @@ extern "C" int ital_fetch_round(const ital_round_desc* r, hipStream_t stream) {
     }
     return 0;
 }
+
+extern "C" int ital_mcmi_round(const ital_mcmi_round_desc* r, hipStream_t stream) {
+    if (!r) return ital_fail(-22, "ital_mcmi_round: null descriptor");
+    const ital_mcmi_desc& tpl = r->step;
+    if (r->k < 1 || r->k > ITAL_MAX_T || r->k > tpl.batch.kmax) return ital_fail(-22, "ital_mcmi_round: k outside 1..min(ITAL_MAX_T, kmax)");
+    if (tpl.pos_offset != 0 || tpl.n_i != tpl.n_all) return ital_fail(-22, "ital_mcmi_round: one rank scores the whole block (pos_offset 0, n_i == n_all)");
+    if (tpl.n_all < r->k) return ital_fail(-22, "ital_mcmi_round: fewer candidates than greedy steps");
+    if (tpl.n_all > (1 << 18)) return ital_fail(-22, "ital_mcmi_round: more than 2^18 candidates (use the per-step entry points)");
+    if (!r->Xc || !r->xnc || !r->pos || !r->record || !r->ret || !tpl.alive || !tpl.cov || (r->m > 0 && !r->Vc))
+        return ital_fail(-22, "ital_mcmi_round: null argument");
+    uint8_t* alive = const_cast<uint8_t*>(tpl.alive);
+    int rc;
+    if (r->begin) {
+        ITAL_LAUNCH(fetch_begin_kernel, dim3(1), dim3(1024), 0, stream, 0, nullptr, (int64_t)0, nullptr, alive, tpl.n_i, r->ret,
+                    tpl.batch.kmax, const_cast<int*>(r->status));
+        if ((rc = ital_check_launch("ital_mcmi_round(begin)"))) return rc;
+    }
+    rc = ital_cov_block(r->Xc, r->xnc, tpl.n_i, r->Xc, r->xnc, tpl.n_all, r->ldx, r->Vc, r->ldv, r->Vc, r->ldv, r->m, r->var,
+                        r->length_scale, const_cast<double*>(tpl.cov), tpl.ld_cov, stream);
+    if (rc) return rc;
+    for (int t = 1; t <= r->k; t++) {
+        ital_mcmi_desc d = tpl;
+        d.t = t;
+        if ((rc = ital_mcmi_score_step(&d, stream))) return rc;
+        rc = ital_select_fused(tpl.ce, r->pos, alive, tpl.n_i, 0, nullptr, 0, 0, 1, tpl.mu, tpl.s2, r->Xc, r->xnc, r->ldx, r->Vc,
+                               r->ldv, r->m, r->ldw, tpl.C, tpl.ldc, t - 1, t - 1, tpl.batch, r->status, r->record, r->ret, stream);
+        if (rc) return rc;
+        if (t < r->k) {
+            const int slot = t - 1;
+            rc = ital_cross_cov_cols(r->Xc, r->xnc, tpl.n_all, r->ldx, tpl.batch.XB + (int64_t)slot * tpl.batch.ldx,
+                                     tpl.batch.XBn + slot, 1, tpl.batch.VB + (int64_t)slot * tpl.batch.ldw, tpl.batch.ldw, r->Vc,
+                                     r->ldv, r->m, r->var, r->length_scale, const_cast<double*>(tpl.C) + (int64_t)slot * tpl.ldc,
+                                     tpl.ldc, stream);
+            if (rc) return rc;
+        }
+    }
+    return 0;
+}

@@ -41,6 +41,7 @@ class MCMI_min(ActiveRetrievalBase):
         self.candidates = []
         self.keep_scores = False
         self.split_kernel = True      # batches of 5 .. 8 through the split scorer (False: the single kernel; cross-check in tests)
+        self.round_call = True        # one rank: the whole round as one call below the C ABI (False: step by step from here)
         self.last_scores = None
         self.profile = None
         self.event_pool = []
@@ -70,28 +71,54 @@ class MCMI_min(ActiveRetrievalBase):
                                 torch.zeros((gp.cap, ldc), dtype=torch.float64, device=dev),
                                 torch.zeros((3, nc), dtype=torch.float64, device=dev))
         _, Xc, Vc, vec = self._block_bufs
+        # one launch: rows, whitened columns, norms, means and variances of the listed samples (zeros for samples of other
+        # ranks); the list travels as one small upload
+        cand_d = torch.from_numpy(np.ascontiguousarray(cand, dtype=np.int64)).to(dev)
+        check(_lib.lib().ital_gather_block(_ptr(cand_d), nc, gp.row0, gp.n, _ptr(gp.Xd), _ptr(gp.xnorm), gp.ldx, _ptr(gp.V),
+                                           gp.ldv, gp.m, _ptr(gp.mu), _ptr(gp.s2), _ptr(Xc), _ptr(Vc), ldc, _ptr(vec[0]),
+                                           _ptr(vec[1]), _ptr(vec[2]), _stream()))
         if gp.collective:
-            Xc.zero_()
-            Vc.zero_()
-            vec.zero_()
-        if not gp.collective:
-            loc = torch.as_tensor(np.asarray(cand, dtype=np.int64) - gp.row0, dtype=torch.int64, device=dev)
-            Xc.copy_(gp.Xd.index_select(0, loc))
-            Vc[: gp.m, :nc] = gp.V[: gp.m].index_select(1, loc)
-            vec[0], vec[1], vec[2] = gp.xnorm[loc], gp.mu[loc], gp.s2[loc]
-        else:
-            # ownership worked out on the host (a device-side mask costs a nonzero() and a synchronisation per use)
-            cand_h = np.asarray(cand, dtype=np.int64)
-            sel_h = np.flatnonzero((cand_h >= gp.row0) & (cand_h < gp.row1))
-            if len(sel_h):
-                sel = torch.from_numpy(sel_h).to(dev)
-                loc = torch.from_numpy(cand_h[sel_h] - gp.row0).to(dev)
-                Xc[sel] = gp.Xd.index_select(0, loc)
-                Vc[: gp.m, sel] = gp.V[: gp.m].index_select(1, loc)
-                vec[0, sel], vec[1, sel], vec[2, sel] = gp.xnorm[loc], gp.mu[loc], gp.s2[loc]
             for buf in (Xc, Vc, vec):
                 sharding.all_reduce_sum(buf, gp.group)
-        return Xc, Vc, ldc, vec[0].contiguous(), vec[1].contiguous(), vec[2].contiguous()
+        return Xc, Vc, ldc, vec[0], vec[1], vec[2]
+
+    def _round(self, k, cand, b, cov, pos_d, alive, ce, Xc, Vc, ldc, xnc, muc, s2c, st):
+        """One rank: covariance block, k scoring / arg-min steps and k - 1 covariance columns enqueued by ONE call
+        (ital_mcmi_round): at the reference's subsample of 1000 a step is 20 - 90 us of kernels and the launches of a Python
+        host are 6 us apart."""
+        lib = _lib.lib()
+        gp = self.gp
+        dev = gp.device
+        nc = len(cand)
+        r = b.get("mcmi_round")
+        if r is None:
+            b["mcmi_round"] = r = _lib.ItalMcmiRoundDesc()
+        d = r.step
+        r.k = k
+        d.n_i, d.pos_offset, d.n_all = nc, 0, nc
+        d.alive, d.mu, d.s2 = _ptr(alive), _ptr(muc), _ptr(s2c)
+        d.cov, d.ld_cov, d.C, d.ldc = _ptr(cov), ldc, _ptr(b["C"]), ldc
+        d.batch = b["batch"]
+        d.noise, d.eps, d.ce = float(self.noise), float(self.eps), _ptr(ce)
+        d.work, d.work_doubles = None, 0
+        if k >= 5 and self.split_kernel:
+            want = int(lib.ital_mcmi_workspace(ITAL_MAX_T, nc))
+            w = b.get("mcmi_work")
+            if w is None or w.numel() < want:          # zero-initialised once: the ticket counters return to zero
+                b["mcmi_work"] = w = torch.zeros(want, dtype=torch.float64, device=dev)
+            d.work, d.work_doubles = _ptr(w), w.numel()
+        r.Xc, r.xnc, r.ldx, r.Vc, r.ldv, r.m, r.ldw = _ptr(Xc), _ptr(xnc), gp.ldx, _ptr(Vc), ldc, gp.m, gp.cap
+        r.var, r.length_scale = float(self.var), float(self.length_scale)
+        r.pos, r.status, r.record, r.ret, r.begin = _ptr(pos_d), _ptr(gp.status), _ptr(b["rec"]), _ptr(b["ret"]), 1
+        check(lib.ital_mcmi_round(ctypes.byref(r), st))
+        self.last_scores = []
+        host = b["ret"].cpu().tolist()            # block positions + status word; the only synchronisation of the round
+        picked = host[:k]
+        gp.check_status(host[b["kmax"]])
+        ret = [int(cand[p]) for p in picked]
+        self._last_batch = (b, ret)
+        self.candidates = np.delete(cand, picked).tolist()   # as `del self.candidates[min_ind]` per pick (mcmi.py:79)
+        return ret
 
     def fetch_unlabelled(self, k, show_progress=False):
         """Fetches a batch of unlabelled samples (reference ital/mcmi.py:48-81); list of python ints."""
@@ -130,6 +157,9 @@ class MCMI_min(ActiveRetrievalBase):
                                     torch.empty(max(n_i, 1), dtype=torch.uint8, device=dev),
                                     torch.empty(max(n_i, 1), dtype=torch.float64, device=dev))
             _, b, cov, pos_d, alive, ce = self._fetch_bufs
+            if (self.round_call and not gp.collective and self.profile is None and not self.keep_scores
+                    and k <= nc <= (1 << 18)):
+                return self._round(k, cand, b, cov, pos_d, alive, ce, Xc, Vc, ldc, xnc, muc, s2c, st)
             alive.fill_(1)
             b["ret"][b["kmax"]:].zero_()       # the selection steps OR the status word into this slot
             ev0 = self._mark()

@@ -89,8 +89,31 @@ def raw_comm(group, device):
             comm = None
         if comm is None:
             return None        # (not cached: the communicator may connect with the first collective)
+        if not _raw_comm_works(group, device, comm):
+            comm = None        # cached: every later exchange of this group goes through torch.distributed
         _RAW_COMMS[key] = (group, comm)      # the group is kept alive with its entry: ids are not reused under it
     return _RAW_COMMS[key][1]
+
+
+def _raw_comm_works(group, device, comm):
+    """First use of a group's communicator below the C ABI: one small all-gather through ital_select_exchange, checked
+    against what every rank must receive (rank r contributes r + 1).  Reached by all ranks together (the first exchange of
+    a learner is collective).  Anything but the expected block -- an exception, a communicator with another rank order --
+    keeps the group on torch.distributed."""
+    import torch
+    import torch.distributed as dist
+    try:
+        from . import _lib
+        world, rank = dist.get_world_size(group), dist.get_rank(group)
+        dev = torch.device(device)
+        send = torch.full((2,), float(rank + 1), dtype=torch.float64, device=dev)
+        recv = torch.zeros((world, 2), dtype=torch.float64, device=dev)
+        _lib.check(_lib.lib().ital_select_exchange(send.data_ptr(), recv.data_ptr(), 2, comm,
+                                                   torch.cuda.current_stream(dev).cuda_stream))
+        want = torch.arange(1, world + 1, dtype=torch.float64).repeat_interleave(2).reshape(world, 2)
+        return bool(torch.equal(recv.cpu(), want))
+    except Exception:      # noqa: BLE001
+        return False
 
 
 def gather_records(record, out, group=None):

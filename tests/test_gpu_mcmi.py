@@ -187,6 +187,68 @@ def test_mcmi_split_scorer_equals_single_kernel(dev, n, d, k, sub):
             np.testing.assert_allclose(out[0][0][1][t][[pos[c] for c in cand]], vals, rtol=CE_RTOL, atol=0)
 
 
+@pytest.mark.parametrize("n,d,k,sub", [(70, 5, 4, None), (400, 12, 6, 300), (1200, 16, 3, 1000), (40, 3, 8, None)])
+def test_mcmi_round_as_one_call_equals_the_steps(dev, n, d, k, sub):
+    """One rank: ital_mcmi_round enqueues covariance block, scoring / arg-min steps and covariance columns in one call;
+    `round_call = False` drives the same entry points step by step.  Same picks and candidate lists over three rounds
+    (a duplicated row: a tie of the arg-min, first position wins), same state afterwards."""
+    from ital_amd import MCMI_min
+    rng = np.random.default_rng(30 + k)
+    X = rng.random((n, d))
+    X[n // 2] = X[n // 3]
+    ls = float(np.sqrt(d / 12.0))
+    labels = {int(i): (1 if X[i, 0] > 0.5 else -1) for i in rng.choice(n, 3, replace=False)}
+    out = []
+    for one_call in (True, False):
+        L = MCMI_min(X, length_scale=ls, subsample=sub, device=dev)
+        L.round_call = one_call
+        L.update(labels)
+        res = []
+        for _ in range(3):
+            np.random.seed(6)
+            ret = L.fetch_unlabelled(k)
+            res.append((ret, list(L.candidates)))
+            L.update({i: (1 if X[i, 0] > 0.5 else -1) for i in ret})
+        out.append((res, np.asarray(L.rel_mean).copy()))
+    assert out[0][0] == out[1][0]
+    np.testing.assert_array_equal(out[0][1], out[1][1])
+
+
+def test_gather_block_equals_indexing(dev):
+    """ital_gather_block: rows, whitened columns, norms, means and variances of a candidate list in one launch; samples
+    outside the rank's rows contribute zeros."""
+    import torch
+    from ital_amd import MCMI_min, _lib
+    rng = np.random.default_rng(5)
+    X = rng.random((300, 20))
+    L = MCMI_min(X, length_scale=1.2, device=dev)
+    L.update({3: 1, 77: -1, 150: 1, 299: -1, 12: 1})
+    gp = L.gp
+    cand = rng.permutation(300)[:130].astype(np.int64)
+    Xc, Vc, ldc, xnc, muc, s2c = L._gather_block(cand)
+    idx = torch.as_tensor(cand, device=gp.device)
+    torch.testing.assert_close(Xc, gp.Xd.index_select(0, idx), rtol=0, atol=0)
+    torch.testing.assert_close(Vc[: gp.m, : len(cand)], gp.V[: gp.m].index_select(1, idx), rtol=0, atol=0)
+    assert float(Vc[:, len(cand):].abs().max()) == 0.0
+    for got, src in ((xnc, gp.xnorm), (muc, gp.mu), (s2c, gp.s2)):
+        torch.testing.assert_close(got, src[idx], rtol=0, atol=0)
+    # a rank that owns rows 100 .. 199 only
+    nc = len(cand)
+    out = [torch.full((nc, gp.ldx), 7.0, dtype=torch.float64, device=gp.device),
+           torch.full((gp.cap, ldc), 7.0, dtype=torch.float64, device=gp.device)] + \
+          [torch.full((nc,), 7.0, dtype=torch.float64, device=gp.device) for _ in range(3)]
+    p = lambda t: t.data_ptr()
+    _lib.check(_lib.lib().ital_gather_block(p(idx), nc, 100, 100, p(gp.Xd[100:]), p(gp.xnorm[100:]), gp.ldx,
+                                            gp.V.data_ptr() + 8 * 100, gp.ldv, gp.m, p(gp.mu[100:]), p(gp.s2[100:]),
+                                            p(out[0]), p(out[1]), ldc, p(out[2]), p(out[3]), p(out[4]),
+                                            torch.cuda.current_stream().cuda_stream))
+    own = torch.as_tensor((cand >= 100) & (cand < 200), device=gp.device)
+    want = gp.Xd.index_select(0, idx) * own[:, None]
+    torch.testing.assert_close(out[0], want, rtol=0, atol=0)
+    torch.testing.assert_close(out[3], gp.mu[idx] * own, rtol=0, atol=0)
+    torch.testing.assert_close(out[1][: gp.m, :nc], gp.V[: gp.m].index_select(1, idx) * own[None, :], rtol=0, atol=0)
+
+
 def test_mcmi_edge_cases(dev):
     from ital_amd import MCMI_min
     rng = np.random.default_rng(3)

@@ -136,7 +136,7 @@ def test_c_abi_exports_every_declared_symbol():
     from ital_amd import _lib
     header = open(os.path.join(ROOT, "include", "ital_hip.h")).read()
     declared = set(re.findall(r"\b(ital_[a-z_0-9]+)\s*\(", header))
-    declared -= {"ital_batch", "ital_score_desc", "ital_round_desc", "ital_append_desc"}
+    declared -= {"ital_batch", "ital_score_desc", "ital_round_desc", "ital_append_desc", "ital_mcmi_round_desc"}
     assert declared == set(_lib.SIGNATURES), (declared ^ set(_lib.SIGNATURES))
     lib = ctypes.CDLL(_lib.LIB_PATH)
     for name in declared:
@@ -234,6 +234,8 @@ def test_ctypes_structs_have_the_layout_of_the_header(tmp_path):
               "ital_round_desc": (_lib.ItalRoundDesc, ["k", "step", "seeds", "jump", "vk", "ev_stop", "n_rows", "length_scale",
                                                        "mi_keep", "begin", "cand_prev", "n_prev", "world", "records_all", "nccl_comm", "exchange",
                                                        "exchange_ctx"]),
+              "ital_mcmi_round_desc": (_lib.ItalMcmiRoundDesc, ["k", "step", "Xc", "ldx", "Vc", "ldv", "m", "ldw", "var", "pos",
+                                                                "status", "record", "ret", "begin"]),
               "ital_np_legacy_state": (_lib.ItalNpLegacyState, ["key", "pos", "has_gauss", "gauss"]),
               "ital_append_desc": (_lib.ItalAppendDesc, ["rows", "lb", "X", "n", "ldl", "ybuf", "ldv", "m", "noise", "status"])}
     lines = []

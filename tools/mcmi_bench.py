@@ -21,14 +21,22 @@ for sub in (1000, None):
     r = L.fetch_unlabelled(k)
     L.update({int(i): float(rel[i]) for i in r})
     torch.cuda.synchronize()
-    L.profile = []
+    for _ in range(3):                                   # (clocks up, lazily loaded code in)
+        r = L.fetch_unlabelled(k)
+        L.update({int(i): float(rel[i]) for i in r})
+    torch.cuda.synchronize()
     t0 = time.perf_counter()
-    reps = 5
-    for _ in range(reps):
+    reps = 10
+    for _ in range(reps):                                # unprofiled: the round is one call below the C ABI
         r = L.fetch_unlabelled(k)
         L.update({int(i): float(rel[i]) for i in r})
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / reps
+    L.profile = []
+    for _ in range(3):                                   # kernel times: step by step with events
+        r = L.fetch_unlabelled(k)
+        L.update({int(i): float(rel[i]) for i in r})
+    torch.cuda.synchronize()
     prof = {}
     for name, t, size, e0, e1 in L.profile:
         prof.setdefault((name, t), []).append((e0.elapsed_time(e1), size))
