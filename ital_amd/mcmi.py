@@ -48,6 +48,18 @@ class MCMI_min(ActiveRetrievalBase):
         self._block_bufs = None
         self._fetch_bufs = None
 
+    @property
+    def candidates(self):
+        """The candidate list the last fetch left behind (reference mcmi.py:57-66, :79), as a list; formed on first read."""
+        c = self._candidates
+        if isinstance(c, tuple):
+            self._candidates = c = np.delete(c[0], c[1]).tolist()
+        return c
+
+    @candidates.setter
+    def candidates(self, value):
+        self._candidates = value
+
     def _mark(self, stage=None, t=0, size=0, start=None):
         if self.profile is None:
             return None
@@ -117,7 +129,7 @@ class MCMI_min(ActiveRetrievalBase):
         gp.check_status(host[b["kmax"]])
         ret = [int(cand[p]) for p in picked]
         self._last_batch = (b, ret)
-        self.candidates = np.delete(cand, picked).tolist()   # as `del self.candidates[min_ind]` per pick (mcmi.py:79)
+        self._candidates = (cand, picked)                    # as `del self.candidates[min_ind]` per pick (mcmi.py:79)
         return ret
 
     def fetch_unlabelled(self, k, show_progress=False):
@@ -214,5 +226,5 @@ class MCMI_min(ActiveRetrievalBase):
         gp.check_status(host[b["kmax"]])
         ret = [int(cand[p]) for p in picked]
         self._last_batch = (b, ret)
-        self.candidates = np.delete(cand, picked).tolist()   # as `del self.candidates[min_ind]` per pick (mcmi.py:79)
+        self._candidates = (cand, picked)                    # as `del self.candidates[min_ind]` per pick (mcmi.py:79)
         return ret
