@@ -416,6 +416,12 @@ def scaling_workload(device, rank, world, group, rounds=3):
         tt = torch.tensor([dt], dtype=torch.float64, device=device)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
+    if world > 1 and not any(p_[0] == "exchange" for p_ in L.profile):
+        # the rounds above ran as single calls (the exchange is issued from C): one more round step by step, untimed, for
+        # the duration of the per-step collective (every rank takes this branch: same path on all of them)
+        L.round_call = False
+        one_round()
+        torch.cuda.synchronize()
     prof = {}
     for name, t, n_c, e0, e1 in L.profile:
         prof.setdefault((name, t), []).append(e0.elapsed_time(e1))
@@ -436,7 +442,8 @@ def scaling_workload(device, rank, world, group, rounds=3):
             "kernel_ms_note": "qmc_main_t*: the lattice-sum kernel alone (one slab of the workspace); qmc_slabsN_t*: first to "
                               "last lattice sum of a step that needed N slabs, incl. the preparation / combine launches between",
             "library_launches_per_round": launches, "peak_device_memory_gib": mem,
-            "note": "per-step exchange = all_gather_into_tensor of one record per rank (null on one rank: no collective)"}
+            "note": "per-step exchange = ncclAllGather of one record per rank on the process group's communicator (null on one "
+                    "rank: no collective)"}
 
 
 def main():
