@@ -76,6 +76,26 @@ def test_two_rank_exchange(mode, case):
     assert n0 + n1 == len(cand) and (n1 == 0 or p1 == n0)           # list positions are continuous across ranks
 
 
+def _raw_comm_worker(rank, world, port, ret):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        # a backend that is not RCCL has no communicator to hand below the C ABI: the exchanges stay on torch.distributed
+        ret[rank] = (sharding.raw_comm(dist.group.WORLD, "cpu"), sharding.raw_comm(None, "cpu"))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_no_raw_communicator_outside_rccl():
+    port = _free_port()
+    with mp.Manager() as mgr:
+        ret = mgr.dict()
+        mp.spawn(_raw_comm_worker, args=(2, port, ret), nprocs=2, join=True)
+        assert dict(ret) == {0: (None, None), 1: (None, None)}
+    assert sharding.raw_comm(None, "cpu") is None      # no process group at all
+
+
 def test_row_range_tiles():
     for n in (1, 7, 64, 9298, 1000003):
         for world in (1, 2, 3, 8):
