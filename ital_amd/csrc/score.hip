@@ -47,8 +47,10 @@
 #endif
 #ifndef ITAL_QMC_WAVES
 // waves per SIMD the register allocation aims at: four up to t = 4 (126 registers), three at t = 5, 6 (145 / 167: per step
-// 24.8 -> 21.1 ms, 95 -> 80 ms at 25 000 candidates) and at t = 7, 8 (168 each with four chains)
-#define ITAL_QMC_WAVES(T) ((T) <= 4 ? 4 : 3)
+// 24.8 -> 21.1 ms, 95 -> 80 ms at 25 000 candidates) and at t = 7, 8 (168 each with four chains); FIVE at t = 3 since the
+// all-upper form and the rational-only Phi brought its six chains down to 95 registers (0.386 -> 0.377 ms per launch, A/B on
+// one box; before that five waves meant 12 B of scratch and no gain)
+#define ITAL_QMC_WAVES(T) ((T) == 3 ? 5 : (T) <= 4 ? 4 : 3)
 #endif
 #ifndef ITAL_QMC_MAIN_PS
 #define ITAL_QMC_MAIN_PS(T) ((T) >= 7)   // lattice coordinates formed per stage (qmc_lane_sum_ps): T = 7, 8 spill otherwise

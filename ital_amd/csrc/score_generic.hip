@@ -90,7 +90,7 @@
 #ifndef ITAL_GEN_MAIN_WAVES
 // waves per SIMD the lattice-sum kernels aim at: four up to 4 variables (120 registers with six chains), three at 5 and 6,
 // two beyond (noisy-user round 41.0 -> 36.5 ms with six chains at these occupancies; four chains at four waves: 38.1)
-#define ITAL_GEN_MAIN_WAVES(T) ((T) > 0 && (T) < 5 ? 4 : (((T) >= 5 && (T) <= 10) || (T) == 13 || (T) == 14 ? 3 : 2))
+#define ITAL_GEN_MAIN_WAVES(T) ((T) == 3 ? 5 : (T) > 0 && (T) < 5 ? 4 : (((T) >= 5 && (T) <= 10) || (T) == 13 || (T) == 14 ? 3 : 2))
 #endif
 #ifndef ITAL_GEN_TFIX_MAX
 #define ITAL_GEN_TFIX_MAX 16   // largest dimension the pipeline takes (plain mode)
