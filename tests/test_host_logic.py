@@ -313,3 +313,47 @@ def test_contiguous_runs_is_a_function_of_the_list_alone():
     assert not sharding.contiguous_runs(shuffled, n, world)
     assert sharding.contiguous_runs(shuffled, n, 1)
     assert sharding.contiguous_runs(np.array([10, 11, 600, 990]), n, world)
+
+
+def test_round_entry_points_refuse_bad_descriptors_without_touching_the_device():
+    """Argument checks of the one-call entry points happen before any HIP call: usable (and tested) without a GPU.  Every
+    refusal is -22 with a message that names the entry point."""
+    import ctypes
+    from ital_amd import _lib
+    lib = _lib.lib()
+
+    def refused(rc, name):
+        assert rc == -22
+        assert name in lib.ital_last_error().decode()
+
+    refused(lib.ital_fetch_round(None, None), "ital_fetch_round")
+    r = _lib.ItalRoundDesc()
+    r.k = 0
+    refused(lib.ital_fetch_round(ctypes.byref(r), None), "ital_fetch_round")           # k outside 1 .. 8
+    r.k = 4
+    r.step.batch.kmax = 4
+    r.step.n_cand = 2
+    refused(lib.ital_fetch_round(ctypes.byref(r), None), "ital_fetch_round")           # fewer candidates than steps
+    r.step.n_cand = 100
+    refused(lib.ital_fetch_round(ctypes.byref(r), None), "ital_fetch_round")           # sel_* missing
+    r.world = 2                                                                           # several ranks without a transport
+    refused(lib.ital_fetch_round(ctypes.byref(r), None), "ital_fetch_round")
+    r.world = 0
+    r.step.n_cand = (1 << 18) + 1
+    refused(lib.ital_fetch_round(ctypes.byref(r), None), "ital_fetch_round")           # beyond the single-call limit
+
+    refused(lib.ital_mcmi_round(None, None), "ital_mcmi_round")
+    m = _lib.ItalMcmiRoundDesc()
+    m.k = 9
+    refused(lib.ital_mcmi_round(ctypes.byref(m), None), "ital_mcmi_round")
+    m.k = 2
+    m.step.batch.kmax = 2
+    m.step.n_i, m.step.n_all, m.step.pos_offset = 10, 12, 0
+    refused(lib.ital_mcmi_round(ctypes.byref(m), None), "ital_mcmi_round")             # one rank scores the whole block
+    m.step.n_all = 10
+    refused(lib.ital_mcmi_round(ctypes.byref(m), None), "ital_mcmi_round")             # null buffers
+
+    refused(lib.ital_gather_block(None, 5, 0, 10, None, None, 16, None, 16, 0, None, None, None, None, 16, None, None, None, None),
+            "ital_gather_block")
+    assert lib.ital_gather_block(None, 0, 0, 10, None, None, 16, None, 16, 0, None, None, None, None, 16, None, None, None, None) == 0
+    refused(lib.ital_select_exchange(None, None, 0, None, None), "ital_select_exchange")
