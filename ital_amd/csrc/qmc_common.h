@@ -35,6 +35,20 @@ __device__ __forceinline__ double uniform_f64(double v) {
     return __hiloint2double(hi, lo);
 }
 
+// Width of the interval of a variable that entered NEGATED (ITAL_QMC_FLIP): MVNDFN forms it as 1 - Phi(z) from the rounded
+// Phi(z) = 1 - p (z > 0) -- exactly 0 once p <= 2^-54, a multiple of 2^-53 below ~1e-3 -- and the reference's logic hangs on
+// such exact zeros (`mi == 0` in the pessimistic label estimation, log(0 + eps)).  The negated form computes Phi(-z) = p
+// itself; 1 - (1 - w) reproduces MVNDFN's value bit for bit (w >= 1/2: both subtractions are exact, nothing changes).
+// `flipped` is wave-uniform: a scalar branch around two additions per chain (the empty asm keeps it a branch).
+template <int NCB>
+__device__ __forceinline__ void flip_width(double (&w)[NCB], bool flipped) {
+    if (flipped) {
+        __asm__ volatile("");
+#pragma unroll
+        for (int c = 0; c < NCB; c++) w[c] = 1.0 - (1.0 - w[c]);
+    }
+}
+
 // Four independent Phi^-1 arguments per lane.  Every lane runs the cheap central branch of AS241; the ~15 % of the
 // arguments that fall into the tails (|p - 1/2| > 0.425) are compacted across the wave through LDS so that the
 // expensive log/sqrt branch runs on full waves of tail arguments only (typically once per 256 inversions instead of
@@ -80,7 +94,8 @@ __device__ __forceinline__ void phinv_wave(const double (&p)[NC], double (&out)[
 // The integrand of NCB lattice points per lane (MVNDFN for one-sided limits): sequential conditioning over the T
 // variables, every chain independent of the others; returns the lane's sum of the integrand values.  cf: packed strict
 // lower triangle of the row-scaled factor, lm: scaled limits (wave-uniform), bit i of infi: variable i is bounded below.
-template <int T, int NCB, class K>
+// FL: the call is in the all-upper form (ITAL_QMC_FLIP); bit i of infi then marks the variables that entered negated.
+template <int T, int NCB, class K, bool FL = false>
 __device__ __forceinline__ double eval_chains(const double (&xx)[NCB][(T - 1 > 0 ? T - 1 : 1)], bool (&dead)[NCB],
                                               const double (&cf)[(T * (T - 1) / 2 > 0 ? T * (T - 1) / 2 : 1)],
                                               const double (&lm)[T], unsigned infi_c, double* tailq, int lane, const K& kk) {
@@ -92,17 +107,21 @@ __device__ __forceinline__ double eval_chains(const double (&xx)[NCB][(T - 1 > 0
 #pragma unroll
     for (int i = 0; i < T; i++) {
         const bool lower = (infi_c >> i) & 1u;
-        double pin[NCB];
+        double pin[NCB], ph[NCB];
 #pragma unroll
         for (int c = 0; c < NCB; c++) {
             double sc = 0;
 #pragma unroll
             for (int j = 0; j < i; j++) sc = fma(cf[i * (i - 1) / 2 + j], yy[c][j], sc);
-            const double ph = mvn_phi_lat(lm[i] - sc, kk);
-            const double d = lower ? ph : 0.0;
-            const double w = lower ? 1.0 - ph : ph;
+            ph[c] = mvn_phi_lat(lm[i] - sc, kk);
+        }
+        if (FL) flip_width<NCB>(ph, lower);
+#pragma unroll
+        for (int c = 0; c < NCB; c++) {
+            const double d = (!FL && lower) ? ph[c] : 0.0;
+            const double w = (!FL && lower) ? 1.0 - ph[c] : ph[c];
             ff[c] *= w;
-            if (i < T - 1) pin[c] = fma(xx[c][i], w, d);   // a dead chain (w == 0) just inverts d: finite, discarded
+            if (i < T - 1) pin[c] = FL ? xx[c][i] * w : fma(xx[c][i], w, d);   // a dead chain (w == 0) just inverts d: finite, discarded
         }
         if (i < T - 1) {
             double out[NCB];
@@ -120,7 +139,7 @@ __device__ __forceinline__ double eval_chains(const double (&xx)[NCB][(T - 1 > 0
 // Sum over this lane's share of the 16 P lattice points of one orthant call of compile-time dimension T (8 randomly
 // shifted Korobov lattices of P points, each point with its antithetic partner).  lat: [8][NDIM] permuted generators, then
 // [8][NDIM] shifts; cf / lm / infi as eval_chains.  The caller adds the lanes up and divides by 16 P.
-template <int T, class K = LitK, int NH_ = ITAL_QMC_NH>
+template <int T, class K = LitK, int NH_ = ITAL_QMC_NH, bool FL = false>
 __device__ __forceinline__ double qmc_lane_sum(const double* __restrict__ lat,
                                                const double (&cf)[(T * (T - 1) / 2 > 0 ? T * (T - 1) / 2 : 1)],
                                                const double (&lm)[T], unsigned infi_c, double* __restrict__ tailq, int lane,
@@ -155,7 +174,7 @@ __device__ __forceinline__ double qmc_lane_sum(const double* __restrict__ lat,
             }
             dead[2 * h] = dead[2 * h + 1] = !ok;
         }
-        acc += eval_chains<T, NC>(xx, dead, cf, lm, infi_c, tailq, lane, kk);
+        acc += eval_chains<T, NC, K, FL>(xx, dead, cf, lm, infi_c, tailq, lane, kk);
     }
     if (NCL > 0 && NCL != NC) {
         constexpr int NCLA = NCL > 0 ? NCL : 1;
@@ -193,7 +212,7 @@ __device__ __forceinline__ double qmc_lane_sum(const double* __restrict__ lat,
             }
             dead[NCLA - 1] = !ok;
         }
-        acc += eval_chains<T, NCLA>(xx, dead, cf, lm, infi_c, tailq, lane, kk);
+        acc += eval_chains<T, NCLA, K, FL>(xx, dead, cf, lm, infi_c, tailq, lane, kk);
     }
     return acc;
 }
@@ -205,7 +224,7 @@ __device__ __forceinline__ double qmc_lane_sum(const double* __restrict__ lat,
 // broadcast reads per item: 64 consecutive items span at most two shifts) and serves the point and its antithetic partner.
 // CFL: the factor and the limits are read from LDS at use as well (`slab`: NCOR factor values, then T limits) instead
 // of living in 2 (NCOR + T) scalar registers.
-template <int T, int NI, bool CFL, class K>
+template <int T, int NI, bool CFL, class K, bool FL = false>
 __device__ __forceinline__ double eval_items_ps(const int (&kq)[NI], const int (&so)[NI], const bool (&ok)[NI],
                                                 const double* __restrict__ lat,
                                                 const double (&cf)[(T * (T - 1) / 2 > 0 ? T * (T - 1) / 2 : 1)],
@@ -229,7 +248,10 @@ __device__ __forceinline__ double eval_items_ps(const int (&kq)[NI], const int (
 #pragma unroll
             for (int c = 0; c < NCB; c++) sc[c] = fma(cij, yy[c][j], sc[c]);
         }
-        double pin[NCB];
+        double pin[NCB], ph[NCB];
+#pragma unroll
+        for (int c = 0; c < NCB; c++) ph[c] = mvn_phi_lat(lmi - sc[c], kk);
+        if (FL) flip_width<NCB>(ph, lower);
 #pragma unroll
         for (int h = 0; h < NI; h++) {
             double x0 = 0;
@@ -241,11 +263,10 @@ __device__ __forceinline__ double eval_items_ps(const int (&kq)[NI], const int (
 #pragma unroll
             for (int a = 0; a < 2; a++) {
                 const int c = 2 * h + a;
-                const double ph = mvn_phi_lat(lmi - sc[c], kk);
-                const double d = lower ? ph : 0.0;
-                const double w = lower ? 1.0 - ph : ph;
+                const double d = (!FL && lower) ? ph[c] : 0.0;
+                const double w = (!FL && lower) ? 1.0 - ph[c] : ph[c];
                 ff[c] *= w;
-                if (i < T - 1) pin[c] = fma(a ? 1 - x0 : x0, w, d);
+                if (i < T - 1) pin[c] = FL ? (a ? 1 - x0 : x0) * w : fma(a ? 1 - x0 : x0, w, d);
             }
         }
         if (i < T - 1) {
@@ -261,7 +282,7 @@ __device__ __forceinline__ double eval_items_ps(const int (&kq)[NI], const int (
     return acc;
 }
 
-template <int T, class K, int NH, bool CFL>
+template <int T, class K, int NH, bool CFL, bool FL = false>
 __device__ __forceinline__ double qmc_lane_sum_ps(const double* __restrict__ lat,
                                                   const double (&cf)[(T * (T - 1) / 2 > 0 ? T * (T - 1) / 2 : 1)],
                                                   const double (&lm)[T], const double* __restrict__ slab, unsigned infi_c,
@@ -283,7 +304,7 @@ __device__ __forceinline__ double qmc_lane_sum_ps(const double* __restrict__ lat
             kq[h] = it - sft * PRIME + 1;
             so[h] = sft * NDIM;
         }
-        acc += eval_items_ps<T, NH, CFL>(kq, so, ok, lat, cf, lm, slab, infi_c, tailq, lane, kk);
+        acc += eval_items_ps<T, NH, CFL, K, FL>(kq, so, ok, lat, cf, lm, slab, infi_c, tailq, lane, kk);
     }
     if (NIL > 0 && NIL != NH) {
         constexpr int NILA = NIL > 0 ? NIL : 1;
@@ -298,7 +319,7 @@ __device__ __forceinline__ double qmc_lane_sum_ps(const double* __restrict__ lat
             kq[h] = it - sft * PRIME + 1;
             so[h] = sft * NDIM;
         }
-        acc += eval_items_ps<T, NILA, CFL>(kq, so, ok, lat, cf, lm, slab, infi_c, tailq, lane, kk);
+        acc += eval_items_ps<T, NILA, CFL, K, FL>(kq, so, ok, lat, cf, lm, slab, infi_c, tailq, lane, kk);
     }
     return acc;
 }
@@ -308,7 +329,7 @@ __device__ __forceinline__ double qmc_lane_sum_ps(const double* __restrict__ lat
 // LDS at use (`slab`: packed lower triangle with diagonal, then the limits -- the evaluator's record), the lattice
 // coordinates are formed per stage instead of up front; the conditioned values y (2 NH chains x T-1) stay in registers
 // because every index is a compile-time constant.
-template <int T, int NCB, class K>
+template <int T, int NCB, class K, bool FL = false>
 __device__ __forceinline__ double eval_chains_big(const int (&kk)[NCB], const int (&so)[NCB], const bool (&anti)[NCB],
                                                   const bool (&ok)[NCB], const double* __restrict__ lat,
                                                   const double* __restrict__ slab, unsigned infi_c, double* tailq, int lane,
@@ -332,18 +353,20 @@ __device__ __forceinline__ double eval_chains_big(const int (&kk)[NCB], const in
 #pragma unroll
             for (int c = 0; c < NCB; c++) sc[c] = fma(cij, yy[c][j], sc[c]);
         }
-        double pin[NCB];
+        double pin[NCB], ph[NCB];
+#pragma unroll
+        for (int c = 0; c < NCB; c++) ph[c] = mvn_phi_lat(lmi - sc[c], coef);
+        if (FL) flip_width<NCB>(ph, lower);
 #pragma unroll
         for (int c = 0; c < NCB; c++) {
-            const double ph = mvn_phi_lat(lmi - sc[c], coef);
-            const double d = lower ? ph : 0.0;
-            const double w = lower ? 1.0 - ph : ph;
+            const double d = (!FL && lower) ? ph[c] : 0.0;
+            const double w = (!FL && lower) ? 1.0 - ph[c] : ph[c];
             ff[c] *= w;
             if (i < T - 1) {
                 const double v = kk[c] * lat[so[c] + i] + lat[8 * NDIM + so[c] + i];
                 const double fr = v - floor(v);
                 const double x0 = fabs(2 * fr - 1);
-                pin[c] = fma(anti[c] ? 1 - x0 : x0, w, d);
+                pin[c] = FL ? (anti[c] ? 1 - x0 : x0) * w : fma(anti[c] ? 1 - x0 : x0, w, d);
             }
         }
         if (i < T - 1) {
@@ -361,7 +384,7 @@ __device__ __forceinline__ double eval_chains_big(const int (&kk)[NCB], const in
 
 // NCB chains per lane and round: whole lattice items (a point and its antithetic partner on the same lane) first; with an
 // odd NCB the last chain of lanes 2i and 2i + 1 is the point and the partner of one more item (32 NCB items per round).
-template <int T, int NCB, class K = LitK>
+template <int T, int NCB, class K = LitK, bool FL = false>
 __device__ __forceinline__ double qmc_lane_sum_big(const double* __restrict__ lat, const double* __restrict__ slab,
                                                    unsigned infi_c, double* __restrict__ tailq, int lane, const K& coef = K()) {
     constexpr int NDIM = T - 1, PRIME = P_TAB[(NDIM < 10 ? NDIM : 10) - 1];
@@ -381,7 +404,7 @@ __device__ __forceinline__ double qmc_lane_sum_big(const double* __restrict__ la
             kk[c] = it - sft * PRIME + 1;
             so[c] = sft * NDIM;
         }
-        acc += eval_chains_big<T, NCB>(kk, so, anti, ok, lat, slab, infi_c, tailq, lane, coef);
+        acc += eval_chains_big<T, NCB, K, FL>(kk, so, anti, ok, lat, slab, infi_c, tailq, lane, coef);
     }
     return acc;
 }

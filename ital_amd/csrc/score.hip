@@ -47,10 +47,10 @@
 #endif
 #ifndef ITAL_QMC_WAVES
 // waves per SIMD the register allocation aims at: four up to t = 4 (126 registers), three at t = 5, 6 (145 / 167: per step
-// 24.8 -> 21.1 ms, 95 -> 80 ms at 25 000 candidates) and at t = 7, 8 (168 each with four chains); FIVE at t = 3 since the
-// all-upper form and the rational-only Phi brought its six chains down to 95 registers (0.386 -> 0.377 ms per launch, A/B on
-// one box; before that five waves meant 12 B of scratch and no gain)
-#define ITAL_QMC_WAVES(T) ((T) == 3 ? 5 : (T) <= 4 ? 4 : 3)
+// 24.8 -> 21.1 ms, 95 -> 80 ms at 25 000 candidates) and at t = 7, 8 (168 each with four chains).  (Five at t = 3 fits
+// without scratch only without the width emulation of negated variables -- flip_width, qmc_common.h -- and was worth
+// 2 %: 0.386 -> 0.377 ms; with it 12 B of scratch: four.)
+#define ITAL_QMC_WAVES(T) ((T) <= 4 ? 4 : 3)
 #endif
 #ifndef ITAL_QMC_MAIN_PS
 #define ITAL_QMC_MAIN_PS(T) ((T) >= 7)   // lattice coordinates formed per stage (qmc_lane_sum_ps): T = 7, 8 spill otherwise
@@ -534,17 +534,18 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(ITAL_QMC_WA
 #pragma unroll
             for (int q = 0; q < T; q++) lm[q] = uniform_f64(rec[Q::R_LIM + q]);
         }
-        const unsigned infi = ITAL_QMC_FLIP ? 0u : (unsigned)(meta >> 8);
+        const unsigned infi = (unsigned)(meta >> 8) & ((1u << T) - 1u);   // FLIP: the variables that entered negated
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 #if ITAL_QMC_HOTK
         typename Q::Coef kk;
         kk.load();
-        const double acc = Q::PS ? qmc_lane_sum_ps<T, typename Q::Coef, Q::NH, Q::CFL>(lat, cf, lm, slab, infi, tailq, lane, kk)
-                                 : qmc_lane_sum<T, typename Q::Coef, Q::NH>(lat, cf, lm, infi, tailq, lane, kk);
+        constexpr bool FL = ITAL_QMC_FLIP != 0;
+        const double acc = Q::PS ? qmc_lane_sum_ps<T, typename Q::Coef, Q::NH, Q::CFL, FL>(lat, cf, lm, slab, infi, tailq, lane, kk)
+                                 : qmc_lane_sum<T, typename Q::Coef, Q::NH, FL>(lat, cf, lm, infi, tailq, lane, kk);
 #else
-        const double acc = qmc_lane_sum<T, LitK, Q::NH>(lat, cf, lm, infi, tailq, lane);
+        const double acc = qmc_lane_sum<T, LitK, Q::NH, ITAL_QMC_FLIP != 0>(lat, cf, lm, infi, tailq, lane);
 #endif
         pr = wave_sum(acc) / (16.0 * Q::PRIME);
     }

@@ -90,7 +90,7 @@
 #ifndef ITAL_GEN_MAIN_WAVES
 // waves per SIMD the lattice-sum kernels aim at: four up to 4 variables (120 registers with six chains), three at 5 and 6,
 // two beyond (noisy-user round 41.0 -> 36.5 ms with six chains at these occupancies; four chains at four waves: 38.1)
-#define ITAL_GEN_MAIN_WAVES(T) ((T) == 3 ? 5 : (T) > 0 && (T) < 5 ? 4 : (((T) >= 5 && (T) <= 10) || (T) == 13 || (T) == 14 ? 3 : 2))
+#define ITAL_GEN_MAIN_WAVES(T) ((T) > 0 && (T) < 5 ? 4 : (((T) >= 5 && (T) <= 10) || (T) == 13 || (T) == 14 ? 3 : 2))
 #endif
 #ifndef ITAL_GEN_TFIX_MAX
 #define ITAL_GEN_TFIX_MAX 16   // largest dimension the pipeline takes (plain mode)
@@ -704,7 +704,7 @@ __device__ double qmc_eval(int n, const double* __restrict__ slab, unsigned infi
 // One MVNDST pass for a call of compile-time dimension T whose rows all close their own group (no linearly dependent
 // variable): the evaluator of the perfect-user fast path (score.hip) -- factor and limits as wave-uniform scalars, fully
 // unrolled, NHF lattice items x antithetic partner per lane.
-template <int T, int NHF = 2>
+template <int T, int NHF = 2, bool FL = false>
 __device__ __forceinline__ double qmc_eval_fixed_inl(const double* __restrict__ slab, unsigned infi,
                                                      const double* __restrict__ lat, int lane, double* __restrict__ tailq) {
     constexpr int NDIM = T - 1, NCOV = T * (T + 1) / 2, NCOR = T * (T - 1) / 2;
@@ -719,9 +719,9 @@ __device__ __forceinline__ double qmc_eval_fixed_inl(const double* __restrict__ 
 #if ITAL_GEN_HOTK
     HotK kk;
     kk.load();
-    const double acc = qmc_lane_sum<T, HotK, NHF>(lat, cf, lm, infi, tailq, lane, kk);
+    const double acc = qmc_lane_sum<T, HotK, NHF, FL>(lat, cf, lm, infi, tailq, lane, kk);
 #else
-    const double acc = qmc_lane_sum<T, LitK, NHF>(lat, cf, lm, infi, tailq, lane);
+    const double acc = qmc_lane_sum<T, LitK, NHF, FL>(lat, cf, lm, infi, tailq, lane);
 #endif
     return wave_sum(acc) / (16.0 * PRIME);
 }
@@ -1208,7 +1208,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(ITAL_GEN_MA
             if (fl && q >= 8 * (n - 1) && ((fl >> (q % (n - 1))) & 1u)) v += 0.5;   // the shifts of a negated variable
             rec[g.lat + q] = v;
         }
-        const unsigned infi_e = (T > 0 && ITAL_QMC_FLIP) ? 0u : infi;
+        constexpr bool FL = T > 0 && ITAL_QMC_FLIP != 0;
+        const unsigned infi_e = infi;          // FL: the variables that entered negated
         wave_sync();
         double value;
         if (T >= 7) {
@@ -1216,15 +1217,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(ITAL_GEN_MA
 #if ITAL_GEN_BIG_HOTK
             ITAL_GEN_BIG_COEF kk;      // exp coefficients as vector-register operands (device_math.h), as in the perfect-user kernel
             kk.load();
-            value = wave_sum(qmc_lane_sum_big<TB, ITAL_GEN_BIG_NCB(TB), ITAL_GEN_BIG_COEF>(rec + g.lat, rec, infi_e, tailq, lane, kk)) /
+            value = wave_sum(qmc_lane_sum_big<TB, ITAL_GEN_BIG_NCB(TB), ITAL_GEN_BIG_COEF, FL>(rec + g.lat, rec, infi_e, tailq, lane, kk)) /
                     (16.0 * P_TAB[(NDIMB < 10 ? NDIMB : 10) - 1]);
 #else
-            value = wave_sum(qmc_lane_sum_big<TB, ITAL_GEN_BIG_NCB(TB)>(rec + g.lat, rec, infi_e, tailq, lane)) /
+            value = wave_sum(qmc_lane_sum_big<TB, ITAL_GEN_BIG_NCB(TB), LitK, FL>(rec + g.lat, rec, infi_e, tailq, lane)) /
                     (16.0 * P_TAB[(NDIMB < 10 ? NDIMB : 10) - 1]);
 #endif
         } else if (T > 0) {
             constexpr int TF = T > 0 && T < 7 ? T : 3;
-            value = qmc_eval_fixed_inl<TF, ITAL_GEN_FIXED_NH(TF)>(rec, infi_e, rec + g.lat, lane, tailq);
+            value = qmc_eval_fixed_inl<TF, ITAL_GEN_FIXED_NH(TF), FL>(rec, infi_e, rec + g.lat, lane, tailq);
         }
         else value = qmc_eval<ITAL_GENERIC_MAX_DIM, 1>(n, rec, infi, (unsigned)((m >> 40) & 0xffffffu), rec + g.lat, lane, tailq);
         if (lane == 0) meta[1] = value;

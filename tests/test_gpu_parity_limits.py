@@ -1,4 +1,5 @@
-"""The two limits of "the reference's picks, exactly" -- pinned (README):
+"""The two limits of "the reference's picks, exactly" -- pinned (README) -- and one semantic of the
+reference that an optimisation once broke (exact zeros of an interval width, last-but-one test):
 
 1. NUMERICAL TIES.  Where the reference's own arithmetic rates two candidates equal to ~1e-12 relative (samples that carry
    no information any more: every MI value of the step agrees to 15 digits), its arg-max is decided by the last bits of a
@@ -114,6 +115,36 @@ def test_candidates_without_information_are_ties():
         fb = {i: (1 if X[i, 0] > 0.5 else -1) for i in got}
         A.update(fb)
         B.update(fb)
+
+
+def test_exact_zeros_of_the_interval_width_are_the_references():
+    """Fuzz case 884 of seed 47 (`label_estimation = 'pessimistic'`, second round, third greedy step).  The reference's rule
+    `if (mi == 0) or (cur_mi < mi)` (ital.py:214-216) hangs on EXACT zeros: a sign pattern whose prior probability MVNDFN
+    returns as exactly 0 -- an interval [a', inf) whose width 1 - Phi(a') rounds to 0 because Phi(a') rounds to 1 -- gives
+    cur_mi = log(0 + eps) - log(0 + eps) = 0, and the running value is reset by the next pattern.  A lattice sum that forms
+    the width as Phi(-a') (1e-17 instead of 0) turns that term into -1e-8 and the step's score of candidate 35 into 3.4e-9
+    instead of 27.63 (seen with the first version of the all-upper form, qmc_common.h ITAL_QMC_FLIP).  The negated
+    variables now reproduce 1 - Phi(a') bit for bit (flip_width): picks and every score as the oracle's."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    case = 884
+    c, A, B = _pair(47, case)
+    X, k = c["X"], c["k"]
+    assert (c["kind"], c["n"], c["d"], k, c["kw"]) == ("optimistic", 70, 2, 4, {"label_estimation": "pessimistic"})
+    saw_reset = False
+    for rnd in range(2):
+        np.random.seed(case * 7 + rnd)
+        got = A.fetch_unlabelled(k)
+        np.random.seed(case * 7 + rnd)
+        want = [int(i) for i in B.fetch_unlabelled(k)]
+        assert got == want
+        for mine, (cand, vals, _) in zip(_device_scores(A, B.trace), B.trace):
+            np.testing.assert_allclose(mine, vals, rtol=1e-8, atol=1e-13)
+            saw_reset |= bool(np.any(np.abs(vals - 27.631021115928547) < 1e-9))      # -log(eps): a pattern of probability 0
+        fb = {i: (1 if X[i, 0] > 0.5 else -1) for i in got}
+        A.update(fb)
+        B.update(fb)
+    assert saw_reset
 
 
 @pytest.mark.parametrize("seed0,case", [(11, 150), (13, 87)])
