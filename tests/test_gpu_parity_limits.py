@@ -13,7 +13,7 @@ reference that an optimisation once broke (exact zeros of an interval width, las
    continuous function of the matrix, so a last-bit difference gives a candidate other, equally valid patterns (measured:
    1 of 191 candidates at 125 000 x 512, 2 of 1000 fuzz cases).  Rule: for the patterns the device sampled the oracle's
    estimate equals the device's for EVERY candidate (strict); the oracle's own sampling reproduces the device's value for
-   at least 98 % of the (step, candidate) pairs (loose).  Instances: fuzz cases 150 (seed 11), 87 (seed 13), 78 and 271 (seed 47).
+   at least 98 % of the (step, candidate) pairs (loose).  Instances: fuzz cases 150 (seed 11), 87 (seed 13), 78 and 271 (seed 47), 13 (seed 59).
 """
 import os
 import sys
@@ -184,7 +184,7 @@ def test_exact_equality_reset_of_label_estimation_is_a_limit(monkeypatch):
     assert 0 < affected <= 0.02 * total, (affected, total)
 
 
-@pytest.mark.parametrize("seed0,case", [(11, 150), (13, 87), (47, 78), (47, 271)])
+@pytest.mark.parametrize("seed0,case", [(11, 150), (13, 87), (47, 78), (47, 271), (59, 13)])
 def test_resampled_monte_carlo_patterns(seed0, case):
     if not torch.cuda.is_available():
         pytest.skip("no GPU")
