@@ -343,7 +343,10 @@ class GaussianProcess(object):
             if keep:
                 self._gather_bufs[keep] = bufs
         send, recv = bufs
-        send[: self.n] = loc
+        if self.n == pad and loc.is_contiguous():
+            send = loc                       # equal shards: the local vector is the send buffer, no staging copy
+        else:
+            send[: self.n] = loc
         sharding.gather_records(send, recv, self.group)
         if pad * self.world == self.n_total:
             return recv.view(-1)
