@@ -524,9 +524,10 @@ class ITAL(ActiveRetrievalBase):
                     state_after=tuple(int(v) for v in st6), draws=draws, events=events, sig=self._round_signature(b, k))
 
     def _select_round(self, k, candidates):
-        """The one-rank path of _select as ONE call below the C ABI (ital_fetch_round): candidate-list upkeep, k scoring
-        steps that end with their selection, k - 1 covariance columns -- enqueued from C (a Python host needs 10 - 17 us per
-        launch, the first greedy steps are shorter than that).  The candidate list stays on the device between rounds: when
+        """_select as ONE call below the C ABI (ital_fetch_round): candidate-list upkeep, k scoring steps that end with
+        their selection (several ranks: with the rank's record, then the exchange issued from C and the resolve launch),
+        k - 1 covariance columns -- enqueued from C (a Python host needs 10 - 17 us per launch, the first greedy steps are
+        shorter than that).  Several ranks work on their own share of the list (list positions lo .. hi).  The candidate list stays on the device between rounds: when
         the list is the previous one minus the previous batch (the retrieval loop: fetch, label the batch, fetch), it is
         compacted there by its alive flags instead of being rebuilt and uploaded; and the descriptor of such a next round
         is filled in while the GPU still works on the current one."""
