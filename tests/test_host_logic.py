@@ -357,3 +357,26 @@ def test_round_entry_points_refuse_bad_descriptors_without_touching_the_device()
             "ital_gather_block")
     assert lib.ital_gather_block(None, 0, 0, 10, None, None, 16, None, 16, 0, None, None, None, None, 16, None, None, None, None) == 0
     refused(lib.ital_select_exchange(None, None, 0, None, None), "ital_select_exchange")
+
+
+def test_all_upper_form_of_the_lattice_sums_is_an_identity_and_keeps_the_references_roundings():
+    """The arithmetic behind ITAL_QMC_FLIP (csrc/qmc_common.h), checked on the host: a variable bounded below enters the
+    lattice sums negated.  (1) Phi^-1(d + x (1 - d)), d = Phi(z), equals -Phi^-1((1 - x) Phi(-z)); (2) the lattice
+    coordinate of the negated variable, |2 frac(v + 1/2) - 1|, is 1 - |2 frac(v) - 1|; (3) the interval width the reference
+    forms, 1 - Phi(z) with the ROUNDED Phi(z) = 1 - p, is what flip_width rebuilds from p = Phi(-z): 1 - (1 - p) -- exactly 0
+    iff p <= 2^-54, a multiple of 2^-53 below 1/2, and the identity for widths >= 1/2."""
+    from scipy.special import ndtr, ndtri
+    rng = np.random.default_rng(12)
+    z = rng.uniform(-3, 3, 2000)        # (further out the reference's own form d + x (1 - d) loses digits next to 1:
+    x = rng.uniform(0.001, 0.999, 2000)  #  1e-7 in Phi^-1 at z = 6 -- the negated form does not)
+    d = ndtr(z)
+    np.testing.assert_allclose(ndtri(d + x * (1 - d)), -ndtri((1 - x) * ndtr(-z)), rtol=1e-9, atol=1e-9)
+    v = rng.uniform(0, 1400, 5000)
+    fr = lambda t: t - np.floor(t)
+    np.testing.assert_allclose(np.abs(2 * fr(v + 0.5) - 1), 1 - np.abs(2 * fr(v) - 1), rtol=0, atol=1e-12)
+    p = np.array([0.0, 2.0 ** -60, 2.0 ** -54, np.nextafter(2.0 ** -54, 1), 2.0 ** -53, 1e-16, 3e-16, 1e-9, 0.3])
+    w = 1.0 - (1.0 - p)
+    assert list(w[:3]) == [0.0, 0.0, 0.0] and np.all(w[3:] > 0)
+    assert np.all(w / 2.0 ** -53 == np.round(w / 2.0 ** -53))            # on the grid of doubles below 1
+    big = rng.uniform(0.5, 1.0, 1000)
+    assert np.array_equal(1.0 - (1.0 - big), big)
