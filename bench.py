@@ -50,10 +50,12 @@ VALU_PER_PAIR_CHAIN = 47 + 0.85 * 45 + 0.15 * 121      # vector instructions of 
 FLOP_PER_MCMI_TERM = 53 + 2 * 44 + 6
 # committed counter summaries (rocprofv3 --pmc passes of this very command, tools/profile_gpu.sh + tools/pmc_summary.py):
 # HBM traffic and instruction counts per launch are read from these files and the file is named in the output
-PMC_FILES = {"headline": "profiles/r3_headline_pmc_summary.csv", "general": "profiles/r3_general_pmc_summary.csv",
-             "k8": "profiles/r3_k8_pmc_summary.csv"}
-ROUND_GAPS_FILE = "profiles/r3_round_gaps.json"   # launches / busy fraction of a round out of a committed kernel trace
-CALIBRATION_FILE = "profiles/r2_oracle_calibration.json"
+PMC_FILES = {"headline": "profiles/r4_headline_pmc_summary.csv", "general": "profiles/r4_general_pmc_summary.csv",
+             "k8": "profiles/r4_k8_pmc_summary.csv"}
+ROUND_GAPS_FILE = "profiles/r4_round_gaps.json"   # launches / busy fraction of a round out of a committed kernel trace
+CALIBRATION_FILE = "profiles/r4_oracle_calibration.json"
+STAMP_FILE = "profiles/r4_stamp.json"             # kernel sources each committed profile was taken with (tools/stamp.py)
+PICKS_N1_FILE = "profiles/scaling_picks_n1.json"   # the batches the N = 1 run of scaling_workload picks (bench.py wrote it on one GPU)
 
 
 def make_data(n, d, seed):
@@ -123,6 +125,27 @@ def hbm_stream_probe(device, rows=1_000_000, d=DIM, m=21, reps=10):
             "note": "same kernel as the greedy steps' cross-covariance column, at 1M rows (2.2 GB per launch)"}
 
 
+def profile_is_current(rel_path):
+    """(True, stamp) when the committed profile `rel_path` was taken with the kernel sources of this tree (tools/stamp.py:
+    sha256 over ital_amd/csrc/* and the header); (False, why) otherwise -- its numbers are then not quoted."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    try:
+        import stamp
+        path = os.path.join(ROOT, STAMP_FILE)
+        if not os.path.exists(path):
+            return False, "no stamp file %s" % STAMP_FILE
+        with open(path) as f:
+            entry = json.load(f).get(rel_path)
+        if entry is None:
+            return False, "%s has no stamp in %s" % (rel_path, STAMP_FILE)
+        now = stamp.csrc_sha()
+        if entry.get("csrc_sha") != now:
+            return False, "taken with other kernel sources (csrc_sha %s, this tree %s): re-run tools/profile_r4.sh" % (entry.get("csrc_sha"), now)
+        return True, entry
+    finally:
+        sys.path.pop(0)
+
+
 def pmc_row(which, kernel_prefix):
     """Row of a kernel in the committed PMC summary named by PMC_FILES[which] (collected with tools/profile_gpu.sh in
     separate passes and corrected as MI355X_MICROARCH.md prescribes), or None."""
@@ -144,6 +167,10 @@ def pmc_fields(which, kernel_prefix, launch_s):
     row = pmc_row(which, kernel_prefix)
     out = {"traffic": None, "valu_issue_frac": None, "pmc_file": PMC_FILES[which] if row else None}
     if row:
+        ok, info = profile_is_current(PMC_FILES[which])
+        out["pmc_stamp"] = info
+        if not ok:
+            return dict(out, pmc_file=None, pmc_note="counters not quoted: " + str(info))
         try:
             out["traffic"] = float(row["fetch_bytes_corrected_avg"]) + float(row["write_bytes_avg"])
         except (KeyError, ValueError):
@@ -161,8 +188,70 @@ def round_gaps():
     path = os.path.join(ROOT, ROUND_GAPS_FILE)
     if not os.path.exists(path):
         return None
+    ok, info = profile_is_current(ROUND_GAPS_FILE)
+    if not ok:
+        return {"file": None, "note": "not quoted: " + str(info)}
     with open(path) as f:
-        return dict(json.load(f), file=ROUND_GAPS_FILE)
+        return dict(json.load(f), file=ROUND_GAPS_FILE, stamp=info)
+
+
+def picks_digest(picks):
+    """sha256 (first 16 hex digits) of the rounds' picks in order, and the four 64-bit words of it that ranks compare."""
+    import hashlib
+    h = hashlib.sha256(np.asarray(picks, dtype=np.int64).tobytes()).digest()
+    return h.hex()[:16], np.frombuffer(h, dtype=np.int64).copy()
+
+
+def ranks_agree(words, device, world):
+    """True when every rank holds the same digest words (all-gather of 4 x int64 through torch.distributed)."""
+    if world == 1:
+        return True
+    import torch
+    import torch.distributed as dist
+    mine = torch.from_numpy(words).to(device)
+    got = [torch.empty_like(mine) for _ in range(world)]
+    if dist.get_backend() == "gloo":
+        got = [g.cpu() for g in got]
+        dist.all_gather(got, mine.cpu())
+        return all(bool(torch.equal(g, mine.cpu())) for g in got)
+    dist.all_gather(got, mine)
+    return all(bool(torch.equal(g, mine)) for g in got)
+
+
+def gather_floats(value, device, world):
+    """The ranks' values of one float, in rank order (on every rank)."""
+    if world == 1:
+        return [float(value)]
+    import torch
+    import torch.distributed as dist
+    t = torch.tensor([float(value)], dtype=torch.float64, device=device)
+    if dist.get_backend() == "gloo":
+        got = [torch.empty(1, dtype=torch.float64) for _ in range(world)]
+        dist.all_gather(got, t.cpu())
+    else:
+        got = [torch.empty_like(t) for _ in range(world)]
+        dist.all_gather(got, t)
+    return [float(g.item()) for g in got]
+
+
+def transport_report(learner, group, device):
+    """Which way the records of a greedy step travel on this rank, and what RCCL says about the communicator."""
+    import ctypes
+    from ital_amd import _lib, sharding
+    if not learner.gp.collective:
+        return {"transport": None}
+    import torch.distributed as dist
+    kind = learner._round_transport()
+    out = {"transport": {"nccl": "raw_nccl", "host": "host"}[kind[0]] if kind else "torch_dist",
+           "round_as_one_call": bool(kind) and learner.round_call, "group_world_size": dist.get_world_size(group)}
+    if kind and kind[0] == "nccl":
+        w, r = ctypes.c_int(-1), ctypes.c_int(-1)
+        how = ctypes.create_string_buffer(600)
+        if _lib.lib().ital_exchange_info(kind[1], ctypes.byref(w), ctypes.byref(r), how, 600) == 0:
+            out.update(rccl_world_size=w.value, rccl_rank=r.value, rccl_found=how.value.decode())
+    else:
+        out["why_not_raw_nccl"] = sharding.raw_comm_reason(group, device)
+    return out
 
 
 def other_workloads(X, rel, device):
@@ -393,8 +482,10 @@ def scaling_workload(device, rank, world, group, rounds=3):
         L.update({int(i): label(int(i)) for i in ret})
         return ret
 
+    picks = []
     L.update({0: 1})
-    one_round()                                            # warm-up
+    picks.append(one_round())                              # warm-up
+    L.host_clock = dict(gap_s=0.0, gaps=0, enqueue_s=0.0, t_download=None)
     L.profile = []
     L.event_pool = [torch.cuda.Event(enable_timing=True) for _ in range(6 * k * rounds + 16)]
     for ev in L.event_pool:
@@ -406,11 +497,28 @@ def scaling_workload(device, rank, world, group, rounds=3):
     t0 = time.perf_counter()
     for _ in range(rounds):
         n_cand = n - len(L.relevant_ids) - len(L.irrelevant_ids)
-        one_round()
+        picks.append(one_round())
         scored += sum(n_cand - t for t in range(k))
     barrier()
     dt = time.perf_counter() - t0
     launches = (_lib.lib().ital_launch_count() - launches0) / rounds
+    hc, L.host_clock = L.host_clock, None
+    # parity evidence of the run itself: every rank must have picked the same batches (digest compared across the ranks),
+    # and the batches of the N = 1 run of this workload (committed: PICKS_N1_FILE) -- the picks do not depend on the sharding
+    sha, words = picks_digest(picks)
+    agree = ranks_agree(words, device, world)
+    key = "%dx%d_k%d_rounds%d" % (n, d, k, rounds + 1)
+    ref_path = os.path.join(ROOT, PICKS_N1_FILE)
+    ref = None
+    if os.path.exists(ref_path):
+        with open(ref_path) as f:
+            ref = json.load(f).get(key)
+    if world == 1 and rank == 0 and os.environ.get("ITAL_BENCH_WRITE_PICKS"):
+        with open(os.environ["ITAL_BENCH_WRITE_PICKS"], "w") as f:
+            json.dump({key: {"picks_sha": sha, "picks": [[int(i) for i in r_] for r_ in picks]}}, f)
+    host_ms = gather_floats(hc["gap_s"] / max(hc["gaps"], 1) * 1e3 if hc["gaps"] else float("nan"), device, world)
+    enq_ms = gather_floats(hc["enqueue_s"] / max(hc["gaps"] + 1, 1) * 1e3, device, world)
+    transport = transport_report(L, group, device)
     if world > 1:
         import torch.distributed as dist
         tt = torch.tensor([dt], dtype=torch.float64, device=device)
@@ -437,6 +545,13 @@ def scaling_workload(device, rank, world, group, rounds=3):
     return {"workload": "synthetic %d x %d, k=%d, perfect user, full 2^t enumeration, fetch_unlabelled + update per round"
                         % (n, d, k), "scaling": "strong", "rows_per_rank": row1 - row0, "world_size": world,
             "backend": backend, "rounds": rounds, "ms_per_round": dt / rounds * 1e3, "candidates_per_s": scored / dt,
+            "picks_sha": sha, "picks_agree_across_ranks": agree,
+            "picks_match_n1": (sha == ref["picks_sha"]) if ref else None, "picks_n1_file": PICKS_N1_FILE if ref else None,
+            "host_ms_per_round": host_ms, "host_enqueue_ms_per_round": enq_ms,
+            "host_ms_note": "per rank: host time between the download of a round's picks and the call that enqueues the next "
+                            "round (feedback, update(), fetch prologue) / time inside that call + the next round's descriptor "
+                            "(GPU busy meanwhile); NaN: the rounds did not run as single calls",
+            **transport,
             "exchange_ms_per_greedy_step": float(np.mean(ex)) if ex else None,
             "kernel_ms": {"%s_t%d" % key: float(np.mean(v)) for key, v in sorted(prof.items())},
             "kernel_ms_note": "qmc_main_t*: the lattice-sum kernel alone (one slab of the workspace); qmc_slabsN_t*: first to "
@@ -551,14 +666,18 @@ def main():
     launches0 = _lib.lib().ital_launch_count()
     t0 = time.perf_counter()
     marks = []
+    timed_picks = []
     for _ in range(args.steps):
         n_cand = n_total - len(learner.relevant_ids) - len(learner.irrelevant_ids)
-        one_round()
+        timed_picks.append(one_round())
         scored += sum(n_cand - t for t in range(BATCH))
         marks.append(time.perf_counter())
     barrier()
     dt = time.perf_counter() - t0
     launches_end = _lib.lib().ital_launch_count()
+    head_sha, head_words = picks_digest(timed_picks)
+    head_agree = ranks_agree(head_words, device, world)
+    head_transport = transport_report(learner, group, device)
     # the same K steps with the interpreter's heap as a process that never froze it has it (reported next to the headline)
     prof_timed, learner.profile = learner.profile, None
     gc.unfreeze()
@@ -655,6 +774,7 @@ def main():
                "kernel_ms": {"%s_t%d" % k: float(np.mean([d for d, _ in v])) * 1e3 for k, v in sorted(prof.items())},
                "ms_per_step_unfrozen_heap": dt_unfrozen / args.steps * 1e3, "preheat_rounds_before_warmup": preheat,
                "library_launches_per_step": launches, "round_gaps": round_gaps(),
+               "picks_sha": head_sha, "picks_agree_across_ranks": head_agree, **head_transport,
                "scaling_workload": scale}
         if scale is not None:
             # the strong-scaling figure north_star asks for (1M x 512, k = 4, rows split over the ranks), also at top level
@@ -670,6 +790,8 @@ def main():
         import torch.distributed as dist
         dist.barrier()
         dist.destroy_process_group()
+    if not head_agree or (scale is not None and not scale["picks_agree_across_ranks"]):
+        raise SystemExit("bench.py: the ranks did NOT pick the same batches -- the line above is not a valid measurement")
 
 
 if __name__ == "__main__":

@@ -28,6 +28,7 @@ typedef struct ihipStream_t* hipStream_t; /* same declaration as hip_runtime_api
 #define ITAL_GENERIC_MAX_REL 16  /* largest number of enumerated / sampled variables of the general scorer */
 #define ITAL_GENERIC_MAX_CALLS (1 << 22) /* orthant probabilities per candidate and greedy step */
 #define ITAL_TOPK_MAX 4096  /* largest k of ital_topk */
+#define ITAL_ROUND_MAX_CAND (1 << 21) /* most candidates per rank of ital_fetch_round (one million rows on one GPU fit) */
 
 /* Library identification / error reporting. */
 const char* ital_version(void);
@@ -252,7 +253,8 @@ int64_t ital_score_workspace(int t, int64_t n_cand);
 /* One whole round of the perfect-user path -- fetch_unlabelled(k), reference ital/ital.py:98-134 -- enqueued by ONE call:
  * candidate-list upkeep, then for t = 1 .. k ital_score_step (ending with the selection inside its last launch: `step.sel_*`
  * must be set) and, for t < k, the new member's cross-covariance column (ital_cross_cov_cols out of the batch state into
- * C[t - 1]).  Nothing synchronises; the picks are ret[0 .. k), the status word ret[kmax].  At most 2^18 candidates. */
+ * C[t - 1]).  Nothing synchronises; the picks are ret[0 .. k), the status word ret[kmax].  At most ITAL_ROUND_MAX_CAND candidates
+ * per rank. */
 typedef struct ital_round_desc {
     int k;                          /* greedy steps */
     ital_score_desc step;           /* the steps' descriptor; t, mi (with mi_keep), seed, jump, jumppat, vk, ev_* are filled in per step */
@@ -313,6 +315,13 @@ int ital_select_resolve(const double* records, int world, int rec_len, int rank,
  * Replaces the Pool.map gather of the per-candidate scores, reference ital/ital.py:124-130. */
 int ital_select_exchange(const double* record, double* records_all, int rec_len, void* nccl_comm, hipStream_t stream);
 
+/* What the exchange would run on: resolves RCCL exactly as ital_select_exchange does and asks it for the communicator's
+ * size and this rank's number in it (ncclCommCount, ncclCommUserRank) -- no collective, nothing enqueued.  A host checks
+ * with it, before the first exchange, that the communicator it is about to hand over orders the ranks as its own
+ * bookkeeping does (ital_amd.sharding.raw_comm agrees on the outcome across the ranks before any of them uses it).
+ * how (optional, how_len bytes): where RCCL was found.  -38: no RCCL in the process; -22: null communicator. */
+int ital_exchange_info(void* nccl_comm, int* world, int* rank, char* how, int how_len);
+
 /* ital_select_local + ital_select_resolve for ONE rank in a single launch (small problems are launch-latency bound).
  * Same semantics; `record` is scratch of ITAL_REC_HEADER + ldx + ldw + kmax doubles. */
 int ital_select_fused(const double* mi, const int32_t* cand, uint8_t* alive, int64_t n_cand, int64_t pos_offset,
@@ -365,10 +374,10 @@ typedef struct ital_mcmi_desc {
     ital_batch batch;       /* bgpos = block position of each member */
     double noise, eps;
     double* ce;             /* [n_i] out: min over label patterns of the summed conditional entropy */
-    double* work;           /* t >= 5: ital_mcmi_workspace(t, n_i) doubles of ZERO-INITIALISED device memory (left zeroed where
-                               it has to be): the step then runs as a preparation kernel (W per candidate) and one workgroup
-                               per (candidate, group of 2^(t-3) label patterns) -- occupancy 3 instead of 1, no scratch.
-                               NULL: the single-kernel form (all t) */
+    double* work;           /* t >= 5 (required there, -22 without): ital_mcmi_workspace(t, n_i) doubles of device memory, any
+                               content (the call clears the counters it keeps in it): the step runs as a preparation kernel
+                               (W per candidate) and one workgroup per (candidate, group of 2^(t-3) label patterns).
+                               t <= 4: unused (one kernel, workgroup per candidate) */
     int64_t work_doubles;
 } ital_mcmi_desc;
 
@@ -455,11 +464,12 @@ typedef struct ital_gscore_desc {
     double* mi;             /* [n_cand] out */
     int* status;
     double* work;           /* workspace in device memory (work_doubles doubles; ital_amd reuses the lattice scorer's).  Without a
-                               subset and clip_cov, for 3 .. 16 variables, and with room for two buffers of at least one
-                               candidate's prepared calls each -- calls x (2.5 + n(n+1)/2 + n + 16(n-1)) doubles, n = nE + 1 -- the
-                               step runs as three kernels (prepare / lattice sums / combine) over slabs of candidates, the
-                               preparation of a slab under the lattice sums of the one before (two internal streams, joined
-                               with `stream` on both sides); otherwise as one kernel that does everything per candidate */
+                               subset and clip_cov, for 3 .. 16 variables, and with room for at least one candidate
+                               (ital_score_generic_workspace: what one slab of all candidates takes; less means more slabs) the
+                               step runs as a pipeline of kernels -- verdicts per call, preparation of the undecided calls,
+                               lattice sums, combine -- the preparation of a chunk of calls under the lattice sums of the one
+                               before (two internal streams, joined with `stream` on both sides); otherwise as one kernel that
+                               does everything per candidate */
     int64_t work_doubles;
     unsigned long long* pair_count; /* non-NULL: += the (Phi, Phi^-1) pairs of the lattice sums that were evaluated
                                (16 P(n-1) points x (n-1) pairs per evaluated call; instrumentation for the roofline) */
@@ -469,6 +479,10 @@ typedef struct ital_gscore_desc {
  * MutualInformation._call_iter_all / _call_iter_sub (reference ital/ital.py:183-275) with rel_iter (:278-291, full
  * enumeration), fb_iter (:300-342), likelihood (:453-481), prob_rel (:345-383) and updated_prob_rel (:432-450). */
 int ital_score_generic(const ital_gscore_desc* d, hipStream_t stream);
+/* Doubles of d->work with which the step of `d` (n_cand, nE, n_picks, fb_mode, mc_rel, mc_fb, subset_mode, clip_cov are read)
+ * runs through the pipeline with all candidates in one slab; 0 when the step is not the pipeline's (single kernel, no
+ * workspace needed). */
+int64_t ital_score_generic_workspace(const ital_gscore_desc* d);
 
 #ifdef __cplusplus
 }

@@ -17,6 +17,7 @@ ITAL_GENERIC_MAX_DIM = 20
 ITAL_GENERIC_MAX_REL = 16
 ITAL_GENERIC_MAX_CALLS = 1 << 22
 ITAL_TOPK_MAX = 4096
+ITAL_ROUND_MAX_CAND = 1 << 21
 
 
 class ItalBatch(ctypes.Structure):
@@ -130,6 +131,7 @@ SIGNATURES = {
     "ital_mcmi_score_step": (c_int, [ctypes.POINTER(ItalMcmiDesc), c_void_p]),
     "ital_mcmi_workspace": (c_int64, [c_int, c_int64]),
     "ital_score_generic": (c_int, [ctypes.POINTER(ItalGscoreDesc), c_void_p]),
+    "ital_score_generic_workspace": (c_int64, [ctypes.POINTER(ItalGscoreDesc)]),
     "ital_select_local": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_void_p, c_int64, c_int, c_int, c_void_p,
                                   c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int64, c_int, c_int, c_void_p,
                                   c_int64, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
@@ -137,6 +139,7 @@ SIGNATURES = {
                                   c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int64, c_int, c_int, c_void_p,
                                   c_int64, c_int, c_int, ItalBatch, c_void_p, c_void_p, c_void_p, c_void_p]),
     "ital_select_exchange": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p]),
+    "ital_exchange_info": (c_int, [c_void_p, c_void_p, c_void_p, ctypes.c_char_p, c_int]),
     "ital_mcmi_round": (c_int, [ctypes.POINTER(ItalMcmiRoundDesc), c_void_p]),
     "ital_gather_block": (c_int, [c_void_p, c_int64, c_int64, c_int64, c_void_p, c_void_p, c_int, c_void_p, c_int64, c_int,
                                   c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p]),

@@ -23,10 +23,12 @@ namespace {
 
 typedef int (*all_gather_fn)(const void*, void*, size_t, int, void*, hipStream_t);   // ncclAllGather
 typedef const char* (*error_string_fn)(int);
+typedef int (*comm_int_fn)(void*, int*);                                              // ncclCommCount, ncclCommUserRank
 constexpr int NCCL_FLOAT64 = 8;   // ncclDouble (nccl.h: ncclFloat64 = 8)
 
 all_gather_fn g_all_gather = nullptr;
 error_string_fn g_error_string = nullptr;
+comm_int_fn g_comm_count = nullptr, g_comm_rank = nullptr;
 char g_how[600] = "";
 
 int find_loaded_rccl(struct dl_phdr_info* info, size_t, void* out) {
@@ -61,8 +63,10 @@ bool resolve() {
     }
     if (!sym) return false;
     g_all_gather = reinterpret_cast<all_gather_fn>(sym);
-    g_error_string = reinterpret_cast<error_string_fn>(handle ? dlsym(handle, "ncclGetErrorString")
-                                                              : dlsym(RTLD_DEFAULT, "ncclGetErrorString"));
+    auto look = [&](const char* name) { return handle ? dlsym(handle, name) : dlsym(RTLD_DEFAULT, name); };
+    g_error_string = reinterpret_cast<error_string_fn>(look("ncclGetErrorString"));
+    g_comm_count = reinterpret_cast<comm_int_fn>(look("ncclCommCount"));
+    g_comm_rank = reinterpret_cast<comm_int_fn>(look("ncclCommUserRank"));
     return true;
 }
 
@@ -81,5 +85,18 @@ extern "C" int ital_select_exchange(const double* record, double* records_all, i
         snprintf(msg, sizeof(msg), "ital_select_exchange: ncclAllGather failed: %s", g_error_string ? g_error_string(rc) : "?");
         return ital_fail(-5, msg);
     }
+    return 0;
+}
+
+extern "C" int ital_exchange_info(void* nccl_comm, int* world, int* rank, char* how, int how_len) {
+    if (!nccl_comm) return ital_fail(-22, "ital_exchange_info: communicator missing (ncclComm_t of this rank)");
+    if (!resolve()) return ital_fail(-38, "ital_exchange_info: no RCCL (ncclAllGather) loaded in this process");
+    if (how && how_len > 0) snprintf(how, (size_t)how_len, "%s", g_how);
+    if (!g_comm_count || !g_comm_rank) return ital_fail(-38, "ital_exchange_info: the loaded RCCL lacks ncclCommCount / ncclCommUserRank");
+    int w = -1, r = -1;
+    const int rc = g_comm_count(nccl_comm, &w) ? -5 : (g_comm_rank(nccl_comm, &r) ? -5 : 0);
+    if (rc) return ital_fail(-5, "ital_exchange_info: ncclCommCount / ncclCommUserRank failed");
+    if (world) *world = w;
+    if (rank) *rank = r;
     return 0;
 }

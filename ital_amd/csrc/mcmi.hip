@@ -688,19 +688,26 @@ __global__ __launch_bounds__(256) void mcmi_split_kernel(McmiArgs a, const doubl
 template <int T>
 static int launch_mcmi(const McmiArgs& a, double* work, int64_t work_doubles, hipStream_t stream) {
     using M = McmiSplit<T>;
-    if (T >= 5 && work) {
+    if constexpr (T >= 5) {
+        // batches of 5 .. 8: preparation kernel + one workgroup per (candidate, group of label patterns); the single kernel
+        // of t <= 4 would need 256 registers + up to 184 accumulation registers and scratch there (it was dropped in round 4)
+        if (!work) return ital_fail(-22, "ital_mcmi_score_step: t >= 5 needs the workspace of ital_mcmi_workspace(t, n_i)");
         if (work_doubles < M::CAND_DOUBLES * a.n_i)
             return ital_fail(-22, "ital_mcmi_score_step: workspace smaller than ital_mcmi_workspace(t, n_i)");
-        // ticket counters first (the same place for every t: zero once, every finishing workgroup leaves its counter at zero)
+        // ticket counters first: n_i words, cleared here -- a workspace that served a call with another n_i holds that
+        // call's data where this call's counters go (every finishing workgroup leaves its own counter at zero, but only its own)
         unsigned int* tickets = reinterpret_cast<unsigned int*>(work);
+        if (hipMemsetAsync(tickets, 0, sizeof(unsigned int) * (size_t)a.n_i, stream) != hipSuccess)
+            return ital_fail(-5, "ital_mcmi_score_step: cannot clear the ticket counters");
         double* wbuf = work + a.n_i;
         double* parts = wbuf + a.n_i * M::WDOUBLES;
         ITAL_LAUNCH(mcmi_prep_kernel<T>, dim3((unsigned)((a.n_i + 127) / 128)), dim3(128), 0, stream, a, wbuf);
         ITAL_LAUNCH((mcmi_split_kernel<T>), dim3((unsigned)a.n_i, (unsigned)M::NHB), dim3(256), 0, stream, a, wbuf, parts, tickets);
         return ital_check_launch("ital_mcmi_score_step(split)");
+    } else {
+        ITAL_LAUNCH(mcmi_score_kernel<T>, dim3((unsigned)a.n_i), dim3(256), 0, stream, a);
+        return ital_check_launch("ital_mcmi_score_step");
     }
-    ITAL_LAUNCH(mcmi_score_kernel<T>, dim3((unsigned)a.n_i), dim3(256), 0, stream, a);
-    return ital_check_launch("ital_mcmi_score_step");
 }
 
 template <int T>

@@ -64,9 +64,98 @@ __global__ __launch_bounds__(1024) void fetch_begin_kernel(int mode, const int32
     if (tid == 0) ret[kmax] = 0;
 }
 
+// The same upkeep for long lists (a million candidates on one rank: the single workgroup above walks them in 4.5 ms) as three
+// launches over tiles of 16 384 entries -- 16 consecutive flags per thread: (1) live entries per tile; (2) every tile
+// compacts itself behind the tiles in front of it (their counts: at most 128 numbers); (3) once all flags are read: re-arm,
+// clear the status slot, compare the survivors with what the host expects.
+constexpr int64_t COMPACT_TILE = 16384;
+constexpr int64_t COMPACT_FROM = 1 << 16;      // shorter lists: the single-workgroup kernel (one launch)
+
+__device__ __forceinline__ unsigned tile_flags(const uint8_t* __restrict__ alive, int64_t at, int64_t n_prev) {
+    unsigned m = 0;                            // bit j: entry at + j is alive
+    if (at + 16 <= n_prev) {
+        const uint64_t* w = reinterpret_cast<const uint64_t*>(alive + at);      // at is a multiple of 16, the buffer 256-byte aligned
+        const uint64_t lo = w[0], hi = w[1];
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            m |= (((lo >> (8 * j)) & 0xffull) != 0 ? 1u : 0u) << j;
+            m |= (((hi >> (8 * j)) & 0xffull) != 0 ? 1u : 0u) << (8 + j);
+        }
+    } else {
+        for (int j = 0; j < 16 && at + j < n_prev; j++) m |= (alive[at + j] != 0 ? 1u : 0u) << j;
+    }
+    return m;
+}
+
+__device__ __forceinline__ int block_sum_1024(int v, int* s_wave) {   // sum over the workgroup, valid in every thread
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    if (lane == 0) s_wave[wave] = v;
+    __syncthreads();
+    int tot = 0;
+    for (int w = 0; w < 16; w++) tot += s_wave[w];
+    __syncthreads();
+    return tot;
+}
+
+__global__ __launch_bounds__(1024) void compact_count_kernel(const uint8_t* __restrict__ alive, int64_t n_prev, int* __restrict__ counts) {
+    __shared__ int s_wave[16];
+    const int64_t at = (int64_t)blockIdx.x * COMPACT_TILE + (int64_t)threadIdx.x * 16;
+    const int cnt = at < n_prev ? __popc(tile_flags(alive, at, n_prev)) : 0;
+    const int tot = block_sum_1024(cnt, s_wave);
+    if (threadIdx.x == 0) counts[blockIdx.x] = tot;
+}
+
+__global__ __launch_bounds__(1024) void compact_scatter_kernel(const int32_t* __restrict__ cand_prev, const uint8_t* __restrict__ alive,
+                                                               int64_t n_prev, int32_t* __restrict__ cand_new,
+                                                               const int* __restrict__ counts) {
+    __shared__ int s_wave[16];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    int64_t base = 0;
+    for (int b = 0; b < (int)blockIdx.x; b++) base += counts[b];
+    const int64_t at = (int64_t)blockIdx.x * COMPACT_TILE + (int64_t)threadIdx.x * 16;
+    const unsigned m = at < n_prev ? tile_flags(alive, at, n_prev) : 0u;
+    const int cnt = __popc(m);
+    int incl = cnt;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const int o = __shfl_up(incl, off, 64);
+        if (lane >= off) incl += o;
+    }
+    if (lane == 63) s_wave[wave] = incl;
+    __syncthreads();
+    int before = incl - cnt;
+    for (int w = 0; w < wave; w++) before += s_wave[w];
+    int64_t out = base + before;
+    for (unsigned mm = m; mm; mm &= mm - 1) cand_new[out++] = cand_prev[at + __builtin_ctz(mm)];
+}
+
+__global__ __launch_bounds__(1024) void compact_rearm_kernel(uint8_t* __restrict__ alive, int64_t n, int64_t* __restrict__ ret, int kmax,
+                                                             int* __restrict__ status, const int* __restrict__ counts, int ntiles) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < n; p += stride) alive[p] = 1;
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        int64_t tot = 0;
+        for (int b = 0; b < ntiles; b++) tot += counts[b];
+        if (tot != n) atomicOr(status, 8);
+        ret[kmax] = 0;
+    }
+}
+
 }  // namespace ital
 
 using namespace ital;
+
+// Scratch of the long-list upkeep: one count per tile (ITAL_ROUND_MAX_CAND / 16 384 = 128 of them), per device.
+static int* compact_counts() {
+    static int* bufs[16] = {};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return nullptr;
+    if (!bufs[dev] && hipMalloc(reinterpret_cast<void**>(&bufs[dev]), sizeof(int) * (ITAL_ROUND_MAX_CAND / COMPACT_TILE + 1)) != hipSuccess)
+        bufs[dev] = nullptr;
+    return bufs[dev];
+}
 
 extern "C" int ital_fetch_round(const ital_round_desc* r, hipStream_t stream) {
     if (!r) return ital_fail(-22, "ital_fetch_round: null descriptor");
@@ -77,12 +166,24 @@ extern "C" int ital_fetch_round(const ital_round_desc* r, hipStream_t stream) {
         return ital_fail(-22, "ital_fetch_round: several ranks need records_all and a transport (nccl_comm or exchange)");
     if (ranks ? tpl.n_cand < 1 : tpl.n_cand < r->k)
         return ital_fail(-22, "ital_fetch_round: fewer candidates than greedy steps (several ranks: none on this rank)");
-    if (tpl.n_cand > (1 << 18)) return ital_fail(-22, "ital_fetch_round: more than 2^18 candidates (use the per-step entry points)");
+    if (tpl.n_cand > ITAL_ROUND_MAX_CAND) return ital_fail(-22, "ital_fetch_round: more than ITAL_ROUND_MAX_CAND candidates (use the per-step entry points)");
     if (!tpl.sel_record || !tpl.sel_ret) return ital_fail(-22, "ital_fetch_round: the round selects inside the scorer: sel_* missing");
     if (r->begin < 0 || r->begin > 2) return ital_fail(-22, "ital_fetch_round: begin must be 0, 1 or 2");
-    if (r->begin == 2 && (!r->cand_prev || r->n_prev < tpl.n_cand || r->n_prev > (1 << 18) || r->cand_prev == tpl.cand))
+    if (r->begin == 2 && (!r->cand_prev || r->n_prev < tpl.n_cand || r->n_prev > ITAL_ROUND_MAX_CAND || r->cand_prev == tpl.cand))
         return ital_fail(-22, "ital_fetch_round: begin = 2 needs the previous list in a buffer of its own");
-    if (r->begin) {
+    if (r->begin == 2 && r->n_prev >= COMPACT_FROM) {
+        int* counts = compact_counts();
+        if (!counts) return ital_fail(-12, "ital_fetch_round: no memory for the tile counts of the list upkeep");
+        const unsigned ntiles = (unsigned)((r->n_prev + COMPACT_TILE - 1) / COMPACT_TILE);
+        uint8_t* alive = const_cast<uint8_t*>(tpl.alive);
+        ITAL_LAUNCH(compact_count_kernel, dim3(ntiles), dim3(1024), 0, stream, alive, r->n_prev, counts);
+        ITAL_LAUNCH(compact_scatter_kernel, dim3(ntiles), dim3(1024), 0, stream, r->cand_prev, alive, r->n_prev,
+                    const_cast<int32_t*>(tpl.cand), counts);
+        ITAL_LAUNCH(compact_rearm_kernel, dim3(ntiles), dim3(1024), 0, stream, alive, tpl.n_cand, tpl.sel_ret, tpl.batch.kmax,
+                    tpl.status, counts, (int)ntiles);
+        const int rc = ital_check_launch("ital_fetch_round(begin, tiles)");
+        if (rc) return rc;
+    } else if (r->begin) {
         ITAL_LAUNCH(fetch_begin_kernel, dim3(1), dim3(1024), 0, stream, r->begin - 1, r->cand_prev, r->n_prev,
                     const_cast<int32_t*>(tpl.cand), const_cast<uint8_t*>(tpl.alive), tpl.n_cand, tpl.sel_ret, tpl.batch.kmax,
                     tpl.status);

@@ -26,6 +26,7 @@
 #include "ital_hip.h"
 #include "ital_internal.h"
 #include "qmc_common.h"
+#include "qmc_exact.h"
 #include "qmc_seed.h"
 #include "select_common.h"
 
@@ -248,6 +249,7 @@ struct Qmc {
 // meta word of a record: bit 0 evaluate the lattice sum; bit 1 prior probability == 1 (else 0) when not evaluated;
 // bit 2 probability after the simulated update == 1 (else 0); bits 8.. limit types after COVSRT
 constexpr long long META_EVAL = 1, META_PRIOR_ONE = 2, META_POST_ONE = 4;
+constexpr long long META_EXACT = 8;   // set by the lattice sum: recompute in MVKBRV's own summation order (qmc_exact.h)
 
 // Swap rows/columns p < q of the packed lower-triangular matrix, the limits and the limit-type bits (RCSWP).
 template <int T>
@@ -548,10 +550,70 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(ITAL_QMC_WA
         const double acc = qmc_lane_sum<T, LitK, Q::NH, ITAL_QMC_FLIP != 0>(lat, cf, lm, infi, tailq, lane);
 #endif
         pr = wave_sum(acc) / (16.0 * Q::PRIME);
+        // label_estimation 'optimistic' / 'pessimistic' compare terms for exact equality: a sum this close to 0 or 1 is
+        // formed again in the reference's own order (qmc_exact_kernel, right after this launch)
+        if (label_mode != 0 && (pr > 1.0 - EXACT_BAND || pr < EXACT_BAND) && lane == 0)
+            const_cast<double*>(rec)[Q::R_META] = __longlong_as_double(meta | META_EXACT);
     }
     if (lane == 0) {
         const double pu = (meta & META_POST_ONE) ? 1.0 : 0.0;
         const double cur = log_eps(pu, eps) - log_eps(pr, eps);   // perfect user: likelihood weight 1 (ital.py:208)
+        terms[item] = label_mode == 0 ? cur * pr : cur;
+    }
+}
+
+// The flagged calls of a slab again, in the reference's summation order (qmc_exact.h): wave per (candidate, pattern); all
+// but a handful leave at once.  Launched only with label_estimation 'optimistic' / 'pessimistic'.
+template <int T>
+__global__ __launch_bounds__(64) void qmc_exact_kernel(const uint8_t* __restrict__ alive, int64_t slab_lo, int64_t slab_n,
+                                                       const double* __restrict__ recs, const double* __restrict__ vk, double eps,
+                                                       int label_mode, double* __restrict__ terms) {
+    using Q = Qmc<T>;
+    extern __shared__ double lds_all[];
+    const int lane = threadIdx.x;
+    const int64_t item = blockIdx.x;
+    const int64_t i = item >> T;
+    if (i >= slab_n || !alive[slab_lo + i]) return;
+    const double* rec = recs + item * Q::REC;
+    const long long meta = __double_as_longlong(uniform_f64(rec[Q::R_META]));
+    if (!(meta & META_EXACT)) return;
+    double* slab = lds_all;                       // packed factor with (unused) diagonal, limits: the natural form
+    double* lat = slab + Q::NCOV + T;
+    double* tailq = lat + Q::LAT;
+    double* vals = tailq + 128;
+    const unsigned infi = (unsigned)(meta >> 8) & ((1u << T) - 1u);
+    const unsigned fl = ITAL_QMC_FLIP ? infi : 0u;       // the record holds the variables bounded below negated: undo
+    for (int q = lane; q < Q::NCOV; q += 64) {
+        int row = 0;
+        while ((row + 1) * (row + 2) / 2 <= q) row++;
+        const int col = q - row * (row + 1) / 2;
+        double v = 0.0;
+        if (col < row) {
+            v = rec[row * (row - 1) / 2 + col];
+            if (((fl >> row) ^ (fl >> col)) & 1u) v = -v;
+        }
+        slab[q] = v;
+    }
+    for (int q = lane; q < T; q += 64) slab[Q::NCOV + q] = ((fl >> q) & 1u) ? -rec[Q::R_LIM + q] : rec[Q::R_LIM + q];
+    {
+        const unsigned int* shifts = reinterpret_cast<const unsigned int*>(rec + Q::R_LAT);
+        const unsigned char* perm = reinterpret_cast<const unsigned char*>(rec + Q::R_LAT + 4 * Q::NDIM);
+        for (int q = lane; q < 8 * Q::NDIM; q += 64) {
+            lat[q] = vk[perm[q]];
+            lat[8 * Q::NDIM + q] = (double)shifts[q] * MRG_INVMP1;
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    qmc_point_values<T>(T, slab, infi, (1u << T) - 1u, lat, lane, tailq, vals);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    const double pr = mvkbrv_serial(Q::PRIME, vals, lane);
+    if (lane == 0) {
+        const double pu = (meta & META_POST_ONE) ? 1.0 : 0.0;
+        const double cur = log_eps(pu, eps) - log_eps(pr, eps);
         terms[item] = label_mode == 0 ? cur * pr : cur;
     }
 }
@@ -621,6 +683,16 @@ static int launch_qmc(const ScoreArgs& a, double* work, int64_t work_doubles, in
         ITAL_LAUNCH(qmc_main_kernel<T>, dim3((unsigned)((n * Q::NPAT + 3) / 4)), dim3(256), lds_main, stream, a.alive, lo,
                            n, recs, a.vk, a.eps, a.label_mode, terms);
         if (ev1 && lo + n >= a.n_cand) (void)hipEventRecord(ev1, stream);
+        if (a.label_mode != 0) {
+            const size_t lds_x = (size_t)(Q::NCOV + T + Q::LAT + 128 + 16 * Q::PRIME) * sizeof(double);
+            static ItalLdsFlags lds_xflags;
+            if (lds_x > 48 * 1024) {
+                const int rc = ital_raise_lds_limit(reinterpret_cast<const void*>(&qmc_exact_kernel<T>), (int)lds_x, lds_xflags, "ital_score_step");
+                if (rc) return rc;
+            }
+            ITAL_LAUNCH(qmc_exact_kernel<T>, dim3((unsigned)(n * Q::NPAT)), dim3(64), lds_x, stream, a.alive, lo, n, recs, a.vk, a.eps,
+                        a.label_mode, terms);
+        }
         ITAL_LAUNCH(qmc_combine_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, terms, a.alive, lo, n,
                     Q::NPAT, a.label_mode, a.mi, a.pos_offset, a.gpos, a.sel, part0, nparts, lo + n >= a.n_cand ? 1 : 0);
         part0 += (int)((n + 255) / 256);

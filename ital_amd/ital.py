@@ -24,7 +24,7 @@ from ._lib import (ITAL_GENERIC_MAX_CALLS, ITAL_GENERIC_MAX_DIM, ITAL_GENERIC_MA
                    ItalGscoreDesc, ItalScoreDesc, check)
 from ._batch import make_batch_buffers
 from .gp import _pad16, _ptr, _stream
-from .retrieval_base import ActiveRetrievalBase
+from .retrieval_base import ActiveRetrievalBase, UnseenList
 
 _LABEL_MODES = {"mean": 0, "optimistic": 1, "pessimistic": 2}
 _HOST_THREADS = max(1, min(16, os.cpu_count() or 1))   # host share of one GPU (Monte-Carlo pattern sampling)
@@ -40,7 +40,8 @@ def _host_pool():
     if _POOL is None:
         _POOL = ThreadPoolExecutor(_HOST_THREADS)
     return _POOL
-_FUSED_SELECT_MAX = 1 << 18   # one rank, up to this many candidates: arg-max + record + resolve in a single launch
+_FUSED_SELECT_MAX = _lib.ITAL_ROUND_MAX_CAND   # per rank, up to this many candidates: arg-max + record (+ resolve) inside the scoring launch
+_FUSED_LAUNCH_MAX = 1 << 18   # one rank, up to this many candidates: ital_select_fused (one workgroup) as the separate selection launch
 
 
 class ITAL(ActiveRetrievalBase):
@@ -81,10 +82,11 @@ class ITAL(ActiveRetrievalBase):
         self.profile = None      # list to receive (stage, t, size, start_event, end_event) per launch (bench.py)
         self._fetch_bufs = None
         self.profile_steps = None      # round path: greedy steps whose lattice sums are bracketed by events (None: all)
-        self.round_call = True        # one rank, up to 2^18 candidates: a whole round through ital_fetch_round (False: step by step from Python)
-        self._dev_list = None         # the candidate list the device holds: (buffers, host array, picks flagged dead)
+        self.round_call = True        # up to ITAL_ROUND_MAX_CAND candidates per rank: a whole round through ital_fetch_round (False: step by step from Python)
+        self._dev_list = None         # the candidate list the device holds: (buffers, UnseenList and its version, picks flagged dead)
         self.select_in_scorer = True  # False: the selection of a greedy step always runs as a launch of its own (cross-check in tests)
         self.mc_walk = [0, 0, 0.0]   # Monte-Carlo pattern sampling: standard normals computed / skipped, host seconds
+        self.host_clock = None       # dict(gap_s=0.0, gaps=0, enqueue_s=0.0, t_download=None): host time of the round path (bench.py)
 
     # ------------------------------------------------------------------ helpers
     def _perfect_user(self):
@@ -215,14 +217,21 @@ class ITAL(ActiveRetrievalBase):
         if gp.m == 0:
             raise RuntimeError("fetch_unlabelled() needs a fitted relevance model: call update() first or pass queries "
                                "(the reference fails with an AttributeError at gp.py:222)")
-        unseen = self._unseen_array()
+        unseen = self._unseen_list()
         k = min(int(k), len(unseen))
         if k <= 0:
             return []
         why = self._unsupported(k, len(unseen))
         if why is not None:
             raise NotImplementedError("ital_amd device scorer: %s is not implemented" % why)
-        candidates = self._candidate_list(unseen)
+        if (self.top_candidates is None and not self._needs_generic() and self.round_call and self.select_in_scorer
+                and self._round_possible(k, unseen)):
+            # the retrieval loop's own case: the candidate list is get_unseen() itself.  Nothing of its size is touched on
+            # the host -- the list lives on the device, the host keeps (base, removed ids) (retrieval_base.UnseenList)
+            self._ce_subset = None
+            self._last_batch = None
+            return self._select_round(k, unseen)
+        candidates = self._candidate_list(unseen.array())
         if len(candidates) < k:
             # k was clamped to the number of unseen samples BEFORE the top_candidates restriction (ital.py:99-117): the
             # reference picks until the list is empty and np.argmax([]) then raises exactly this (ital.py:130) -- with
@@ -258,10 +267,10 @@ class ITAL(ActiveRetrievalBase):
         return cand, n_loc, pos_offset, cand_d, gpos_d, alive
 
     def _ascending(self, candidates):
-        """The candidate list is the cached get_unseen() array itself (ascending by construction): lets the sharding
-        arithmetic use binary searches instead of passes over a list of up to millions of entries."""
-        uc = getattr(self, "_unseen_cache", None)
-        return uc is not None and candidates is uc["array"]
+        """The candidate list is the get_unseen() array itself (ascending by construction): lets the sharding arithmetic
+        use binary searches instead of passes over a list of up to millions of entries."""
+        u = self.__dict__.get("_unseen")
+        return u is not None and candidates is u[0]._flat
 
     def _qmc_workspace(self, b, t, n_loc):
         """Workspace of the lattice scorer (prepared calls of a slab of candidates), grown on demand up to `qmc_work_bytes`."""
@@ -270,6 +279,17 @@ class ITAL(ActiveRetrievalBase):
         if w is None or w.numel() < want:
             b["qmc_work"] = w = torch.empty(want, dtype=torch.float64, device=self.gp.device)
         return w
+
+    def _sel_parts_doubles(self, k, n_loc):
+        """Doubles of the block partials of the selection inside the scoring launches of a round of k steps: three per
+        scoring block -- n/256 blocks at t = 1, n/32 at t = 2, n/256 plus one per slab of the lattice workspace from t = 3 on
+        (with a small workspace cap, `qmc_work_bytes`, a step of t = 7, 8 runs in slabs of a few candidates each)."""
+        slabs = 0
+        if k >= 3 and n_loc > 0:
+            have = max(self.qmc_work_bytes // 8, 1 << 16)
+            per = int(_lib.lib().ital_score_workspace(k, 1))
+            slabs = -(-n_loc // max(have // per, 1)) if have < per * n_loc else 1
+        return 3 * (n_loc // 32 + 64 + slabs)
 
     def _select(self, k, candidates):
         """Greedy construction of a batch of k out of `candidates` (k <= len(candidates))."""
@@ -327,15 +347,15 @@ class ITAL(ActiveRetrievalBase):
                         slabs = -(-n_loc // max(work.numel() // int(lib.ital_score_workspace(t, 1)), 1))
                         self.profile.append(("qmc_main" if slabs == 1 else "qmc_slabs%d" % slabs, t,
                                              n_alive if not gp.collective else n_loc, k0, k1))
-                fused = not gp.collective and 0 < n_loc <= _FUSED_SELECT_MAX
                 tail = self.select_in_scorer and 0 < n_loc <= _FUSED_SELECT_MAX
+                fused = not gp.collective and 0 < n_loc <= (_FUSED_SELECT_MAX if tail else _FUSED_LAUNCH_MAX)
                 if tail:
                     # the scoring launch ends with the selection itself (the block that finishes last selects): one rank --
                     # arg-max, record and batch bookkeeping, no selection launch at all; several ranks -- arg-max and record
                     # (what ital_select_local does in a single-workgroup launch of its own), exchange and resolve follow
                     parts = b.get("sel_parts")
-                    if parts is None or parts.numel() < 3 * (n_loc // 32 + 64):
-                        b["sel_parts"] = parts = torch.empty(3 * (n_loc // 32 + 64), dtype=torch.float64, device=dev)
+                    if parts is None or parts.numel() < self._sel_parts_doubles(k, n_loc):
+                        b["sel_parts"] = parts = torch.empty(self._sel_parts_doubles(k, n_loc), dtype=torch.float64, device=dev)
                         b["sel_counter"] = torch.zeros(1, dtype=torch.int32, device=dev)
                     desc.sel_X, desc.sel_xnorm, desc.sel_ldx = _ptr(gp.Xd), _ptr(gp.xnorm), gp.ldx
                     desc.sel_V, desc.sel_ldv, desc.sel_m, desc.sel_ldw, desc.sel_rank = _ptr(gp.V), gp.ldv, gp.m, gp.cap, gp.rank
@@ -395,19 +415,20 @@ class ITAL(ActiveRetrievalBase):
         return [int(i) for i in ret]
 
     def _round_possible(self, k, candidates):
-        """Can this round run as one ital_fetch_round call?  One rank: up to 2^18 candidates.  Several ranks: the ascending
-        get_unseen() list (every rank's share one run of it), at least one and at most 2^18 candidates on every rank, and a
-        transport for the per-step record exchange.  Decided from the list and the process group alone: the same on every rank."""
+        """Can this round run as one ital_fetch_round call?  One rank: any list of up to ITAL_ROUND_MAX_CAND candidates.
+        Several ranks: the ascending get_unseen() list (an UnseenList: every rank's share is one run of it), at least one
+        and at most that many candidates on every rank, and a transport for the per-step record exchange.  Decided from
+        the list and the process group alone: the same on every rank."""
         gp = self.gp
         n = len(candidates)
         if n < k:
             return False
         if not gp.collective:
             return n <= _FUSED_SELECT_MAX
-        if not self._ascending(candidates) or self._round_transport() is None:
+        if not isinstance(candidates, UnseenList) or self._round_transport() is None:
             return False
         bounds = [sharding.row_range(gp.n_total, gp.world, r)[0] for r in range(gp.world)] + [gp.n_total]
-        sizes = np.diff(np.searchsorted(candidates, bounds))
+        sizes = np.diff([candidates.count_below(x) for x in bounds])
         return bool(sizes.min() >= 1 and sizes.max() <= _FUSED_SELECT_MAX)
 
     def _round_transport(self):
@@ -535,9 +556,10 @@ class ITAL(ActiveRetrievalBase):
         gp = self.gp
         dev = gp.device
         n = len(candidates)
+        listed = isinstance(candidates, UnseenList)      # (several ranks: always, see _round_possible)
         if gp.collective:
             # this rank's share of the ascending list: one run of it, list positions lo .. hi
-            lo, hi = int(np.searchsorted(candidates, gp.row0)), int(np.searchsorted(candidates, gp.row1))
+            lo, hi = candidates.count_below(gp.row0), candidates.count_below(gp.row1)
         else:
             lo, hi = 0, n
         n_loc = hi - lo
@@ -547,22 +569,22 @@ class ITAL(ActiveRetrievalBase):
             # ---- candidate list: two device buffers (the compaction reads one, writes the other)
             lists = b.get("cand_lists")
             if lists is None or lists[0].numel() < n_loc or b.get("alive") is None or b["alive"].numel() < n_loc \
-                    or b["sel_parts"].numel() < 3 * (n_loc // 32 + 64):
+                    or b["sel_parts"].numel() < self._sel_parts_doubles(k, n_loc):
                 b["cand_lists"] = lists = [torch.empty(max(n_loc, 1), dtype=torch.int32, device=dev) for _ in range(2)]
                 b["cand_cur"] = 0
                 b["alive"] = torch.empty(n_loc, dtype=torch.uint8, device=dev)
                 b["mi"] = torch.empty(n_loc, dtype=torch.float64, device=dev)
-                b["sel_parts"] = torch.empty(3 * (n_loc // 32 + 64), dtype=torch.float64, device=dev)
+                b["sel_parts"] = torch.empty(self._sel_parts_doubles(k, n_loc), dtype=torch.float64, device=dev)
                 b["sel_counter"] = torch.zeros(1, dtype=torch.int32, device=dev)
                 b["round_descs"] = [_lib.ItalRoundDesc(), _lib.ItalRoundDesc()]
                 b["round_next"] = None
                 self._dev_list = None
             dl = self._dev_list
-            uc = getattr(self, "_unseen_cache", None)
             stream = mvn_stream.GLOBAL
-            follows = (dl is not None and dl["b"] is b and uc is not None and candidates is uc["array"]
-                       and uc["parent"] is dl["host"] and len(uc["removed"]) == len(dl["picks"])
-                       and set(uc["removed"].tolist()) == set(dl["picks"]))
+            # the device holds the list as of version v with the picks of that round flagged dead: it follows the host's
+            # when the host's list is that version minus exactly those picks
+            follows = (listed and dl is not None and dl["b"] is b and dl["unseen"] is candidates
+                       and dl["version"] == candidates.version - 1 and tuple(sorted(dl["picks"])) == candidates.last_removed)
             self._dev_list = None                              # re-published after the round's successful download
             p = b["round_next"]
             if (p is not None and follows and not self.keep_scores and p["k"] == k and p["n"] == n and p["m"] == gp.m
@@ -585,8 +607,8 @@ class ITAL(ActiveRetrievalBase):
                     b["cand_cur"] ^= 1
                 else:
                     begin = 1
-                    lists[b["cand_cur"]][:n_loc].copy_(torch.from_numpy(
-                        (np.asarray(candidates[lo:hi], dtype=np.int64) - gp.row0).astype(np.int32)))
+                    share = candidates.in_rows(gp.row0, gp.row1) if listed else np.asarray(candidates, dtype=np.int64)
+                    lists[b["cand_cur"]][:n_loc].copy_(torch.from_numpy((share - gp.row0).astype(np.int32)))
                 p = self._round_prepare(0, b, k, n, gp.m, begin, b["cand_cur"], stream.state, n_prev, n_loc, lo)
             b["round_next"] = None
             self.last_round = (p["begin"], p["slot"])          # diagnostics / tests: how the candidate list reached the device
@@ -596,6 +618,14 @@ class ITAL(ActiveRetrievalBase):
                 keep = torch.zeros((k, n_loc), dtype=torch.float64, device=dev)
                 r.mi_keep = _ptr(keep)
             saved_stream = (stream.state, stream.draws)
+            hc = self.host_clock
+            if hc is not None:
+                # host time on the critical path of the retrieval loop: from the download of the previous round's picks (the
+                # caller's feedback, update(), this prologue) to the call that enqueues the next round
+                t_call = time.perf_counter()
+                if hc.get("t_download") is not None:
+                    hc["gap_s"] += t_call - hc["t_download"]
+                    hc["gaps"] += 1
             check(lib.ital_fetch_round(ctypes.byref(r), st))
             stream.state, stream.draws = p["state_after"], stream.draws + p["draws"]
             if self.profile is not None:
@@ -606,7 +636,11 @@ class ITAL(ActiveRetrievalBase):
                 # (several ranks: this rank's share of that list is known only with the picks -- patched in when the round comes)
                 b["round_next"] = self._round_prepare(p["slot"] ^ 1, b, k, n - k, gp.m + k, 2, b["cand_cur"] ^ 1, stream.state,
                                                       n_loc, n_loc if gp.collective else n - k, lo)
+            if hc is not None:
+                hc["enqueue_s"] += time.perf_counter() - t_call     # the call itself + the next round's descriptor (GPU busy)
             host = b["ret"].cpu().tolist()     # the only synchronisation of the round: the picks and the status word
+            if hc is not None:
+                hc["t_download"] = time.perf_counter()
             ret, status = host[:k], host[b["kmax"]]
             self.last_scores = [keep[t, :n_loc] for t in range(k)] if keep is not None else []
             if status & 8:
@@ -615,11 +649,12 @@ class ITAL(ActiveRetrievalBase):
                 # see _select: duplicates inside the batch / a simulated update that does not pin the labels
                 gp.status.bitwise_and_(~6)
                 stream.state, stream.draws = saved_stream
-                return self._fetch_generic(k, candidates)
+                return self._fetch_generic(k, candidates.array() if listed else candidates)
         if status:
             gp.check_status(status)
         self._last_batch = (b, list(ret))
-        self._dev_list = dict(b=b, host=candidates, picks=[int(i) for i in ret], n_loc=n_loc)
+        if listed:
+            self._dev_list = dict(b=b, unseen=candidates, version=candidates.version, picks=[int(i) for i in ret], n_loc=n_loc)
         return [int(i) for i in ret]
 
     # ------------------------------------------------------------------ general scorer (noisy users, estimation subset)
@@ -758,11 +793,12 @@ class ITAL(ActiveRetrievalBase):
                 desc.mi, desc.status = _ptr(mi), _ptr(gp.status)
                 desc.pair_count = _ptr(self.pair_counter)
                 if self.generic_pipeline and not subset_mode and not self._clip_active() and 3 <= nE + 1 <= 16:
-                    # workspace of the three-kernel pipeline: two buffers of prepared calls (slabs of candidates)
-                    n_u = nE + 1
-                    calls = npat * (1 + nfb)
-                    per_cand = calls * (3 + n_u * (n_u + 1) // 2 + n_u + 16 * (n_u - 1))
-                    want = min(2 * per_cand * max(n_loc, 1) + 4, max(self.qmc_work_bytes // 8, 2 * per_cand + 4))
+                    # workspace of the pipeline of kernels (verdicts, records of the calls to integrate): what one slab of
+                    # all candidates takes, capped (the library then walks the candidates in several slabs)
+                    desc.mc_rel, desc.mc_fb = (npat if rel_mc else 0), (nfb if fb_mc else 0)     # (read by the size query)
+                    want = int(lib.ital_score_generic_workspace(ctypes.byref(desc)))
+                    desc.mc_rel, desc.mc_fb = 0, 0
+                    want = min(want, max(self.qmc_work_bytes // 8, 1 << 16))
                     w = b.get("qmc_work")
                     if w is None or w.numel() < want:
                         b["qmc_work"] = w = torch.empty(want, dtype=torch.float64, device=dev)
@@ -883,7 +919,7 @@ class ITAL(ActiveRetrievalBase):
                         z_next = (g0, self._walk_normals(n_alive, g0, g1, npat_nx * (nr + 1)).reshape(-1, npat_nx, nr + 1))
                 if not subset_mode:
                     slot = t - 1
-                    if not gp.collective and n_loc <= _FUSED_SELECT_MAX:
+                    if not gp.collective and n_loc <= _FUSED_LAUNCH_MAX:
                         check(lib.ital_select_fused(_ptr(mi), _ptr(cand_d), _ptr(alive), n_loc, pos_offset, _ptr(gpos_d),
                                                     gp.row0, gp.rank, 0, _ptr(gp.mu), _ptr(gp.s2), _ptr(gp.Xd),
                                                     _ptr(gp.xnorm), gp.ldx, _ptr(gp.V), gp.ldv, gp.m, gp.cap, _ptr(C), gp.ldv,

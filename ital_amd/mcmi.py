@@ -40,7 +40,6 @@ class MCMI_min(ActiveRetrievalBase):
         self.eps = 1e-12  # reference ital/mcmi.py:88
         self.candidates = []
         self.keep_scores = False
-        self.split_kernel = True      # batches of 5 .. 8 through the split scorer (False: the single kernel; cross-check in tests)
         self.round_call = True        # one rank: the whole round as one call below the C ABI (False: step by step from here)
         self.last_scores = None
         self.profile = None
@@ -113,11 +112,11 @@ class MCMI_min(ActiveRetrievalBase):
         d.batch = b["batch"]
         d.noise, d.eps, d.ce = float(self.noise), float(self.eps), _ptr(ce)
         d.work, d.work_doubles = None, 0
-        if k >= 5 and self.split_kernel:
+        if k >= 5:
             want = int(lib.ital_mcmi_workspace(ITAL_MAX_T, nc))
             w = b.get("mcmi_work")
-            if w is None or w.numel() < want:          # zero-initialised once: the ticket counters return to zero
-                b["mcmi_work"] = w = torch.zeros(want, dtype=torch.float64, device=dev)
+            if w is None or w.numel() < want:
+                b["mcmi_work"] = w = torch.empty(want, dtype=torch.float64, device=dev)
             d.work, d.work_doubles = _ptr(w), w.numel()
         r.Xc, r.xnc, r.ldx, r.Vc, r.ldv, r.m, r.ldw = _ptr(Xc), _ptr(xnc), gp.ldx, _ptr(Vc), ldc, gp.m, gp.cap
         r.var, r.length_scale = float(self.var), float(self.length_scale)
@@ -189,12 +188,12 @@ class MCMI_min(ActiveRetrievalBase):
                 desc.batch = b["batch"]
                 desc.noise, desc.eps = float(self.noise), float(self.eps)
                 desc.ce = _ptr(ce)
-                if t >= 5 and self.split_kernel and n_i:
+                if t >= 5 and n_i:
                     # batches of 5 .. 8: preparation kernel + one workgroup per (candidate, group of label patterns)
                     want = int(lib.ital_mcmi_workspace(t, n_i))
                     w = b.get("mcmi_work")
-                    if w is None or w.numel() < want:      # zero-initialised once: the ticket counters return to zero
-                        b["mcmi_work"] = w = torch.zeros(int(lib.ital_mcmi_workspace(ITAL_MAX_T, n_i)), dtype=torch.float64,
+                    if w is None or w.numel() < want:
+                        b["mcmi_work"] = w = torch.empty(int(lib.ital_mcmi_workspace(ITAL_MAX_T, n_i)), dtype=torch.float64,
                                                          device=dev)
                     desc.work, desc.work_doubles = _ptr(w), w.numel()
                 ev0 = self._mark()

@@ -14,6 +14,78 @@ import numpy as np
 from .gp import GaussianProcess
 
 
+class UnseenList(object):
+    """The ascending list of samples without feedback (reference retrieval_base.py:78-87) as an ascending base array plus a
+    short sorted list of ids taken out of it since: what a round of the retrieval loop needs from the list -- its length,
+    the number of entries below a row boundary, the entries of one rank's rows -- costs O(k log N) per round instead of a
+    copy of the N-sized array (8 MB at a million samples, on the critical path of every rank whatever the number of ranks).
+    The array itself is only formed for callers that read it (get_unseen(), the options that restrict or subsample the
+    list).  `version` counts the removals: the candidate list a device holds is described by the version it was built
+    from (ital.py)."""
+
+    REBASE_AT = 4096         # removed ids from which a materialisation also becomes the new base
+
+    def __init__(self, base):
+        self.base = base                     # ascending int64 array, never written to
+        self.removed = []                    # ascending python ints, all members of base
+        self.version = 0
+        self.last_removed = ()               # the ids of the last remove() (version - 1 -> version)
+        self._flat = base                    # the list as an array (None: not formed since the last removal)
+
+    def __len__(self):
+        return len(self.base) - len(self.removed)
+
+    def count_below(self, x):
+        """Number of list entries < x (= list position of the first entry >= x)."""
+        import bisect
+        return int(np.searchsorted(self.base, x)) - bisect.bisect_left(self.removed, x)
+
+    def remove(self, ids):
+        """Takes `ids` (distinct) out of the list; False (list unchanged) when one of them is not on it."""
+        import bisect
+        ids = sorted(set(int(i) for i in ids))
+        if not ids:
+            return True
+        arr = np.asarray(ids, dtype=np.int64)
+        at = np.searchsorted(self.base, arr)
+        if np.any(at >= len(self.base)) or np.any(self.base[np.minimum(at, len(self.base) - 1)] != arr):
+            return False
+        for i in ids:
+            j = bisect.bisect_left(self.removed, i)
+            if j < len(self.removed) and self.removed[j] == i:
+                return False
+        prev = self._flat
+        for i in ids:
+            bisect.insort(self.removed, i)
+        self.version += 1
+        self.last_removed = tuple(ids)
+        self._flat, self._prev_flat = None, (prev, arr) if prev is not None else None
+        return True
+
+    def in_rows(self, row0, row1):
+        """The list entries in [row0, row1) as an array: O(entries returned)."""
+        import bisect
+        a, b = int(np.searchsorted(self.base, row0)), int(np.searchsorted(self.base, row1))
+        part = self.base[a:b]
+        r0, r1 = bisect.bisect_left(self.removed, row0), bisect.bisect_left(self.removed, row1)
+        if r1 > r0:
+            part = np.delete(part, np.searchsorted(part, np.asarray(self.removed[r0:r1], dtype=np.int64)))
+        return part
+
+    def array(self):
+        """The whole list as an int64 array (treat as read-only; the same object until the next removal)."""
+        if self._flat is None:
+            prev = getattr(self, "_prev_flat", None)
+            if prev is not None:             # the array before the last removal is at hand: one pass over it
+                self._flat = np.delete(prev[0], np.searchsorted(prev[0], prev[1]))
+            else:
+                self._flat = np.delete(self.base, np.searchsorted(self.base, np.asarray(self.removed, dtype=np.int64)))
+            self._prev_flat = None
+            if len(self.removed) >= self.REBASE_AT:
+                self.base, self.removed = self._flat, []
+        return self._flat
+
+
 class ActiveRetrievalBase(object):
 
     #: initial capacity of the labelled set on the device (None: GaussianProcess picks it; it grows on demand)
@@ -45,7 +117,6 @@ class ActiveRetrievalBase(object):
         self.irrelevant_ids = set()
         self.unnameable_ids = set()
         self._last_batch = None
-        self._unseen_cache = None
         self.gp.reset()
         if len(self.queries) > 0:
             n = len(self.data)
@@ -59,20 +130,25 @@ class ActiveRetrievalBase(object):
     def state_dict(self):
         """Everything needed to continue a retrieval session in another process: the labelled set in insertion order with
         the sizes of the update() calls that built it, the id sets, the round counter and the position of the replayed
-        mvndst stream.  Small (O(labelled samples)): the whitened block V is rebuilt on load, not stored."""
+        mvndst stream and the state of numpy's global legacy generator (what MCMI_min(subsample), the change-estimation
+        subset and the Monte-Carlo switches draw from, as the reference does).  Small (O(labelled samples)): the whitened
+        block V is rebuilt on load, not stored -- the replay appends sample by sample where the session appended staged
+        batches, so the means agree to ~1e-15, not bit for bit (a pick at an exact numerical tie may differ)."""
         from . import mvn_stream
         gp = self.gp
         return dict(version=1, n=len(self.data), hyper=(float(self.length_scale), float(self.var), float(self.noise)),
                     ind=[int(i) for i in gp.ind], y=(gp.y.copy() if gp.y is not None else np.zeros(0)),
                     appends=list(gp.appends), relevant_ids=sorted(self.relevant_ids),
                     irrelevant_ids=sorted(self.irrelevant_ids), unnameable_ids=sorted(self.unnameable_ids),
-                    rounds=int(self.rounds), mvn_stream=(tuple(mvn_stream.GLOBAL.state), int(mvn_stream.GLOBAL.draws)))
+                    rounds=int(self.rounds), mvn_stream=(tuple(mvn_stream.GLOBAL.state), int(mvn_stream.GLOBAL.draws)),
+                    np_random=np.random.get_state())
 
     def load_state_dict(self, sd, restore_stream=True):
         """Restores a session saved by state_dict() on a learner constructed over the same data (and queries) with the same
         hyper-parameters: reset(), then the same sequence of appends to the GP (same kernels, same order: the predictive
         means equal the saved session's to ~1e-15), the id sets, the round counter and -- unless told otherwise -- the
-        process-wide position of the mvndst stream.  Collective on several ranks, like update()."""
+        process-wide positions of the two random streams (mvndst's, numpy's global generator).  Collective on several ranks,
+        like update()."""
         from . import mvn_stream
         if sd.get("version") != 1 or sd["n"] != len(self.data):
             raise ValueError("state_dict of another data set / version")
@@ -94,9 +170,10 @@ class ActiveRetrievalBase(object):
         self.unnameable_ids = set(sd["unnameable_ids"])
         self.rounds = int(sd["rounds"])
         self._fitted = self.gp.m > 0
-        self._unseen_cache = None
         if restore_stream:
             mvn_stream.GLOBAL.state, mvn_stream.GLOBAL.draws = tuple(sd["mvn_stream"][0]), int(sd["mvn_stream"][1])
+            if sd.get("np_random") is not None:
+                np.random.set_state(sd["np_random"])
         return self
 
     @property
@@ -120,14 +197,32 @@ class ActiveRetrievalBase(object):
         """reference retrieval_base.py:78-87 (ascending sample indices, python ints)."""
         return self._unseen_array().tolist()
 
-    def _unseen_array(self):
-        """Ascending indices of the samples without feedback (int64 array; treat as read-only).  The array of the previous
-        call is kept: after an update() that only added feedback it is shortened by the newly seen samples instead of being
-        rebuilt from the three sets (N-sized work on the critical path of every round otherwise)."""
-        sizes = (len(self.relevant_ids), len(self.irrelevant_ids), len(self.unnameable_ids))
-        c = getattr(self, "_unseen_cache", None)
-        if c is not None and c["sizes"] == sizes:
-            return c["array"]
+    # the three id sets are public attributes, as in the reference; assigning a new set to one of them (rather than going
+    # through update()) invalidates the derived candidate bookkeeping
+    def _set_ids(self, name, value):
+        self.__dict__[name] = value
+        self.__dict__["_unseen"] = None
+
+    def _get_ids(self, name):
+        try:
+            return self.__dict__[name]
+        except KeyError:
+            raise AttributeError(name[1:]) from None       # before fit() / reset(), as an attribute never assigned
+
+    relevant_ids = property(lambda self: self._get_ids("_relevant_ids"), lambda self, v: self._set_ids("_relevant_ids", v))
+    irrelevant_ids = property(lambda self: self._get_ids("_irrelevant_ids"), lambda self, v: self._set_ids("_irrelevant_ids", v))
+    unnameable_ids = property(lambda self: self._get_ids("_unnameable_ids"), lambda self, v: self._set_ids("_unnameable_ids", v))
+
+    def _id_sizes(self):
+        return (len(self.relevant_ids), len(self.irrelevant_ids), len(self.unnameable_ids))
+
+    def _unseen_list(self):
+        """The samples without feedback as an UnseenList, kept between calls: update() takes the newly seen samples out of
+        it (O(k log N)).  Rebuilt from the three id sets (N-sized work) when they were changed behind update()'s back:
+        a set assigned anew, or sizes that no longer match what update() left."""
+        u = self.__dict__.get("_unseen")
+        if u is not None and u[1] == self._id_sizes():
+            return u[0]
         seen = self.relevant_ids | self.irrelevant_ids | self.unnameable_ids
         if not seen:
             arr = np.arange(len(self.data), dtype=np.int64)
@@ -135,30 +230,26 @@ class ActiveRetrievalBase(object):
             mask = np.ones(len(self.data), dtype=bool)
             mask[np.fromiter(seen, dtype=np.int64, count=len(seen))] = False
             arr = np.flatnonzero(mask)
-        self._unseen_cache = dict(sizes=sizes, array=arr, parent=None, removed=None)
-        return arr
+        lst = UnseenList(arr)
+        self.__dict__["_unseen"] = (lst, self._id_sizes())
+        return lst
+
+    def _unseen_array(self):
+        """Ascending indices of the samples without feedback (int64 array; treat as read-only)."""
+        return self._unseen_list().array()
 
     def _unseen_after(self, new_ids, sizes_before):
-        """Called by update() once the id sets hold `new_ids` (samples that had no feedback before): the cached array minus
-        them, remembering what it was derived from (the device keeps its candidate list the same way, ital.py)."""
-        c = getattr(self, "_unseen_cache", None)
-        if c is None or c["sizes"] != sizes_before:
-            self._unseen_cache = None
+        """Called by update() once the id sets hold `new_ids` (samples that had no feedback before): the kept list loses
+        them (the device keeps its candidate list the same way, ital.py)."""
+        u = self.__dict__.get("_unseen")
+        if u is None or u[1] != sizes_before:
+            self.__dict__["_unseen"] = None
             return
-        arr = c["array"]
-        ids = np.asarray(sorted(set(int(i) for i in new_ids)), dtype=np.int64)
-        if len(ids):
-            at = np.searchsorted(arr, ids)
-            if np.any(at >= len(arr)) or np.any(arr[np.minimum(at, len(arr) - 1)] != ids):
-                self._unseen_cache = None          # feedback for something that was not a candidate: rebuild next time
-                return
-            cuts = [0] + (at + 1).tolist()          # the pieces between the removed entries, copied once
-            ends = at.tolist() + [len(arr)]
-            new = np.concatenate([arr[a:b] for a, b in zip(cuts, ends)])
-        else:
-            new = arr
-        sizes = (len(self.relevant_ids), len(self.irrelevant_ids), len(self.unnameable_ids))
-        self._unseen_cache = dict(sizes=sizes, array=new, parent=arr, removed=ids)
+        ids = set(int(i) for i in new_ids)
+        if not u[0].remove(ids):
+            self.__dict__["_unseen"] = None        # feedback for something that was not a candidate: rebuild next time
+            return
+        self.__dict__["_unseen"] = (u[0], self._id_sizes())
 
     def fetch_unlabelled(self, k):
         raise NotImplementedError('fetch_unlabelled() has to be implemented in a derived class.')

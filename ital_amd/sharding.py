@@ -64,56 +64,118 @@ def _host_staged(t, group):
     return t.is_cuda and dist.get_backend(group) == "gloo"
 
 
-_RAW_COMMS = {}
+_RAW_COMMS = {}          # (id(group), device) -> (group, ncclComm_t as int or None, why the group stays on torch.distributed)
+_log = None
+
+
+def _logger():
+    global _log
+    if _log is None:
+        import logging
+        _log = logging.getLogger("ital_amd.sharding")
+    return _log
+
+
+def _agree(flag, group, device):
+    """min over the ranks of a 0/1 flag, through torch.distributed (the decision every rank must take alike)."""
+    import torch
+    import torch.distributed as dist
+    t = torch.tensor([1 if flag else 0], dtype=torch.int32, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MIN, group=group)
+    return bool(int(t.item()))
 
 
 def raw_comm(group, device):
     """This rank's ncclComm_t of an "nccl" (RCCL) process group as an integer -- the communicator torch.distributed itself
-    uses (ProcessGroupNCCL._comm_ptr) -- or None: other backends, a torch without that accessor, a communicator that is not
-    connected yet, ITAL_RAW_COMM=0.  With it the library issues ncclAllGather itself, on the caller's stream
-    (ital_select_exchange, ital_fetch_round): no trip through torch.distributed's Python and stream hand-over per exchange.
-    Operations on the communicator stay ordered: torch's own collectives wait for the current stream and the current
-    stream waits for them (async_op=False everywhere in this package)."""
+    uses (ProcessGroupNCCL._comm_ptr) -- or None: other backends, a torch without that accessor, ITAL_RAW_COMM=0, a
+    communicator that fails the checks below ON ANY RANK.  With it the library issues ncclAllGather itself, on the
+    caller's stream (ital_select_exchange, ital_fetch_round): no trip through torch.distributed's Python and stream
+    hand-over per exchange.  Operations on the communicator stay ordered: torch's own collectives wait for the current
+    stream and the current stream waits for them (async_op=False everywhere in this package).
+
+    COLLECTIVE on first use per group (every rank of the group must call it at the same point -- the first exchange of a
+    learner is such a point): whether the ranks leave torch.distributed is decided TOGETHER, never by a rank alone.  (1) a
+    torch all-reduce (MIN) of "this rank wants to and may" (backend, ITAL_RAW_COMM) -- it also connects the communicator;
+    (2) every rank reads its communicator and asks the library what RCCL says about it (ital_exchange_info: size and rank
+    must be the group's), all-reduce (MIN) of the outcome; (3) only if every rank passed: one small all-gather through
+    ital_select_exchange, checked against what every rank must receive, all-reduce (MIN) of that.  A rank that fails a
+    step says why (logging, `raw_comm_reason`), and ALL ranks stay on torch.distributed: nobody is left waiting in a raw
+    all-gather the others never enter."""
     import os
     import torch
     import torch.distributed as dist
-    if group is None or not dist.is_initialized() or os.environ.get("ITAL_RAW_COMM") == "0":
+    if group is None or not dist.is_initialized():
         return None
     key = (id(group), str(device))
-    if key not in _RAW_COMMS:
-        comm = None
+    if key in _RAW_COMMS:
+        return _RAW_COMMS[key][1]
+    if dist.get_backend(group) != "nccl":          # (a property of the group: the same on every rank)
+        _RAW_COMMS[key] = (group, None, "backend %s moves the records through torch.distributed" % dist.get_backend(group))
+        return None
+    dev = torch.device(device)
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    comm, why = None, None
+    if os.environ.get("ITAL_RAW_COMM") == "0":
+        why = "ITAL_RAW_COMM=0 on rank %d" % rank
+    backend = None
+    if why is None:
         try:
-            if dist.get_backend(group) == "nccl":
-                comm = int(group._get_backend(torch.device(device))._comm_ptr()) or None
-        except Exception:      # noqa: BLE001
-            comm = None
-        if comm is None:
-            return None        # (not cached: the communicator may connect with the first collective)
-        if not _raw_comm_works(group, device, comm):
-            comm = None        # cached: every later exchange of this group goes through torch.distributed
-        _RAW_COMMS[key] = (group, comm)      # the group is kept alive with its entry: ids are not reused under it
-    return _RAW_COMMS[key][1]
+            backend = group._get_backend(dev)
+            if not hasattr(backend, "_comm_ptr"):
+                why = "this torch's ProcessGroupNCCL has no _comm_ptr()"
+        except Exception as e:      # noqa: BLE001
+            why = "no NCCL backend object for %s: %r" % (dev, e)
+    ok = _agree(why is None, group, dev)           # step 1 (the all-reduce itself connects the communicator)
+    if ok:
+        try:
+            comm = int(backend._comm_ptr()) or None
+            if comm is None:
+                why = "rank %d: the communicator is not connected (null _comm_ptr)" % rank
+            else:
+                from . import _lib
+                import ctypes
+                w, r = ctypes.c_int(-1), ctypes.c_int(-1)
+                how = ctypes.create_string_buffer(600)
+                _lib.check(_lib.lib().ital_exchange_info(comm, ctypes.byref(w), ctypes.byref(r), how, 600))
+                if (w.value, r.value) != (world, rank):
+                    why = ("rank %d: RCCL numbers this communicator rank %d of %d, the process group rank %d of %d"
+                           % (rank, r.value, w.value, rank, world))
+        except Exception as e:      # noqa: BLE001
+            why = "rank %d: %s" % (rank, e)
+        ok = _agree(why is None, group, dev)       # step 2
+    if ok:
+        try:
+            probe = _raw_comm_probe(dev, world, rank, comm)
+            if not probe:
+                why = "rank %d: the probing all-gather on the raw communicator returned other data than expected" % rank
+        except Exception as e:      # noqa: BLE001
+            why = "rank %d: the probing all-gather on the raw communicator failed: %s" % (rank, e)
+        ok = _agree(why is None, group, dev)       # step 3
+    if not ok:
+        why = why or "another rank of the group cannot use its raw communicator (its log says why)"
+        _logger().warning("ital_amd: record exchange of this process group stays on torch.distributed: %s", why)
+        comm = None
+    _RAW_COMMS[key] = (group, comm, why)           # the group is kept alive with its entry: ids are not reused under it
+    return comm
 
 
-def _raw_comm_works(group, device, comm):
-    """First use of a group's communicator below the C ABI: one small all-gather through ital_select_exchange, checked
-    against what every rank must receive (rank r contributes r + 1).  Reached by all ranks together (the first exchange of
-    a learner is collective).  Anything but the expected block -- an exception, a communicator with another rank order --
-    keeps the group on torch.distributed."""
+def raw_comm_reason(group, device):
+    """Why `raw_comm` keeps this group on torch.distributed (None: it does not, or was not asked yet)."""
+    e = _RAW_COMMS.get((id(group), str(device)))
+    return e[2] if e else None
+
+
+def _raw_comm_probe(dev, world, rank, comm):
+    """One small all-gather through ital_select_exchange on the communicator, checked against what every rank must
+    receive (rank r contributes r + 1).  Entered by all ranks or by none (raw_comm agrees on that first)."""
     import torch
-    import torch.distributed as dist
-    try:
-        from . import _lib
-        world, rank = dist.get_world_size(group), dist.get_rank(group)
-        dev = torch.device(device)
-        send = torch.full((2,), float(rank + 1), dtype=torch.float64, device=dev)
-        recv = torch.zeros((world, 2), dtype=torch.float64, device=dev)
-        _lib.check(_lib.lib().ital_select_exchange(send.data_ptr(), recv.data_ptr(), 2, comm,
-                                                   torch.cuda.current_stream(dev).cuda_stream))
-        want = torch.arange(1, world + 1, dtype=torch.float64).repeat_interleave(2).reshape(world, 2)
-        return bool(torch.equal(recv.cpu(), want))
-    except Exception:      # noqa: BLE001
-        return False
+    from . import _lib
+    send = torch.full((2,), float(rank + 1), dtype=torch.float64, device=dev)
+    recv = torch.zeros((world, 2), dtype=torch.float64, device=dev)
+    _lib.check(_lib.lib().ital_select_exchange(send.data_ptr(), recv.data_ptr(), 2, comm,
+                                               torch.cuda.current_stream(dev).cuda_stream))
+    want = torch.arange(1, world + 1, dtype=torch.float64).repeat_interleave(2).reshape(world, 2)
+    return bool(torch.equal(recv.cpu(), want))
 
 
 def gather_records(record, out, group=None):

@@ -42,6 +42,10 @@ FIXTURES = {
                                 kw=dict(label_estimation="optimistic")),
     "synth200_topcand": dict(data="synth", rows=200, d=12, ls=None, k=3, rounds=2, learner="ITAL",
                              kw=dict(top_candidates=40)),
+    # float top_candidates = multiple of the number of labelled samples (reference ital.py:111-114; what the shipped
+    # *-topscoring.conf use): 12, 50, 87 candidates in rounds 1 .. 3
+    "synth200_topcand_float": dict(data="synth", rows=200, d=12, ls=None, k=3, rounds=3, learner="ITAL",
+                                   kw=dict(top_candidates=12.5)),
     "iris_ce5": dict(data="iris", rows=120, ls=0.1, k=4, rounds=2, learner="ITAL",
                      kw=dict(change_estimation_subset=5)),
     "synth80_mcrel": dict(data="synth", rows=80, d=6, ls=None, k=5, rounds=1, learner="ITAL",

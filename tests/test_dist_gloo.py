@@ -96,6 +96,79 @@ def test_no_raw_communicator_outside_rccl():
     assert sharding.raw_comm(None, "cpu") is None      # no process group at all
 
 
+class _FakeNcclBackend(object):
+    """Stands in for ProcessGroupNCCL on a CPU box: hands out a 'communicator' per the test's plan."""
+
+    def __init__(self, ptr):
+        self.ptr = ptr
+
+    def _comm_ptr(self):
+        return self.ptr
+
+
+def _raw_decision_worker(rank, world, port, plan, ret):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import ctypes
+        from ital_amd import _lib
+        group = dist.group.WORLD
+        # the protocol of sharding.raw_comm with the pieces below the C ABI replaced (no RCCL on a CPU box): gloo carries
+        # the agreeing all-reduces, the backend / communicator checks follow the plan of this rank
+        real_backend = dist.get_backend
+        dist.get_backend = lambda g=None: "nccl"
+        if plan[rank] == "env":
+            os.environ["ITAL_RAW_COMM"] = "0"
+        type(group)._get_backend = lambda self, dev: _FakeNcclBackend(0 if plan[rank] == "null" else 1234 + rank)
+
+        class FakeLib(object):
+            def ital_exchange_info(self, comm, w, r, how, n):
+                if plan[rank] == "norccl":
+                    return -38
+                ctypes.cast(w, ctypes.POINTER(ctypes.c_int))[0] = world
+                ctypes.cast(r, ctypes.POINTER(ctypes.c_int))[0] = (rank + 1) % world if plan[rank] == "order" else rank
+                return 0
+
+            def ital_last_error(self):
+                return b"no RCCL (test)"
+
+        real_lib = _lib.lib
+        _lib.lib = lambda: FakeLib()
+        probes = []
+        sharding._raw_comm_probe = lambda dev, w, r, comm: probes.append(comm) or plan[rank] != "probe"
+        try:
+            got = sharding.raw_comm(group, "cpu")
+            again = sharding.raw_comm(group, "cpu")              # cached: no further collective
+        finally:
+            dist.get_backend, _lib.lib = real_backend, real_lib
+        ret[rank] = (got, again, len(probes), sharding.raw_comm_reason(group, "cpu"))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("plan", [("ok", "ok"), ("env", "ok"), ("ok", "null"), ("norccl", "ok"), ("ok", "order"), ("probe", "ok")])
+def test_leaving_torch_distributed_is_decided_by_all_ranks_together(plan):
+    """sharding.raw_comm: a rank without a usable communicator (ITAL_RAW_COMM=0 on that rank only, a null _comm_ptr, no RCCL
+    found, another rank order, a failed probe) keeps EVERY rank on torch.distributed -- nobody enters a raw all-gather
+    alone -- and says why; with all ranks fine all of them get their communicator.  (Gloo carries the agreement here; on a
+    GPU node the same code runs over RCCL, tests/test_gpu_multidevice.py.)"""
+    port = _free_port()
+    with mp.Manager() as mgr:
+        ret = mgr.dict()
+        mp.spawn(_raw_decision_worker, args=(2, port, plan, ret), nprocs=2, join=True)
+        res = dict(ret)
+    if plan == ("ok", "ok"):
+        assert [res[r][0] for r in (0, 1)] == [1234, 1235] and res[0][2] == res[1][2] == 1
+        assert res[0][3] is None and res[1][3] is None
+    else:
+        bad = [r for r in (0, 1) if plan[r] != "ok"][0]
+        for r in (0, 1):
+            assert res[r][0] is None and res[r][1] is None and res[r][3]
+            assert res[r][2] == (1 if "probe" in plan else 0)        # the probe is entered by both ranks or by neither
+        assert ("rank %d" % bad) in res[bad][3] and "another rank" in res[1 - bad][3]
+
+
 def test_row_range_tiles():
     for n in (1, 7, 64, 9298, 1000003):
         for world in (1, 2, 3, 8):

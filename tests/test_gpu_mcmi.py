@@ -148,43 +148,50 @@ def test_mcmi_against_oracle(dev, seed, n, d, k, sub):
         B.update(fb)
 
 
-@pytest.mark.parametrize("n,d,k,sub", [(90, 5, 8, None), (400, 12, 7, 300), (130, 7, 6, None), (1200, 16, 5, 1000)])
-def test_mcmi_split_scorer_equals_single_kernel(dev, n, d, k, sub):
-    """Batches of 5 .. 8 (three shipped configurations use batch_size = 6, reference configs/toy*.conf): the split form
-    (preparation kernel + one workgroup per candidate and group of label patterns) forms every sum over the candidates in
-    the order of the single kernel -- same values to the last bits, same picks; the small case is also checked against the oracle."""
+@pytest.mark.parametrize("n,d,k,sub", [(90, 5, 8, None), (110, 12, 7, None), (130, 7, 6, None), (400, 16, 5, 120)])
+def test_mcmi_split_scorer_against_the_oracle(dev, n, d, k, sub):
+    """Batches of 5 .. 8 (three shipped configurations use batch_size = 6, reference configs/toy*.conf) run as a preparation
+    kernel + one workgroup per candidate and group of label patterns (the only form since round 4: the single kernel
+    needed 256 + 184 registers and scratch there).  Picks and every conditional entropy of two rounds against the oracle;
+    a workspace that served a larger block before (stale data where the new call keeps its counters) changes nothing."""
     from ital_amd import MCMI_min
+    from oracle.ital import OracleMCMI
     rng = np.random.default_rng(10 + k)
     X = rng.random((n, d))
     ls = float(np.sqrt(d / 12.0))
     labels = {int(i): (1 if X[i, 0] > 0.5 else -1) for i in rng.choice(n, 3, replace=False)}
-    out = []
-    for split in (True, False):
-        L = MCMI_min(X, length_scale=ls, subsample=sub, device=dev)
-        L.split_kernel = split
-        L.keep_scores = True
-        L.update(labels)
-        res = []
-        for _ in range(2):
-            np.random.seed(5)
-            ret = L.fetch_unlabelled(k)
-            res.append((ret, [s_.cpu().numpy().copy() for s_ in L.last_scores]))
-            L.update({i: (1 if X[i, 0] > 0.5 else -1) for i in ret})
-        out.append(res)
-    for (ra, sa), (rb, sb) in zip(*out):
-        assert ra == rb
-        for x, y in zip(sa, sb):
-            np.testing.assert_allclose(x, y, rtol=1e-13, atol=0)      # (last bits differ: the compiler contracts the two forms' FMAs differently)
-    if n <= 100:
-        from oracle.ital import OracleMCMI
-        B = OracleMCMI(X, length_scale=ls, subsample=sub)
-        B.update(labels)
-        np.random.seed(5)
+    A = MCMI_min(X, length_scale=ls, subsample=sub, device=dev)
+    A.keep_scores = True
+    A.round_call = False              # step by step: the scores of every step are kept
+    B = OracleMCMI(X, length_scale=ls, subsample=sub)
+    A.update(labels)
+    B.update(labels)
+    for rnd in range(2):
+        np.random.seed(5 + rnd)
+        got = A.fetch_unlabelled(k)
+        np.random.seed(5 + rnd)
         want = [int(i) for i in B.fetch_unlabelled(k)]
-        assert out[0][0][0] == want
+        assert got == want
         pos = {c: i for i, c in enumerate(B.trace[0][0])}
         for t, (cand, vals, _) in enumerate(B.trace):
-            np.testing.assert_allclose(out[0][0][1][t][[pos[c] for c in cand]], vals, rtol=CE_RTOL, atol=0)
+            np.testing.assert_allclose(A.last_scores[t].cpu().numpy()[[pos[c] for c in cand]], vals, rtol=CE_RTOL, atol=0)
+        fb = {i: (1 if X[i, 0] > 0.5 else -1) for i in got}
+        A.update(fb)
+        B.update(fb)
+        if rnd == 0:
+            # leave garbage in the workspace where a block of another size keeps its ticket counters
+            A._fetch_bufs[1]["mcmi_work"].fill_(float("nan"))
+
+
+def test_mcmi_batches_above_four_need_the_workspace(dev):
+    """C ABI: ital_mcmi_score_step with t >= 5 and no workspace is refused (-22), not silently run another way."""
+    import ctypes
+    from ital_amd import _lib
+    d = _lib.ItalMcmiDesc()
+    d.t, d.n_i, d.n_all, d.ld_cov, d.ldc = 5, 8, 8, 8, 8
+    d.batch.kmax = 8
+    rc = _lib.lib().ital_mcmi_score_step(ctypes.byref(d), None)
+    assert rc == -22 and b"workspace" in _lib.lib().ital_last_error()
 
 
 @pytest.mark.parametrize("n,d,k,sub", [(70, 5, 4, None), (400, 12, 6, 300), (1200, 16, 3, 1000), (40, 3, 8, None)])

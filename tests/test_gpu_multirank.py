@@ -2,7 +2,6 @@
 their records over gloo, host-staged) must reproduce the single-rank picks and the reference's golden picks.
 The RCCL transport itself is the driver's multi-GPU bench; everything else of the N > 1 path runs here."""
 import os
-import socket
 import sys
 
 import numpy as np
@@ -12,29 +11,20 @@ pytestmark = pytest.mark.gpu
 
 torch = pytest.importorskip("torch")
 import torch.distributed as dist  # noqa: E402
-import torch.multiprocessing as mp  # noqa: E402
 
 HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
 sys.path.insert(0, os.path.join(HERE, "golden"))
+import _ranks  # noqa: E402
 import make_golden  # noqa: E402  (fixture table only)
 import make_golden_baselines  # noqa: E402  (fixture table only)
 
 FIXTURES = dict(make_golden.FIXTURES, **make_golden_baselines.FIXTURES)
 
 
-def _free_port():
-    s = socket.socket()
-    s.bind(("127.0.0.1", 0))
-    p = s.getsockname()[1]
-    s.close()
-    return p
-
-
-def _worker(rank, world, port, name, out):
-    os.environ["MASTER_ADDR"] = "127.0.0.1"
-    os.environ["MASTER_PORT"] = str(port)
-    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+def _worker(rank, world, port, name, mode, out):
+    """A golden fixture's session on `world` ranks (placement: _ranks.join).  Everything the assertions need goes to out[rank]."""
+    dev, group = _ranks.join(rank, world, port, mode)
     try:
         from ital_amd import ITAL, MCMI_min, mvn_stream
         from ital_amd.baselines import EMOC, EntropySampling
@@ -43,8 +33,8 @@ def _worker(rank, world, port, name, out):
         cls = {"ITAL": ITAL, "MCMI_min": MCMI_min, "EMOC": EMOC, "EntropySampling": EntropySampling}[spec["learner"]]
         np.random.seed(0)
         mvn_stream.GLOBAL.reset()
-        L = cls(z["X"], length_scale=float(z["length_scale"]), device="cuda:0", rank=rank, world=world,
-                group=dist.group.WORLD, **spec["kw"])
+        L = cls(z["X"], length_scale=float(z["length_scale"]), device=dev, rank=rank, world=world, group=group, **spec["kw"])
+        assert L.gp.collective
         L.update({int(z["query"]): 1})
         rel = z["rel"]
         picks = []
@@ -58,49 +48,54 @@ def _worker(rank, world, port, name, out):
             top = (np.asarray(L.top_results(10)).tolist(), np.asarray(L.rel_mean).copy())
         dist.barrier()
         upd = L.updated_prediction({int(rel.argmax()): 1, int(rel.argmin()): -1}, [0, len(rel) // 2, len(rel) - 1])
-        out[rank] = (picks, np.asarray(L.rel_mean).copy(), (L.gp.row0, L.gp.row1), top, upd)
+        transport = L._round_transport() if hasattr(L, "_round_transport") else None
+        out[rank] = (picks, np.asarray(L.rel_mean).copy(), (L.gp.row0, L.gp.row1), top, upd, transport and transport[0],
+                     (mvn_stream.GLOBAL.draws, tuple(mvn_stream.GLOBAL.state)))
     finally:
-        dist.destroy_process_group()
+        _ranks.leave(group)
 
 
-@pytest.mark.parametrize("name", ["usps500", "synth96_k6", "synth300_mcmi", "usps500_mcmi", "emoc_synth150",
-                                  "entropy_synth80", "synth80_mcrel", "synth50_mcboth", "synth200_topcand",
-                                  "synth200_noisy", "synth50_clip"])
-def test_two_ranks_match_golden(name):
-    if not torch.cuda.is_available():
-        pytest.skip("no GPU")
+def check_golden(name, res):
+    """What every rank of a sharded golden session must have produced (`res`: out[0 .. world - 1] of _worker)."""
     z = np.load(os.path.join(HERE, "golden", name + ".npz"))
-    world, port = 2, _free_port()
-    with mp.Manager() as mgr:
-        out = mgr.dict()
-        mp.spawn(_worker, args=(world, port, name, out), nprocs=world, join=True)
-        r0, r1 = out[0], out[1]
+    world = len(res)
     want = [z[f"r{r}_ret"].tolist() for r in range(int(z["rounds"]))]
-    assert r0[0] == want and r1[0] == want                          # both ranks return the reference's picks
-    np.testing.assert_allclose(r0[1], z["final_rel_mean"], rtol=0, atol=1e-9)
-    np.testing.assert_array_equal(r0[1], r1[1])
-    assert r0[2][0] == 0 and r0[2][1] == r1[2][0] and r1[2][1] == len(z["X"])   # each rank held half of the rows
-    top10, mean0 = r0[3]
+    for r in res:
+        assert r[0] == want                                         # every rank returns the reference's picks
+        np.testing.assert_array_equal(r[1], res[0][1])
+        assert r[6] == res[0][6]                                    # the replayed mvndst stream stands at the same place
+    np.testing.assert_allclose(res[0][1], z["final_rel_mean"], rtol=0, atol=1e-9)
+    n = len(z["X"])
+    assert res[0][2][0] == 0 and res[-1][2][1] == n                 # the ranks' row blocks tile the data
+    assert all(res[w][2][1] == res[w + 1][2][0] for w in range(world - 1))
+    top10, mean0 = res[0][3]
     assert top10 == np.argsort(mean0, kind="stable")[::-1][:10].tolist()
     if "top_results_10" in z:
         assert top10 == z["top_results_10"].tolist()
-    # full covariance blocks across the shards: both ranks hold the same simulated update (reference retrieval_base.py:129-164)
-    np.testing.assert_array_equal(r0[4][0], r1[4][0])
-    np.testing.assert_array_equal(r0[4][1], r1[4][1])
-    assert r0[4][1].shape == (3, 3) and np.all(np.isfinite(r0[4][1]))
+    # full covariance blocks across the shards: all ranks hold the same simulated update (reference retrieval_base.py:129-164)
+    for r in res[1:]:
+        np.testing.assert_array_equal(res[0][4][0], r[4][0])
+        np.testing.assert_array_equal(res[0][4][1], r[4][1])
+    assert res[0][4][1].shape == (3, 3) and np.all(np.isfinite(res[0][4][1]))
 
 
-def _dup_worker(rank, world, port, X, out):
-    os.environ["MASTER_ADDR"] = "127.0.0.1"
-    os.environ["MASTER_PORT"] = str(port)
-    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-    if world > 1:
-        dist.init_process_group("gloo", rank=rank, world_size=world)
+GOLDEN_SHARDED = ["usps500", "synth96_k6", "synth300_mcmi", "usps500_mcmi", "emoc_synth150", "entropy_synth80", "synth80_mcrel",
+                  "synth50_mcboth", "synth200_topcand", "synth200_topcand_float", "synth200_noisy", "synth50_clip"]
+
+
+@pytest.mark.parametrize("name", GOLDEN_SHARDED)
+def test_two_ranks_match_golden(name):
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    check_golden(name, _ranks.spawn(_worker, 2, name, "gloo"))
+
+
+def _dup_worker(rank, world, port, X, mode, out):
+    dev, group = _ranks.join(rank, world, port, mode)
     try:
         from ital_amd import ITAL, mvn_stream
         mvn_stream.GLOBAL.reset()
-        L = ITAL(X, length_scale=0.9, device="cuda:0", rank=rank, world=world,
-                 group=dist.group.WORLD if world > 1 else None)
+        L = ITAL(X, length_scale=0.9, device=dev, rank=rank, world=world, group=group)
         L.keep_scores = True
         L.update({58: 1, 59: -1})
         picks = [L.fetch_unlabelled(4)]
@@ -108,95 +103,36 @@ def _dup_worker(rank, world, port, X, out):
         picks.append(L.fetch_unlabelled(3))
         out[rank] = (picks, mvn_stream.GLOBAL.draws, int(L.gp.status.item()))
     finally:
-        if world > 1:
-            dist.destroy_process_group()
+        _ranks.leave(group)
 
 
-def test_duplicate_rows_on_different_shards_fall_back_on_every_rank():
-    """A batch that contains a sample and its exact copy makes the conditional covariance singular: only the rank that
-    scores the copy notices, but the fall-back to the general scorer (and its collectives) must be taken by all ranks.
-    The status word travels in the selection record; picks and stream position equal the single-rank run's."""
-    if not torch.cuda.is_available():
-        pytest.skip("no GPU")
-    rng = np.random.default_rng(9)
-    X = rng.random((60, 5))
-    X[30:58] = X[0:28]     # every sample of rank 0's shard but two has an exact copy on rank 1: whatever is picked first,
-                           # its copy is scored against it from the third greedy step on
-    res = {}
-    for world in (1, 2):
-        port = _free_port()
-        with mp.Manager() as mgr:
-            out = mgr.dict()
-            mp.spawn(_dup_worker, args=(world, port, X, out), nprocs=world, join=True)
-            res[world] = dict(out)
-    assert res[2][0][0] == res[2][1][0] == res[1][0][0]
-    assert res[2][0][1] == res[2][1][1] == res[1][0][1]
-    assert res[2][0][2] == 0 and res[2][1][2] == 0      # the fall-back bits were cleared on both ranks
-
-
-def _nccl_worker(rank, world, port, name, out):
-    os.environ["MASTER_ADDR"] = "127.0.0.1"
-    os.environ["MASTER_PORT"] = str(port)
-    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-    os.environ["ITAL_FORCE_COLLECTIVES"] = "1"
-    torch.cuda.set_device(0)
-    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", 0))
-    try:
-        from ital_amd import ITAL, MCMI_min, mvn_stream
-        from ital_amd.baselines import EMOC, EntropySampling
-        z = np.load(os.path.join(HERE, "golden", name + ".npz"))
-        spec = FIXTURES[name]
-        cls = {"ITAL": ITAL, "MCMI_min": MCMI_min, "EMOC": EMOC, "EntropySampling": EntropySampling}[spec["learner"]]
-        np.random.seed(0)
-        mvn_stream.GLOBAL.reset()
-        L = cls(z["X"], length_scale=float(z["length_scale"]), device="cuda:0", rank=rank, world=world,
-                group=dist.group.WORLD, **spec["kw"])
-        assert L.gp.collective
-        L.update({int(z["query"]): 1})
-        rel = z["rel"]
-        picks = []
-        for r in range(int(z["rounds"])):
-            ret = L.fetch_unlabelled(int(z["k"]))
-            picks.append(ret)
-            L.update({int(i): float(rel[i]) for i in ret})
-        out[rank] = (picks, np.asarray(L.rel_mean).copy())
-    finally:
-        dist.destroy_process_group()
+def duplicate_rows_case():
+    X = duplicate_rows_case()
+    one = _ranks.spawn(_dup_worker, 1, X, None)[0]
+    two = _ranks.spawn(_dup_worker, 2, X, "gloo")
+    assert two[0][0] == two[1][0] == one[0]
+    assert two[0][1] == two[1][1] == one[1]
+    assert two[0][2] == 0 and two[1][2] == 0      # the fall-back bits were cleared on both ranks
 
 
 @pytest.mark.parametrize("name", ["usps500", "synth300_mcmi"])
 def test_rccl_code_path_on_a_one_rank_group(name):
     """The collectives of the sharded path (record all-gather, row all-reduce, vector all-gather) through RCCL itself --
-    on a one-rank "nccl" process group, which is all a one-GPU box can host."""
+    on a one-rank "nccl" process group, which is all a one-GPU box can host (several devices: test_gpu_multidevice.py)."""
     if not torch.cuda.is_available():
         pytest.skip("no GPU")
-    z = np.load(os.path.join(HERE, "golden", name + ".npz"))
-    port = _free_port()
-    with mp.Manager() as mgr:
-        out = mgr.dict()
-        mp.spawn(_nccl_worker, args=(1, port, name, out), nprocs=1, join=True)
-        r0 = out[0]
-    assert r0[0] == [z[f"r{r}_ret"].tolist() for r in range(int(z["rounds"]))]
-    np.testing.assert_allclose(r0[1], z["final_rel_mean"], rtol=0, atol=1e-9)
+    res = _ranks.spawn(_worker, 1, name, "rccl1")
+    check_golden(name, res)
+    if name == "usps500":
+        assert res[0][5] == "nccl"           # the rounds ran as single calls with ncclAllGather issued from C
 
 
-def _round_worker(rank, world, port, backend, round_call, X, k, rounds, out):
-    os.environ["MASTER_ADDR"] = "127.0.0.1"
-    os.environ["MASTER_PORT"] = str(port)
-    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-    group = None
-    if backend is not None:
-        torch.cuda.set_device(0)
-        if backend == "nccl":
-            os.environ["ITAL_FORCE_COLLECTIVES"] = "1"
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", 0))
-        else:
-            dist.init_process_group(backend, rank=rank, world_size=world)
-        group = dist.group.WORLD
+def _round_worker(rank, world, port, mode, round_call, X, k, rounds, out):
+    dev, group = _ranks.join(rank, world, port, mode)
     try:
         from ital_amd import ITAL, mvn_stream
         mvn_stream.GLOBAL.reset()
-        L = ITAL(X, length_scale=float(np.sqrt(X.shape[1] / 12.0)), device="cuda:0", rank=rank, world=world, group=group)
+        L = ITAL(X, length_scale=float(np.sqrt(X.shape[1] / 12.0)), device=dev, rank=rank, world=world, group=group)
         L.round_call = round_call
         L.update({0: 1, len(X) - 1: -1})
         picks, how, scores = [], [], []
@@ -212,16 +148,37 @@ def _round_worker(rank, world, port, backend, round_call, X, k, rounds, out):
         out[rank] = (picks, how, scores, (L.gp.row0, L.gp.row1), transport and transport[0], mvn_stream.GLOBAL.draws,
                      np.asarray(L.rel_mean).copy())
     finally:
-        if backend is not None:
-            dist.destroy_process_group()
+        _ranks.leave(group)
 
 
-def _run_round_workers(world, backend, round_call, X, k, rounds):
-    port = _free_port()
-    with mp.Manager() as mgr:
-        out = mgr.dict()
-        mp.spawn(_round_worker, args=(world, port, backend, round_call, X, k, rounds, out), nprocs=world, join=True)
-        return dict(out)
+def _run_round_workers(world, mode, round_call, X, k, rounds):
+    return dict(enumerate(_ranks.spawn(_round_worker, world, mode, round_call, X, k, rounds)))
+
+
+def check_rounds_against_one_rank(one, ranks_round, ranks_steps, k, rounds, transport):
+    """`ranks_round` / `ranks_steps`: the sharded run through ital_fetch_round / step by step (dicts rank -> result of
+    _round_worker); `one`: the one-rank run.  Picks, stream position, means, score vectors."""
+    world = len(ranks_round)
+    for res in (ranks_round, ranks_steps):
+        assert all(res[r][0] == one[0] for r in range(world))
+        assert all(res[r][5] == one[5] for r in range(world))
+        np.testing.assert_allclose(res[0][6], one[6], rtol=0, atol=1e-12)
+    for rank in range(world):
+        assert ranks_round[rank][4] == transport
+        # how the candidate list reached the device: uploaded once, then compacted there (speculative descriptor: slot flips)
+        assert [h[0] for h in ranks_round[rank][1]] == [1] + [2] * (rounds - 1)
+        assert all(h is None for h in ranks_steps[rank][1])
+        for a, b_ in zip(ranks_round[rank][2], ranks_steps[rank][2]):
+            live = a != 0                 # (members picked earlier in the round: zero here, the stale score there)
+            assert live.sum() >= len(a) - k
+            np.testing.assert_array_equal(a[live], b_[: len(a)][live])
+    # the shares' score vectors are the one-rank vector cut at the share boundaries (last round; dead entries excepted)
+    lo_hi = [ranks_round[r][3] for r in range(world)]
+    assert all(lo_hi[r][1] == lo_hi[r + 1][0] for r in range(world - 1))
+    for t in range(k):
+        whole = np.concatenate([ranks_round[r][2][t] for r in range(world)])
+        assert whole.shape == one[2][t].shape
+        np.testing.assert_allclose(whole, one[2][t], rtol=1e-12, atol=0)
 
 
 @pytest.mark.parametrize("n,d,k", [(700, 16, 4), (90, 6, 5)])
@@ -239,26 +196,7 @@ def test_round_as_one_call_on_two_ranks(n, d, k):
     one = _run_round_workers(1, None, True, X, k, rounds)[0]
     two_round = _run_round_workers(2, "gloo", True, X, k, rounds)
     two_steps = _run_round_workers(2, "gloo", False, X, k, rounds)
-    for res in (two_round, two_steps):
-        assert res[0][0] == res[1][0] == one[0]
-        assert res[0][5] == res[1][5] == one[5]
-        np.testing.assert_allclose(res[0][6], one[6], rtol=0, atol=1e-12)
-    for rank in (0, 1):
-        assert two_round[rank][4] == "host"
-        # how the candidate list reached the device: uploaded once, then compacted there (speculative descriptor: slot flips)
-        assert [h[0] for h in two_round[rank][1]] == [1] + [2] * (rounds - 1)
-        assert all(h is None for h in two_steps[rank][1])
-        for a, b_ in zip(two_round[rank][2], two_steps[rank][2]):
-            live = a != 0                 # (members picked earlier in the round: zero here, the stale score there)
-            assert live.sum() >= len(a) - k
-            np.testing.assert_array_equal(a[live], b_[: len(a)][live])
-    # the shares' score vectors are the one-rank vector cut at the share boundary (last round; dead entries excepted)
-    lo_hi = [two_round[r][3] for r in (0, 1)]
-    assert lo_hi[0][1] == lo_hi[1][0]
-    for t in range(k):
-        both = np.concatenate([two_round[0][2][t], two_round[1][2][t]])
-        assert both.shape == one[2][t].shape
-        np.testing.assert_allclose(both, one[2][t], rtol=1e-12, atol=0)
+    check_rounds_against_one_rank(one, two_round, two_steps, k, rounds, "host")
 
 
 def test_round_as_one_call_through_rccl():
@@ -268,7 +206,7 @@ def test_round_as_one_call_through_rccl():
         pytest.skip("no GPU")
     X = np.random.default_rng(78).random((600, 12))
     one = _run_round_workers(1, None, True, X, 4, 4)[0]
-    res = _run_round_workers(1, "nccl", True, X, 4, 4)[0]
+    res = _run_round_workers(1, "rccl1", True, X, 4, 4)[0]
     assert res[4] == "nccl"
     assert [h[0] for h in res[1]] == [1, 2, 2, 2]
     assert res[0] == one[0] and res[5] == one[5]

@@ -6,7 +6,6 @@ candidates (the other ranks' standard normals are skipped, not computed: ital_np
 
 Reference path under test: ital/ital.py:124-130 (Pool.map over candidates -> row shards), :293-297 (pattern sampling)."""
 import os
-import socket
 import sys
 import time
 
@@ -16,20 +15,11 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 torch = pytest.importorskip("torch")
-import torch.distributed as dist  # noqa: E402
-import torch.multiprocessing as mp  # noqa: E402
-
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 sys.path.insert(0, ROOT)
-
-
-def _free_port():
-    s = socket.socket()
-    s.bind(("127.0.0.1", 0))
-    p = s.getsockname()[1]
-    s.close()
-    return p
+sys.path.insert(0, HERE)
+import _ranks  # noqa: E402
 
 
 def _rows(row0, row1, d, seed, block=65536):
@@ -49,12 +39,8 @@ def _label(i):
     return 1.0 if (i * 2654435761) % (1 << 32) < (1 << 31) else -1.0
 
 
-def _worker(rank, world, port, cfg, out):
-    os.environ["MASTER_ADDR"] = "127.0.0.1"
-    os.environ["MASTER_PORT"] = str(port)
-    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-    if world > 1:
-        dist.init_process_group("gloo", rank=rank, world_size=world)
+def _worker(rank, world, port, cfg, mode, out):
+    dev, group = _ranks.join(rank, world, port, mode)
     try:
         from ital_amd import ITAL, mvn_stream, sharding
         n, d, k, rounds = cfg["n"], cfg["d"], cfg["k"], cfg["rounds"]
@@ -62,8 +48,7 @@ def _worker(rank, world, port, cfg, out):
         data = sharding.ShardedRows(_rows(row0, row1, d, seed=11), n, row0)
         np.random.seed(7)
         mvn_stream.GLOBAL.reset()
-        L = ITAL(data, length_scale=float(np.sqrt(d / 12.0)), device="cuda:0", rank=rank, world=world,
-                 group=dist.group.WORLD if world > 1 else None, **cfg["kw"])
+        L = ITAL(data, length_scale=float(np.sqrt(d / 12.0)), device=dev, rank=rank, world=world, group=group, **cfg["kw"])
         L.keep_scores = True
         L.update({3: 1, n - 5: -1})                 # one labelled sample on each shard
         sample = np.random.default_rng(5).choice(n, 400, replace=False)
@@ -84,30 +69,26 @@ def _worker(rank, world, port, cfg, out):
             L.update({int(i): _label(int(i)) for i in ret})
         out[rank] = dict(picks=picks, scores=scores, draws=mvn_stream.GLOBAL.draws, state=tuple(mvn_stream.GLOBAL.state),
                          secs=secs, mc_walk=list(L.mc_walk), np_tail=np.random.random_sample(3).tolist(),
-                         rows=(row0, row1))
+                         rows=(row0, row1), transport=(L._round_transport() or (None,))[0] if world > 1 else None)
     finally:
-        if world > 1:
-            dist.destroy_process_group()
+        _ranks.leave(group)
 
 
-def _run(world, cfg):
-    port = _free_port()
-    with mp.Manager() as mgr:
-        out = mgr.dict()
-        mp.spawn(_worker, args=(world, port, cfg, out), nprocs=world, join=True)
-        return [out[r] for r in range(world)]
+def _run(world, cfg, mode="gloo"):
+    return _ranks.spawn(_worker, world, cfg, mode if world > 1 else None)
 
 
-def _compare(one, two, n):
-    a, (b0, b1) = one[0], two
-    assert b0["picks"] == a["picks"] and b1["picks"] == a["picks"]            # same batches on every rank as on one
-    for r in (b0, b1):
+def _compare(one, many, n):
+    """`many`: the results of the ranks of a sharded run; `one`: the one-rank run of the same session."""
+    a, world = one[0], len(many)
+    for r in many:
+        assert r["picks"] == a["picks"]                                       # same batches on every rank as on one
         assert r["draws"] == a["draws"] and r["state"] == a["state"]          # the replayed mvndst stream stands where it would
         assert r["np_tail"] == a["np_tail"]                                   # numpy's global generator too
-    assert b0["rows"] == (0, n // 2) and b1["rows"] == (n // 2, n)
+    assert [r["rows"] for r in many] == [(n * w // world, n * (w + 1) // world) for w in range(world)]
     checked = 0
     for rnd, ref in enumerate(a["scores"]):
-        for part in (b0["scores"][rnd], b1["scores"][rnd]):
+        for part in (r["scores"][rnd] for r in many):
             for idx, vals in part.items():
                 if idx in ref:
                     np.testing.assert_allclose(vals, ref[idx], rtol=1e-12, atol=0)    # MI does not depend on the sharding

@@ -105,7 +105,7 @@ def _run_fixture(dev, golden_dir, name, rounds=None, mi_atol=1e-10, force_generi
 
 
 @pytest.mark.parametrize("name", ["usps500", "butterflies", "synth300", "synth96_k6", "usps2007",
-                                  "synth200_optimistic", "synth200_topcand"])
+                                  "synth200_optimistic", "synth200_topcand", "synth200_topcand_float"])
 def test_golden_fixture(dev, golden_dir, name):
     L, z = _run_fixture(dev, golden_dir, name)
     assert L.top_results(10).tolist() == z["top_results_10"].tolist()

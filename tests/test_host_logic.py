@@ -380,3 +380,38 @@ def test_all_upper_form_of_the_lattice_sums_is_an_identity_and_keeps_the_referen
     assert np.all(w / 2.0 ** -53 == np.round(w / 2.0 ** -53))            # on the grid of doubles below 1
     big = rng.uniform(0.5, 1.0, 1000)
     assert np.array_equal(1.0 - (1.0 - big), big)
+
+
+def test_unseen_list_equals_the_rebuilt_array_under_random_removals():
+    """retrieval_base.UnseenList (base + removed ids, O(k log N) per round) against the list rebuilt from scratch as the
+    reference does on every call (retrieval_base.py:78-87): length, positions of row boundaries, the entries of a row
+    range, the materialised array -- through removals, failed removals and a rebase."""
+    from ital_amd.retrieval_base import UnseenList
+    rng = np.random.default_rng(3)
+    n = 5000
+    seen0 = rng.choice(n, 40, replace=False)
+    want = np.setdiff1d(np.arange(n), seen0)
+    u = UnseenList(want.copy())
+    u.REBASE_AT = 64
+    version = 0
+    for step in range(60):
+        ids = rng.choice(want, int(rng.integers(1, 9)), replace=False)
+        if step % 7 == 3:
+            assert not u.remove(list(ids) + [int(seen0[0])])          # one id is not on the list: nothing changes
+            assert not u.remove([n + 5]) and u.version == version
+        assert u.remove(ids.tolist())
+        version += 1
+        want = np.setdiff1d(want, ids)
+        assert u.version == version and u.last_removed == tuple(sorted(int(i) for i in ids))
+        assert not u.remove([int(ids[0])])                           # already taken out
+        assert len(u) == len(want)
+        for x in (0, 1, int(want[7]), int(ids[0]), int(ids[0]) + 1, n // 2, n - 1, n, n + 10):
+            assert u.count_below(x) == int(np.searchsorted(want, x))
+        r0, r1 = sorted(int(v) for v in rng.integers(0, n + 1, 2))
+        np.testing.assert_array_equal(u.in_rows(r0, r1), want[(want >= r0) & (want < r1)])
+        if step % 3 == 0:
+            arr = u.array()
+            np.testing.assert_array_equal(arr, want)
+            assert u.array() is arr                                  # the same object until the next removal
+    assert len(u.removed) < 64 + 9                                   # materialising rebased the list on the way
+    np.testing.assert_array_equal(u.array(), want)

@@ -41,7 +41,7 @@ def replay(golden_dir, name, rounds=None):
 
 
 @pytest.mark.parametrize("name,rounds", [("usps500", 1), ("synth200_noisy", 1), ("synth200_motivated", 1),
-                                         ("synth200_optimistic", 1), ("synth200_topcand", 2), ("iris_ce5", 1),
+                                         ("synth200_optimistic", 1), ("synth200_topcand", 2), ("synth200_topcand_float", 3), ("iris_ce5", 1),
                                          ("usps500_mcmi", 2), ("synth300_mcmi", 2), ("synth80_mcrel", 1),
                                          ("synth60_mcfb", 2), ("synth50_mcboth", 1), ("synth50_clip", 2)])
 def test_oracle_reproduces_reference(golden_dir, name, rounds):

@@ -70,7 +70,10 @@ def make_case(seed0, case):
     elif kind == "optimistic":
         kw = dict(label_estimation=str(rng.choice(["optimistic", "pessimistic"])))
     elif kind == "topcand":
-        kw = dict(top_candidates=int(rng.integers(3, 12)))
+        # an absolute number, or a multiple of the number of labelled samples (float: reference ital.py:111-114, the shipped
+        # *-topscoring.conf) -- large enough for k candidates with a single labelled sample
+        kw = dict(top_candidates=int(rng.integers(3, 12))) if case % 2 == 0 else \
+            dict(top_candidates=float(rng.uniform(k + 0.5, k + 8.0)))
     elif kind == "mix":
         kw = dict(label_prob=float(rng.uniform(0.4, 0.9)), mistake_prob=float(rng.uniform(0.0, 0.3)),
                   change_estimation_subset=int(rng.integers(1, 4)), monte_carlo_num_fb=int(rng.integers(1, 3)))
