@@ -429,6 +429,55 @@ def k8_workload(device, n=25000, d=512, k=8):
     return res
 
 
+def k16_workload(device, n=1_000_000, d=512, k=16, mc=1):
+    """BASELINE.json configs[4] / SURVEY.md 8d C5' in one piece on ONE GPU: 1 000 000 x 512, batches of 16,
+    monte_carlo_num_rel = 1 (2^16 sign patterns are infeasible anywhere: the reference's own switch, ital.py:293-297) -- one
+    fetch + update round, with the roofline of its lattice sums (the general scorer's pipeline, 3 .. 16 variables)."""
+    import torch
+    from ital_amd import ITAL, mvn_stream
+    X = block_rows(0, n, d, seed=1)
+    mvn_stream.GLOBAL.reset()
+    np.random.seed(0)
+    L = ITAL(X, length_scale=float(np.sqrt(d / 12.0)), monte_carlo_num_rel=mc, device=device)
+    L.pair_counter = torch.zeros(1, dtype=torch.int64, device=device)
+    L.update({0: 1})
+    L.profile = []
+    L.event_pool = [torch.cuda.Event(enable_timing=True) for _ in range(8 * k)]
+    for ev in L.event_pool:
+        ev.record()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    ret = L.fetch_unlabelled(k)
+    t1 = time.perf_counter()
+    L.update({int(i): (1.0 if (int(i) * 2654435761) % (1 << 32) < (1 << 31) else -1.0) for i in ret})
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    scored = sum(n - 1 - t for t in range(k))
+    steps = {t: e0.elapsed_time(e1) * 1e-3 for name, t, c, e0, e1 in L.profile if name == "score_generic"}
+    sec = sum(v for t, v in steps.items() if t >= 3)
+    pairs = float(L.pair_counter.item())
+    ach = pairs * FLOP_PER_PAIR / sec / 1e12 if sec > 0 else 0.0
+    made, skipped, walk_s = L.mc_walk
+    res = {"ms_per_round": dt * 1e3, "fetch_s": t1 - t0, "candidates_per_s": scored / dt,
+           "config": "synthetic %d x %d, k=%d, perfect user, monte_carlo_num_rel=%d (BASELINE.json configs[4], SURVEY 8d C5'), "
+                     "one GPU" % (n, d, k, mc),
+           "step_ms": {"t%d" % t: v * 1e3 for t, v in sorted(steps.items())},
+           "pattern_sampling": {"standard_normals_computed": made, "skipped": skipped, "host_s": walk_s,
+                                "note": "numpy's legacy generator walked in the reference's order (ital_np_legacy_normals), under "
+                                        "the scorer of the step before"},
+           "peak_device_memory_gib": torch.cuda.max_memory_allocated(device) / 2 ** 30,
+           "roofline": {"bound": "fp64-valu", "kernel": "gen_main_kernel<3..16> (lattice sums of ital_score_generic)", "achieved": ach,
+                        "peak": FP64_VALU_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach / FP64_VALU_PEAK_TFLOPS,
+                        "pairs_counted_on_device": pairs, "seconds_steps_3_to_16": sec, "traffic": None,
+                        "note": "pairs = lattice points x (n - 1) of the calls that are integrated, counted by the kernels; time = "
+                                "the ital_score_generic steps of 3 .. 16 variables whole (preparation, lattice sums, combine, the "
+                                "host's pattern uploads between the ranges of a step)"}}
+    del L, X
+    gc.collect()
+    torch.cuda.empty_cache()
+    return res
+
+
 def cpu_baseline(X, cores):
     """The oracle (CPU restatement of the reference, oracle/) in the reference's parallel mode on a bounded sample."""
     from oracle.ital import OracleITAL
@@ -572,6 +621,8 @@ def main():
     ap.add_argument("--batch", type=int, default=4, help="batch size k (experiments)")
     ap.add_argument("--label-prob", type=float, default=1.0, help="user model (experiments; != 1 selects the general scorer)")
     ap.add_argument("--mistake-prob", type=float, default=0.0)
+    ap.add_argument("--extra", default="", help="comma list of opt-in workloads (N = 1): c4 = 50 000 x 2048, k = 8 (BASELINE "
+                    "configs[3], ~5 s); c5k16 = 1 000 000 x 512, k = 16, monte_carlo_num_rel = 1 (configs[4] whole, ~2.5 min)")
     ap.add_argument("--force-collectives", action="store_true",
                     help="one rank, but through the exchange path of N > 1 (1-rank RCCL group): prices the per-step collective")
     args = ap.parse_args()
@@ -782,6 +833,14 @@ def main():
             out["ms_per_round_strong_1M"] = scale["ms_per_round"]
         if world == 1 and not os.environ.get("ITAL_BENCH_NO_EXTRAS"):
             out["other_workloads"] = other_workloads(X, rel, device)
+        extra = [e for e in args.extra.split(",") if e]
+        if world == 1 and extra:
+            ow = out.setdefault("other_workloads", {})
+            if "c4" in extra:
+                ow["ital_k8_50000x2048"] = dict(k8_workload(device, 50000, 2048, 8), config="synthetic 50000 x 2048, k=8, perfect user, "
+                                                "full 2^t enumeration (BASELINE.json configs[3], SURVEY 8d C4'), one GPU")
+            if "c5k16" in extra:
+                ow["ital_k16_mc1_1Mx512"] = k16_workload(device)
         out["cpu_baseline"] = cpu_base
         if cpu_base:
             out["speedup_vs_cpu_baseline"] = out["value"] / cpu_base["value"]

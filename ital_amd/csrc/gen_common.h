@@ -87,6 +87,13 @@
 #define ITAL_GEN_EARLY 1   // decide saturated calls from the standardised limits, before COVSRT
 #endif
 
+#ifndef ITAL_GEN_FN
+// the larger helpers (COVSRT, the group layout, the saturation test): out of line by default -- the single kernel calls them
+// from several places; gen_pipeline.hip, whose kernels call each of them once, inlines them (an out-of-line callee saves
+// registers on a stack: scratch memory)
+#define ITAL_GEN_FN static __device__
+#endif
+
 namespace ital {
 
 constexpr int GN = ITAL_GENERIC_MAX_DIM;  // largest orthant dimension
@@ -104,7 +111,7 @@ struct GArgs {
 };
 
 // ------------------------------------------------------------------------------------------------ COVSRT, runtime n
-static __device__ void rcswp_n(int n, int p, int q, double* cov, double* lim, unsigned& infi) {
+ITAL_GEN_FN void rcswp_n(int n, int p, int q, double* cov, double* lim, unsigned& infi) {
     double tmp = lim[p]; lim[p] = lim[q]; lim[q] = tmp;
     unsigned bp = (infi >> p) & 1u, bq = (infi >> q) & 1u;
     infi = (infi & ~((1u << p) | (1u << q))) | (bq << p) | (bp << q);
@@ -114,9 +121,10 @@ static __device__ void rcswp_n(int n, int p, int q, double* cov, double* lim, un
     for (int i = q + 1; i < n; i++) { tmp = cov[pidx(i, p)]; cov[pidx(i, p)] = cov[pidx(i, q)]; cov[pidx(i, q)] = tmp; }
 }
 
-static __device__ bool covsrt_n(int n, double* cov, double* lim, double* y, unsigned& infi) {
+// (the limit types travel by value -- in, and the re-ordered ones out: a reference into the caller's registers would
+// force them into scratch memory across this out-of-line call)
+ITAL_GEN_FN unsigned covsrt_n(int n, double* cov, double* lim, double* y, unsigned infi) {
     const double SQTWPI = 2.506628274631001, EPS = 1e-10;
-    bool ok = true;
     for (int i = 0; i < n; i++) {
         double dmin = 0, emin = 1, zmin = 0, cvdiag = 0;
         int jmin = i;
@@ -184,13 +192,13 @@ static __device__ bool covsrt_n(int n, double* cov, double* lim, double* y, unsi
             y[i] = 0;
         }
     }
-    return ok;
+    return infi;
 }
 
 // After COVSRT: which rows close a group of MVNDFN (a row whose successor has a positive diagonal, or the last row),
 // and the factor re-packed so that column (closing row of group g) carries the coefficient of group g -- the
 // evaluator can then index its y registers by row.  Bit i of the result = row i closes a group.
-static __device__ unsigned group_layout(int n, double* cov) {
+ITAL_GEN_FN unsigned group_layout(int n, double* cov) {
     unsigned closes = 0;
     int ik = 0;                    // groups closed before the current row
     unsigned long long crow0 = 0, crow1 = 0;   // closing row of each group, 5 bits each (12 groups per word)
@@ -236,7 +244,7 @@ __device__ __forceinline__ int pow3(int n) {
 enum { K_SKIP = 4 };
 
 // Call `call` of candidate position p.  cpp = calls per pattern (npre prior calls + nfb feedback configurations).
-static __device__ CallInfo decode_call(const ital_gscore_desc& d, int64_t p, int call, int cpp, int npre, int nr, int npat) {
+ITAL_GEN_FN CallInfo decode_call(const ital_gscore_desc& d, int64_t p, int call, int cpp, int npre, int nr, int npat) {
     CallInfo c;
     const bool subset = d.subset_mode != 0;
     const int pi = call / cpp, s = call - pi * cpp;
@@ -305,7 +313,7 @@ struct Prep {
 // |lim_a| > 37 + 9 sqrt(n - 1): one variable on the empty side makes every lattice point contribute exactly 0, all
 // variables on the full side make every point contribute exactly 1 -- the values the full path returns.
 // Returns 4 (== 0), 2 (== 1) or 0 (undecided).
-static __device__ int early_decision(int n, const double* lim, unsigned infi) {
+ITAL_GEN_FN int early_decision(int n, const double* lim, unsigned infi) {
     const double thr = 37.0 + 9.0 * sqrt((double)(n - 1));
     bool all_full = true, any_empty = false;
     for (int a = 0; a < n; a++) {
@@ -319,19 +327,13 @@ static __device__ int early_decision(int n, const double* lim, unsigned infi) {
 
 // Standardised problem (limits lim, packed correlations cov with unit diagonal, n >= 2) -> closed form (n = 2) or the
 // COVSRT-ed slab with its saturation verdict.
-static __device__ void finish_call(int n, double* cov, double* lim, double* y, Prep& out) {
-    if (n == 2) {
-        out.value = bvn_orthant(lim[0], lim[1], out.infi & 1u, (out.infi >> 1) & 1u, cov[pidx(1, 0)]);
-        out.flags = 1;
-        return;
-    }
-    covsrt_n(n, cov, lim, y, out.infi);
-    out.closes = group_layout(n, cov);
+// Integrand identically 1 / 0 after COVSRT?  Every conditional limit stays beyond +-37 for any |y| <= 9.  Returns 2 / 4 / 0.
+ITAL_GEN_FN int saturation_n(int n, const double* cov, const double* lim, unsigned infi) {
     bool sat1 = true, sat0 = false;
     for (int i = 0; i < n; i++) {
         double bound = 0;
         for (int j = 0; j < i; j++) bound += fabs(cov[pidx(i, j)]) * 9.0;
-        const bool lower = (out.infi >> i) & 1u;
+        const bool lower = (infi >> i) & 1u;
         if (lower) {
             if (!(lim[i] + bound < -37.0)) sat1 = false;
             if (lim[i] - bound > 37.0) sat0 = true;
@@ -340,8 +342,19 @@ static __device__ void finish_call(int n, double* cov, double* lim, double* y, P
             if (lim[i] + bound < -37.0) sat0 = true;
         }
     }
-    if (sat0) out.flags = 4;
-    else if (sat1) out.flags = 2;
+    return sat0 ? 4 : (sat1 ? 2 : 0);
+}
+
+__device__ __forceinline__ void finish_call(int n, double* cov, double* lim, double* y, Prep& out) {
+    if (n == 2) {
+        out.value = bvn_orthant(lim[0], lim[1], out.infi & 1u, (out.infi >> 1) & 1u, cov[pidx(1, 0)]);
+        out.flags = 1;
+        return;
+    }
+    out.infi = covsrt_n(n, cov, lim, y, out.infi);
+    out.closes = group_layout(n, cov);
+    const int sat = saturation_n(n, cov, lim, out.infi);
+    if (sat) out.flags = sat;
 }
 
 // clip_cov (reference ital/ital.py:386-429, :590-616): connected components of |corr| > clip over the n variables, in
@@ -413,7 +426,7 @@ static __device__ ITAL_GEN_NOINLINE Prep build_group(int g, const double* mlim, 
 
 // Prepares one call in the lane's slab: cov (packed, n(n+1)/2), lim (n), y (n); scratch fs for the update.
 template <bool CLIP>
-static __device__ ITAL_GEN_NOINLINE Prep prepare_call(const ital_gscore_desc& d, const CallInfo& ci, int nU, int nr, int ldS, const double* muU,
+static __device__ ITAL_GEN_NOINLINE Prep prepare_call(const ital_gscore_desc& d, const CallInfo ci, int nU, int nr, int ldS, const double* muU,
                              const double* SigU, const int* usort, const int* ipos, bool clamp_prior, double* slab,
                              double* fs, double* master) {
     Prep out;
@@ -679,6 +692,81 @@ static __device__ double qmc_eval(int n, const double* __restrict__ slab, unsign
         }
 #pragma unroll
         for (int c = 0; c < NC; c++) acc += dead[c] ? 0.0 : ff[c];
+    }
+    return wave_sum(acc) / (16.0 * prime);
+}
+
+// The same pass with the conditioned values of the chains in LDS (yl: [2][GN - 1][64] doubles of wave-private memory) and
+// plain loops over the runtime dimension: one lattice item per lane and round (a point and its antithetic partner), the
+// same operations in the same order as qmc_eval<NMAX, 1>.  For the rare calls with linearly dependent variables
+// (gen_pipeline.hip): no unrolled copies of the stage for 20 dimensions, no register arrays that end up in scratch memory.
+static __device__ double qmc_eval_lds(int n, const double* __restrict__ slab, unsigned infi, unsigned closes,
+                                      const double* __restrict__ lat, int lane, double* __restrict__ tailq, double* __restrict__ yl) {
+    const int ndim = n - 1;
+    const int prime = P_TAB[(ndim < 10 ? ndim : 10) - 1];
+    const double* cf = slab;
+    const double* lm = slab + n * (n + 1) / 2;
+    const int items = 8 * prime;
+    double* y0 = yl + lane;
+    double* y1 = yl + (GN - 1) * 64 + lane;
+    double acc = 0.0;
+    for (int base = 0; base < items; base += 64) {
+        const int item = base + lane;
+        const bool ok = item < items;
+        const int it = ok ? item : 0;
+        const int sft = it / prime;
+        const int kk = it - sft * prime + 1;
+        const int so = sft * ndim;
+        double ff[2] = {1.0, 1.0}, ai[2] = {0.0, 0.0}, bi[2] = {0.0, 0.0};
+        bool dead[2] = {!ok, !ok};
+        bool infa = false, infb = false;   // wave-uniform: the open group has a lower / an upper limit (MVNDFN)
+        int ik = 0;                        // groups closed so far = lattice coordinate of the open group
+        for (int i = 0; i < n; i++) {
+            const bool lower = (infi >> i) & 1u;
+            const bool close = (closes >> i) & 1u;
+            const bool last = i == n - 1;
+            double sc0 = 0, sc1 = 0;
+            for (int j = 0; j < i; j++) {
+                const double c = cf[pidx(i, j)];
+                sc0 = fma(c, y0[j * 64], sc0);
+                sc1 = fma(c, y1[j * 64], sc1);
+            }
+            const double z0 = lm[i] - sc0, z1 = lm[i] - sc1;
+            if (lower) { ai[0] = infa ? fmax(ai[0], z0) : z0; ai[1] = infa ? fmax(ai[1], z1) : z1; infa = true; }
+            else { bi[0] = infb ? fmin(bi[0], z0) : z0; bi[1] = infb ? fmin(bi[1], z1) : z1; infb = true; }
+            if (close) {
+                double xh = 0;
+                if (!last) {
+                    const double v = kk * lat[so + ik] + lat[8 * ndim + so + ik];
+                    const double fr = v - floor(v);
+                    xh = fabs(2 * fr - 1);
+                }
+                double pin[2];
+#pragma unroll
+                for (int c = 0; c < 2; c++) {
+                    const double dd = infa ? mvn_phi(ai[c]) : 0.0;
+                    const double ee = infb ? mvn_phi(bi[c]) : 1.0;
+                    const double w = ee - dd;
+                    dead[c] = dead[c] || !(w > 0);
+                    ff[c] *= w;
+                    const double x = (c & 1) ? 1 - xh : xh;
+                    pin[c] = fma(x, w, dd);
+                }
+                if (!last) {
+                    double outv[2];
+                    phinv_wave<2>(pin, outv, tailq, lane);
+                    y0[i * 64] = outv[0];
+                    y1[i * 64] = outv[1];
+                }
+                infa = false; infb = false;
+                ik++;
+            } else if (!last) {
+                y0[i * 64] = 0.0;
+                y1[i * 64] = 0.0;
+            }
+        }
+        acc += dead[0] ? 0.0 : ff[0];
+        acc += dead[1] ? 0.0 : ff[1];
     }
     return wave_sum(acc) / (16.0 * prime);
 }

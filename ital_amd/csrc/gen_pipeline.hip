@@ -25,8 +25,10 @@
 //   Calls per candidate are few there (2 t c) and the lattice sums of 6 .. 15 dimensions dwarf the preparation.
 //
 // Record of a call to integrate (doubles): meta word, id (candidate of the slab * calls + call), packed factor with
-// diagonal (n (n+1) / 2) and limits (n) as the evaluators read them, then the call's 8 shifted lattices packed as in
-// score.hip: 8 (n-1) shifts as MVNUNI's 32-bit integers, 8 (n-1) permuted generators as byte indices.
+// diagonal (n (n+1) / 2) and limits (n) as the evaluators read them, then the call's 8 shifted lattices packed: 8 (n-1) shifts
+// as MVNUNI's 32-bit integers, the 8 permuted generator vectors as 4-bit indices (a 64-bit word per shift).
+// the kernels of this unit call each of the larger helpers once: inlined (an out-of-line callee saves registers on a stack)
+#define ITAL_GEN_FN __device__ __forceinline__
 #include "gen_common.h"
 #include "qmc_exact.h"
 
@@ -71,15 +73,16 @@ __device__ __forceinline__ MrgState mrg_jump(const ital_gscore_desc& d, MrgState
     return st;
 }
 
-// The 8 lattices of a call of dimension n from generator state `sti`, packed into `out` (5 (n-1) doubles): the shifts as
-// MVNUNI's integers, the generator vector after DKSMRC's accumulated random transpositions as indices into vk[n][.].
+// The 8 lattices of a call of dimension n from generator state `sti`, packed into `out` (4 (n-1) + 8 doubles): the shifts as
+// MVNUNI's 32-bit integers, the generator vector after DKSMRC's accumulated random transpositions as 4-bit indices into
+// vk[n][.], one 64-bit word per shift.
 // gen: n - 1 doubles of scratch (LDS: indexed at run time).
 static __device__ ITAL_GEN_NOINLINE void make_lattice_packed(MrgState sti, int n, double* gen, double* __restrict__ out) {
     MrgStateF st = mrg_to_f(sti);
     const int ndim = n - 1;
     for (int j = 0; j < ndim; j++) gen[j] = (double)j;
     unsigned int* shifts = reinterpret_cast<unsigned int*>(out);
-    unsigned char* perm = reinterpret_cast<unsigned char*>(out + 4 * ndim);
+    unsigned long long* perm = reinterpret_cast<unsigned long long*>(out + 4 * ndim);
     for (int sft = 0; sft < 8; sft++) {
         for (int j = 1; j <= ndim - 1; j++) {
             const double u = mrg_next_f(st);
@@ -88,7 +91,9 @@ static __device__ ITAL_GEN_NOINLINE void make_lattice_packed(MrgState sti, int n
             gen[j - 1] = gen[jp - 1];
             gen[jp - 1] = xt;
         }
-        for (int j = 0; j < ndim; j++) perm[sft * ndim + j] = (unsigned char)gen[j];
+        unsigned long long w = 0;                      // ndim <= 15 indices below 16: four bits each
+        for (int j = 0; j < ndim; j++) w |= (unsigned long long)(unsigned int)gen[j] << (4 * j);
+        perm[sft] = w;
         for (int j = 0; j < ndim; j++) shifts[sft * ndim + j] = (unsigned int)mrg_next_z(st);
     }
 }
@@ -334,8 +339,8 @@ __global__ __launch_bounds__(256) void gen_build_kernel(ital_gscore_desc d, GPip
     const unsigned int e = g.chunk_lo + r;
     const bool mine = r < g.cap && e < nU;
     bool integrate = false, regular = false;
-    Prep pp;
-    pp.n = T; pp.infi = 0; pp.flags = 0; pp.value = 0; pp.closes = 0; pp.ng = 0; pp.gdraws = 0;
+    unsigned infi = 0, closes = 0;      // limit types (bit a: variable at position a bounded below), rows that close a group
+    int flags = 0;                      // 2 / 4: the integrand is identically 1 / 0
     double* slab = lds_all + (size_t)threadIdx.x * STRIDE;
     unsigned int id = 0;
     int64_t i = 0;
@@ -382,7 +387,7 @@ __global__ __launch_bounds__(256) void gen_build_kernel(ital_gscore_desc d, GPip
         for (int u = 0; u < T; u++) {
             sd[u] = sqrt(cv[u * (u + 1) / 2 + u]);
             lim[at[u]] = -mean[u] / sd[u];
-            pp.infi |= ((relU >> u) & 1u) << at[u];
+            infi |= ((relU >> u) & 1u) << at[u];
             cov[pidx(at[u], at[u])] = 1.0;
         }
 #pragma unroll
@@ -393,11 +398,14 @@ __global__ __launch_bounds__(256) void gen_build_kernel(ital_gscore_desc d, GPip
                 // (y[a] * y[b] of prepare_call: the standard deviations in the call's order, larger position first)
                 cov[pidx(a, b)] = cv[u * (u + 1) / 2 + v] / (at[u] > at[v] ? sd[u] * sd[v] : sd[v] * sd[u]);
             }
-        int verdict = ITAL_GEN_EARLY ? early_decision(T, lim, pp.infi) : 0;
-        if (verdict) pp.flags = verdict;
-        else finish_call(T, cov, lim, y, pp);
-        integrate = !(pp.flags & 6);
-        regular = integrate && pp.closes == (1u << T) - 1u;
+        flags = ITAL_GEN_EARLY ? early_decision(T, lim, infi) : 0;
+        if (!flags) {
+            infi = covsrt_n(T, cov, lim, y, infi);
+            closes = group_layout(T, cov);
+            flags = saturation_n(T, cov, lim, infi);
+        }
+        integrate = !(flags & 6);
+        regular = integrate && closes == (1u << T) - 1u;
     }
     const unsigned long long em = __ballot(regular), cm = __ballot(integrate && !regular);
     unsigned int lbase = 0, cbase = 0;
@@ -410,18 +418,18 @@ __global__ __launch_bounds__(256) void gen_build_kernel(ital_gscore_desc d, GPip
     if (integrate) {
         double* rec = g.recs + (size_t)r * g.R;
         const uint64_t before = (uint64_t)meta[1];
-        rec[0] = __longlong_as_double(pack_meta(pp.flags, T, pp.infi, pp.closes));
+        rec[0] = __longlong_as_double(pack_meta(flags, T, infi, closes));
         rec[1] = (double)id;
-        write_slab(T, slab, (regular && ITAL_QMC_FLIP) ? pp.infi : 0u, rec + 2);
+        write_slab(T, slab, (regular && ITAL_QMC_FLIP) ? infi : 0u, rec + 2);
         const int* sp = g.cstate + i * 6;
         MrgState st = {sp[0], sp[1], sp[2], sp[3], sp[4], sp[5]};
         make_lattice_packed(mrg_jump(d, st, before), T, slab, rec + g.lat);        // the slab is free now
         if (regular) g.list[lbase + (unsigned int)__popcll(em & ((1ull << lane) - 1ull))] = r;
         else g.list[g.cap - 1u - cbase - (unsigned int)__popcll(cm & ((1ull << lane) - 1ull))] = r;
-        meta[0] = __longlong_as_double(pack_meta(pp.flags, T, pp.infi, pp.closes));
+        meta[0] = __longlong_as_double(pack_meta(flags, T, infi, closes));
     } else {
-        meta[0] = __longlong_as_double(pack_meta(pp.flags, T, pp.infi, pp.closes));
-        meta[1] = (pp.flags & 2) ? 1.0 : 0.0;
+        meta[0] = __longlong_as_double(pack_meta(flags, T, infi, closes));
+        meta[1] = (flags & 2) ? 1.0 : 0.0;
     }
 }
 
@@ -552,10 +560,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(ITAL_GEN_MA
     const int lane = threadIdx.x & 63;
     const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int lds_lat = g.lat - 2;                                   // slab (factor, limits), then the unpacked lattices
+    // (T == 0: one wave per workgroup, which also holds the chains' conditioned values in LDS: qmc_eval_lds)
     double* rec = lds_all + (size_t)wid * (lds_lat + 16 * (g.n - 1) + ITAL_GEN_TAILQ);
     double* tailq = rec + lds_lat + 16 * (g.n - 1);
     const unsigned int count = g.count[T > 0 ? 0 : 1];
-    const unsigned int nwaves = gridDim.x * 4;
+    const unsigned int nwaves = gridDim.x * (blockDim.x >> 6);
     unsigned long long pairs = 0;
     auto integrate = [&](unsigned int e) {
         const unsigned int r = g.list[T > 0 ? e : g.cap - 1u - e];
@@ -571,10 +580,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(ITAL_GEN_MA
         for (int q = lane; q < ns; q += 64) rec[q] = src[2 + q];
         {   // unpack the lattices: generator = vk[n][index], shift = integer * 1/(m1 + 1) exactly as MVNUNI forms it
             const unsigned int* shifts = reinterpret_cast<const unsigned int*>(src + g.lat);
-            const unsigned char* perm = reinterpret_cast<const unsigned char*>(src + g.lat + 4 * ndim);
+            const unsigned long long* perm = reinterpret_cast<const unsigned long long*>(src + g.lat + 4 * ndim);
             for (int q = lane; q < 8 * ndim; q += 64) {
-                rec[lds_lat + q] = vk[n * GN + perm[q]];
-                rec[lds_lat + 8 * ndim + q] = (double)shifts[q] * MRG_INVMP1 + (((fl >> (q % ndim)) & 1u) ? 0.5 : 0.0);
+                const int sft = q / ndim, j = q - sft * ndim;
+                rec[lds_lat + q] = vk[n * GN + (int)((perm[sft] >> (4 * j)) & 15ull)];
+                rec[lds_lat + 8 * ndim + q] = (double)shifts[q] * MRG_INVMP1 + (((fl >> j) & 1u) ? 0.5 : 0.0);
             }
         }
         constexpr bool FL = T > 0 && ITAL_QMC_FLIP != 0;
@@ -595,7 +605,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(ITAL_GEN_MA
             constexpr int TF = T > 0 && T < 7 ? T : 3;
             value = qmc_eval_fixed_inl<TF, ITAL_GEN_FIXED_NH(TF), FL>(rec, infi, rec + lds_lat, lane, tailq);
         }
-        else value = qmc_eval<ITAL_GENERIC_MAX_DIM, 1>(n, rec, infi, (unsigned)((m >> 40) & 0xffffffu), rec + lds_lat, lane, tailq);
+        else value = qmc_eval_lds(n, rec, infi, (unsigned)((m >> 40) & 0xffffffu), rec + lds_lat, lane, tailq, tailq + ITAL_GEN_TAILQ);
         if (lane == 0) {
             g.meta[(size_t)id * 2 + 1] = value;
             // label_estimation 'optimistic' / 'pessimistic' compare terms for exact equality: a sum this close to 0 or 1 is
@@ -616,7 +626,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(ITAL_GEN_MA
         constexpr int ND = T > 1 ? T - 1 : 1;
         pairs = (blockIdx.x == 0 && wid == 0) ? (unsigned long long)count * (16ull * P_TAB[(ND < 10 ? ND : 10) - 1] * ND) : 0ull;
     } else {
-        for (unsigned int e = blockIdx.x * 4 + wid; e < count; e += nwaves) integrate(e);
+        for (unsigned int e = blockIdx.x * (blockDim.x >> 6) + wid; e < count; e += nwaves) integrate(e);
     }
     if (lane == 0 && pair_count && pairs) atomicAdd(pair_count, pairs);
 }
@@ -654,9 +664,10 @@ __global__ __launch_bounds__(64) void gen_exact_kernel(GPipe g, const double* __
     for (int q = lane; q < n; q += 64) slab[ncov + q] = ((fl >> q) & 1u) ? -src[2 + ncov + q] : src[2 + ncov + q];
     {
         const unsigned int* shifts = reinterpret_cast<const unsigned int*>(src + g.lat);
-        const unsigned char* perm = reinterpret_cast<const unsigned char*>(src + g.lat + 4 * ndim);
+        const unsigned long long* perm = reinterpret_cast<const unsigned long long*>(src + g.lat + 4 * ndim);
         for (int q = lane; q < 8 * ndim; q += 64) {
-            lat[q] = vk[n * GN + perm[q]];
+            const int sft = q / ndim, j = q - sft * ndim;
+            lat[q] = vk[n * GN + (int)((perm[sft] >> (4 * j)) & 15ull)];
             lat[8 * ndim + q] = (double)shifts[q] * MRG_INVMP1;
         }
     }
@@ -784,7 +795,7 @@ PipePlan pipe_plan(const ital_gscore_desc* d) {
     pl.npat = (int)npat; pl.cpp = 1 + (int)nfb;
     pl.total = (int64_t)pl.npat * pl.cpp;
     pl.lat = 2 + n * (n + 1) / 2 + n;
-    pl.R = pl.lat + 5 * (n - 1);
+    pl.R = pl.lat + 4 * (n - 1) + 8;
     if (pl.fast) {
         pl.per_cand = 3 + pl.total * 2 + (pl.total + 1) / 2;
         pl.chunk_max = (int64_t)1 << 20;
@@ -819,6 +830,7 @@ int ital_gen_pipeline(const ital_gscore_desc* d, hipStream_t stream) {
     GPipe g = {};
     g.total = (int)pl.total; g.npat = pl.npat; g.cpp = pl.cpp; g.n = n; g.R = pl.R; g.lat = pl.lat;
     const size_t lds_m = (size_t)4 * (pl.lat - 2 + 16 * (n - 1) + ITAL_GEN_TAILQ) * sizeof(double);
+    const size_t lds_m0 = (size_t)(pl.lat - 2 + 16 * (n - 1) + ITAL_GEN_TAILQ + 2 * (GN - 1) * 64) * sizeof(double);   // one wave
     // label_estimation 'optimistic' / 'pessimistic' (plain mode only): sums that decide an exact comparison are formed again in
     // the reference's order
     const int exact = (d->label_mode != 0 && d->fb_mode != 3 && n <= GEN_EXACT_MAX) ? 1 : 0;
@@ -835,7 +847,7 @@ int ital_gen_pipeline(const ital_gscore_desc* d, hipStream_t stream) {
         ITAL_GEN_MAIN(10) ITAL_GEN_MAIN(11) ITAL_GEN_MAIN(12) ITAL_GEN_MAIN(13) ITAL_GEN_MAIN(14) ITAL_GEN_MAIN(15)            \
         ITAL_GEN_MAIN(16)                                                                                                     \
     }                                                                                                                         \
-    ITAL_LAUNCH(gen_main_kernel<0>, dim3(64), dim3(256), lds_m, ps->main, g, d->vk, d->pair_count, exact);                       \
+    ITAL_LAUNCH(gen_main_kernel<0>, dim3(256), dim3(64), lds_m0, ps->main, g, d->vk, d->pair_count, exact);                      \
     if (exact) ITAL_LAUNCH(gen_exact_kernel, dim3(g.cap), dim3(64), lds_x, ps->main, g, d->vk, g.cap)
 
     if (pl.fast) {

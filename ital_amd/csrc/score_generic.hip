@@ -27,10 +27,12 @@
 namespace ital {
 
 #ifndef ITAL_GEN_WAVES
-#define ITAL_GEN_WAVES(TFIX) ((TFIX) > 0 ? 3 : 2)   // measured: compile-time-dimension evaluator 3 waves per SIMD, runtime one 2 (spills)
+#define ITAL_GEN_WAVES 2   // waves per SIMD the single kernel aims at (the runtime-dimension evaluator spills at three)
 #endif
-template <int NMAX, int NH, int TFIX, bool CLIP>
-__global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(ITAL_GEN_WAVES(TFIX), ITAL_GEN_WAVES(TFIX)))) void score_generic_kernel(GArgs a) {
+// (Until round 3 this kernel also had instantiations with a compile-time evaluator for plain mode with 3 .. 6 variables;
+// that case is gen_pipeline.hip's -- without a workspace it runs here on the runtime-dimension evaluator.)
+template <int NMAX, int NH, bool CLIP>
+__global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(ITAL_GEN_WAVES, ITAL_GEN_WAVES))) void score_generic_kernel(GArgs a) {
     extern __shared__ double lds_all[];
     const ital_gscore_desc& d = a.d;
     const int lane = threadIdx.x & 63;
@@ -203,10 +205,7 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(ITAL_GEN_WA
                 value = (fl_c & 2) ? 1.0 : 0.0;
             } else {
                 const double* slab_c = slabs + (size_t)cl * a.stride;
-                if (TFIX > 0 && n_c == TFIX && closes_c == (1u << (TFIX > 0 ? TFIX : 1)) - 1u)
-                    value = qmc_eval_fixed<(TFIX > 0 ? TFIX : 3)>(slab_c, infi_c, slab_c + a.lat, lane, tailq);
-                else
-                    value = qmc_eval<NMAX, NH>(n_c, slab_c, infi_c, closes_c, slab_c + a.lat, lane, tailq);
+                value = qmc_eval<NMAX, NH>(n_c, slab_c, infi_c, closes_c, slab_c + a.lat, lane, tailq);
                 pairs += 16ull * P_TAB[(n_c - 1 < 10 ? n_c - 1 : 10) - 1] * (n_c - 1);
             }
             const CallInfo ci = decode_call(d, p, chunk0 + cl, cpp, npre, nr, npat);
@@ -303,36 +302,27 @@ extern "C" int ital_score_generic(const ital_gscore_desc* d, hipStream_t stream)
     const size_t lds = (size_t)2 * a.wave_doubles * sizeof(double);
     if (lds > 160 * 1024) return ital_fail(-12, "ital_score_generic: LDS budget exceeded");
     const int64_t blocks = (d->n_cand + 1) / 2;
-    // plain mode (no subset): every call of dimension >= 3 has dimension n_picks + 1 -> compile-time evaluator
-    const int tfix = (!d->subset_mode && nUmax >= 3 && nUmax <= 6) ? nUmax : 0;
     // ---- plain mode with a compile-time evaluator: the pipeline of kernels (gen_pipeline.hip)
     if (ITAL_GEN_PIPELINE && !clip && !d->draw_count) {
         const int rc = ital_gen_pipeline(d, stream);
         if (rc <= 0) return rc;
     }
-#define ITAL_GEN_LAUNCH(NMAX_, NH_, TFIX_, CLIP_)                                                                             \
+#define ITAL_GEN_LAUNCH(NMAX_, NH_, CLIP_)                                                                             \
     do {                                                                                                               \
         static ItalLdsFlags lds_flags;                                                                                 \
-        if (const int rc = ital_raise_lds_limit(reinterpret_cast<const void*>(&score_generic_kernel<NMAX_, NH_, TFIX_, CLIP_>), \
+        if (const int rc = ital_raise_lds_limit(reinterpret_cast<const void*>(&score_generic_kernel<NMAX_, NH_, CLIP_>), \
                                                 160 * 1024, lds_flags, "ital_score_generic"))                          \
             return rc;                                                                                                 \
-        ITAL_LAUNCH((score_generic_kernel<NMAX_, NH_, TFIX_, CLIP_>), dim3((unsigned)blocks), dim3(128), lds, stream, a); \
+        ITAL_LAUNCH((score_generic_kernel<NMAX_, NH_, CLIP_>), dim3((unsigned)blocks), dim3(128), lds, stream, a); \
     } while (0)
     if (clip) {     // grouped probabilities: the instantiations that carry the group passes
-        if (nUmax <= 6) ITAL_GEN_LAUNCH(6, 2, 0, true);
-        else if (nUmax <= 12) ITAL_GEN_LAUNCH(12, ITAL_GEN_NH12, 0, true);
-        else ITAL_GEN_LAUNCH(ITAL_GENERIC_MAX_DIM, 1, 0, true);
+        if (nUmax <= 6) ITAL_GEN_LAUNCH(6, 2, true);
+        else if (nUmax <= 12) ITAL_GEN_LAUNCH(12, ITAL_GEN_NH12, true);
+        else ITAL_GEN_LAUNCH(ITAL_GENERIC_MAX_DIM, 1, true);
     } else {
-        switch (tfix) {
-            case 3: ITAL_GEN_LAUNCH(6, 2, 3, false); break;
-            case 4: ITAL_GEN_LAUNCH(6, 2, 4, false); break;
-            case 5: ITAL_GEN_LAUNCH(6, 2, 5, false); break;
-            case 6: ITAL_GEN_LAUNCH(6, 2, 6, false); break;
-            default:
-                if (nUmax <= 6) ITAL_GEN_LAUNCH(6, 2, 0, false);
-                else if (nUmax <= 12) ITAL_GEN_LAUNCH(12, ITAL_GEN_NH12, 0, false);
-                else ITAL_GEN_LAUNCH(ITAL_GENERIC_MAX_DIM, 1, 0, false);
-        }
+        if (nUmax <= 6) ITAL_GEN_LAUNCH(6, 2, false);
+        else if (nUmax <= 12) ITAL_GEN_LAUNCH(12, ITAL_GEN_NH12, false);
+        else ITAL_GEN_LAUNCH(ITAL_GENERIC_MAX_DIM, 1, false);
     }
 #undef ITAL_GEN_LAUNCH
     return ital_check_launch("ital_score_generic");

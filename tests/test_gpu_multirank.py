@@ -249,6 +249,11 @@ def test_record_exchange_below_the_c_abi_through_rccl():
                                             torch.cuda.current_stream().cuda_stream))
         torch.cuda.synchronize()
         assert torch.equal(out[0], rec)
+        # what RCCL says about the communicator (sharding.raw_comm compares it with the process group's numbering)
+        w, r = ctypes.c_int(-1), ctypes.c_int(-1)
+        how = ctypes.create_string_buffer(600)
+        _lib.check(lib.ital_exchange_info(comm, ctypes.byref(w), ctypes.byref(r), how, 600))
+        assert (w.value, r.value) == (1, 0) and b"librccl" in how.value
         assert rccl_objects() == before and len(before) == 1      # still the one RCCL the communicator came from
         assert lib.ital_select_exchange(rec.data_ptr(), out.data_ptr(), rec_len, None,
                                         torch.cuda.current_stream().cuda_stream) != 0     # no communicator: refused

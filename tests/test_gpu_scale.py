@@ -216,12 +216,12 @@ def test_c5_one_million_x512_k4_full_enumeration(dev):
     print("C5': fetch_unlabelled(4) on 1000000 x 512: %.2f s, %d oracle evaluations" % (dt, ntask))
 
 
-def test_c5_share_125000x512_k16_monte_carlo(dev):
-    """BASELINE configs[4] as one of 8 ranks sees it: 125 000 x 512, batch of 16, monte_carlo_num_rel = 1 (2^16 patterns
-    are infeasible anywhere): the general scorer up to orthant dimension 16, patterns sampled on numpy's generator in the
-    reference's order.  Oracle checks at steps 1, 2, 3, 5, 8, 12, 16."""
+def _monte_carlo_k16_case(dev, n, checked, label):
+    """BASELINE configs[4]'s switch: n x 512, batch of 16, monte_carlo_num_rel = 1 (2^16 patterns are infeasible anywhere):
+    the general scorer up to orthant dimension 16, patterns sampled on numpy's generator in the reference's order.  Oracle
+    checks at the steps of `checked` (step -> candidates)."""
     from ital_amd import ITAL, mvn_stream
-    n, d, k, mc = 125_000, 512, 16, 1
+    d, k, mc = 512, 16, 1
     rng = np.random.default_rng(7)
     X = rng.random((n, d))
     ls = float(np.sqrt(d / 12.0))
@@ -260,7 +260,6 @@ def test_c5_share_125000x512_k16_monte_carlo(dev):
         s = scores[t]
         assert np.all(np.isfinite(s[live]))
         assert pick_pos[t] == int(np.flatnonzero(live)[np.argmax(s[live])])
-    checked = {1: 48, 2: 48, 3: 32, 5: 24, 8: 16, 12: 8, 16: 8}
     samples = _sample_positions(np.random.default_rng(8), n_cand, pick_pos, k, lambda t: checked.get(t, 0))
     samples = {t: ps for t, ps in samples.items() if t in checked}
     # The reference maps its normals through an SVD of the candidate's covariance, and LAPACK's sign of a singular vector
@@ -271,6 +270,21 @@ def test_c5_share_125000x512_k16_monte_carlo(dev):
     ntask, bad = _check_against_sub_oracle(X, ls, L, picks, cand0, scores, samples, dict(monte_carlo_num_rel=mc), stream0,
                                            draws, seed=11, normals_per_cand=normals, workers=8,
                                            patterns=[np.asarray(a) for a in L.last_patterns], allow_resampled=0.05)
-    print("C5' share: fetch_unlabelled(16) on 125000 x 512, monte_carlo_num_rel=1: %.1f s, %d oracle evaluations "
-          "(all equal for the device's patterns), %d candidates re-sampled differently by the oracle's LAPACK"
-          % (dt, ntask, len(bad)))
+    made, skipped, walk_s = L.mc_walk
+    print("%s: fetch_unlabelled(16) on %d x 512, monte_carlo_num_rel=1: %.1f s (%.0f scored candidates/s), %d oracle evaluations "
+          "(all equal for the device's patterns), %d candidates re-sampled differently by the oracle's LAPACK; pattern sampling: "
+          "%.3g standard normals computed, %.3g skipped, %.1f s of host time (under the scorer); peak device memory %.1f GiB"
+          % (label, n, dt, k * n / dt, ntask, len(bad), made, skipped, walk_s, torch.cuda.max_memory_allocated() / 2 ** 30))
+    return dt
+
+
+def test_c5_share_125000x512_k16_monte_carlo(dev):
+    """BASELINE configs[4] as one of 8 ranks sees it: 125 000 x 512.  Oracle checks at steps 1, 2, 3, 5, 8, 12, 16."""
+    _monte_carlo_k16_case(dev, 125_000, {1: 48, 2: 48, 3: 32, 5: 24, 8: 16, 12: 8, 16: 8}, "C5' share")
+
+
+@pytest.mark.skipif(not os.environ.get("ITAL_TEST_C5_FULL"), reason="2.5 minutes of GPU: set ITAL_TEST_C5_FULL=1 (log: profiles/r4_c5_full.log)")
+def test_c5_whole_one_million_x512_k16_monte_carlo(dev):
+    """BASELINE configs[4] in one piece on ONE GPU: 1 000 000 x 512, k = 16, monte_carlo_num_rel = 1 -- the N = 1 anchor of
+    the k = 16 curve (8 GPUs take an eighth each).  Oracle checks at steps 1, 4, 8, 16."""
+    _monte_carlo_k16_case(dev, 1_000_000, {1: 24, 4: 16, 8: 8, 16: 6}, "C5' whole")
