@@ -3,8 +3,15 @@
  * candidate selection.  Plain pointers and sizes only: every pointer is a *borrowed device pointer*
  * (the caller owns the memory, e.g. through torch tensors), every call is asynchronous on the given
  * HIP stream, returns 0 or a negative errno-style code (message: ital_last_error()).  No allocation
- * crosses the ABI, nothing synchronises the device, so a whole fetch_unlabelled(k) round can be
+ * crosses the ABI (workspaces are the caller's), nothing synchronises the device, so a whole fetch_unlabelled(k) round can be
  * enqueued (or graph-captured) without host round trips.
+ *
+ * Threading: ONE caller thread per process, as the reference's learners (module-global state, ital/ital.py:619-621).  The
+ * library keeps a little process-wide state without locks -- the last error message, the launch counter
+ * (ital_launch_count: instrumentation), the RCCL entry points ital_select_exchange / ital_exchange_info resolve on first
+ * use, the internal streams / scratch of ital_score_generic and ital_fetch_round per device.  A few small device
+ * allocations of that kind are made by the library itself on first use (per device, never freed; a graph capture must
+ * therefore follow one uncaptured call).
  *
  * The reference (cvjena/ITAL) is pure Python and has no FFI; each entry point below replaces the native
  * numerical routine the reference reaches at the cited place.  INTEGRATION.md shows the ctypes binding

@@ -257,12 +257,17 @@ __global__ __launch_bounds__(256) void gen_seed_kernel(GSeed s) {
     sp[0] = rng.x10; sp[1] = rng.x11; sp[2] = rng.x12; sp[3] = rng.x20; sp[4] = rng.x21; sp[5] = rng.x22;
 }
 
-// Thread per (candidate, call): is the call's orthant probability decided by its standardised limits alone?  grid =
-// (candidates of the slab, groups of 256 calls); with sampled feedback (all-zero samples make no call and draw nothing: the
-// stream offset of a call depends on the samples before it) one workgroup walks all groups of its candidate.
+// Thread per (candidate, call): is the call's orthant probability decided by its standardised limits alone?  One workgroup
+// per candidate walks its calls in groups of blockDim.x (the host picks the width that wastes the fewest lanes); the
+// undecided ones are collected in LDS and appended to list U with ONE atomic per candidate (a wave-level append -- 190 000
+// atomics on one address per noisy-user step -- took 1.9 ms of this kernel's 2.2).  With sampled feedback all-zero samples
+// make no call and draw nothing: the stream offset of a call is the number of calls made before it, counted along the walk.
 template <int T>
 __global__ __launch_bounds__(256) void gen_verdict_kernel(ital_gscore_desc d, GPipe g) {
-    __shared__ unsigned int s_wave[4];
+    constexpr int STAGE = 2048;                           // undecided ids collected before a flush (>= 8 groups)
+    __shared__ unsigned int s_ids[STAGE];
+    __shared__ unsigned int s_made[4], s_und[4];
+    __shared__ unsigned int s_base;
     const int64_t i = blockIdx.x;
     const int64_t p = g.slab_lo + i;
     if (!d.alive[p]) return;
@@ -272,12 +277,18 @@ __global__ __launch_bounds__(256) void gen_verdict_kernel(ital_gscore_desc d, GP
     int ipos[T];
 #pragma unroll
     for (int v = 0; v < T; v++) ipos[v] = v < d.n_picks ? d.pick_pos[v] : d.nE;
-    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, nwave = blockDim.x >> 6;
     constexpr unsigned DRAWS = 8 * (2 * (T - 1) - 1);     // uniforms of every call that is made (integrated or not)
-    const bool walk = d.mc_fb > 0;
     double* meta = g.meta + (size_t)i * g.total * 2;
-    unsigned int made_before = 0;                         // walk: calls made in the groups before this one
-    for (int c0 = walk ? 0 : (int)blockIdx.y * 256; c0 < g.total; c0 += 256) {
+    unsigned int made_before = 0, staged = 0;             // calls made / undecided ids staged so far (the same in every thread)
+    auto flush = [&]() {                                  // (all threads)
+        if (threadIdx.x == 0) s_base = atomicAdd(g.countU, staged);
+        __syncthreads();
+        for (unsigned int j = threadIdx.x; j < staged; j += blockDim.x) g.listU[s_base + j] = s_ids[j];
+        __syncthreads();
+        staged = 0;
+    };
+    for (int c0 = 0; c0 < g.total; c0 += (int)blockDim.x) {
         const int call = c0 + (int)threadIdx.x;
         const bool mine = call < g.total;
         int flags = 16;
@@ -304,26 +315,28 @@ __global__ __launch_bounds__(256) void gen_verdict_kernel(ital_gscore_desc d, GP
         const bool made = mine && !(flags & 16);
         const bool undecided = mine && flags == 0;
         const unsigned long long mm = __ballot(made), um = __ballot(undecided);
-        unsigned int rank_made = (unsigned int)call;      // calls made before this one (no sampled feedback: all of them)
-        if (walk) {
-            if (lane == 0) s_wave[wid] = (unsigned int)__popcll(mm);
-            __syncthreads();
-            rank_made = made_before + (unsigned int)__popcll(mm & ((1ull << lane) - 1ull));
-            for (int w = 0; w < wid; w++) rank_made += s_wave[w];
-            made_before += s_wave[0] + s_wave[1] + s_wave[2] + s_wave[3];
-            __syncthreads();
+        if (lane == 0) { s_made[wid] = (unsigned int)__popcll(mm); s_und[wid] = (unsigned int)__popcll(um); }
+        __syncthreads();
+        unsigned int rank_made = made_before + (unsigned int)__popcll(mm & ((1ull << lane) - 1ull));
+        unsigned int slot = staged + (unsigned int)__popcll(um & ((1ull << lane) - 1ull));
+        unsigned int made_all = 0, und_all = 0;
+        for (int w = 0; w < nwave; w++) {
+            if (w < wid) { rank_made += s_made[w]; slot += s_und[w]; }
+            made_all += s_made[w];
+            und_all += s_und[w];
         }
-        unsigned int ubase = 0;
-        if (lane == 0 && um) ubase = atomicAdd(g.countU, (unsigned int)__popcll(um));
-        ubase = (unsigned int)__builtin_amdgcn_readfirstlane((int)ubase);
         if (mine) {
             meta[2 * call] = __longlong_as_double(pack_meta(flags, T, 0, 0));
             // decided: the value; undecided: where the call's uniforms start in the candidate's stretch of the stream
             meta[2 * call + 1] = undecided ? (double)((uint64_t)rank_made * DRAWS) : ((flags & 2) ? 1.0 : 0.0);
-            if (undecided) g.listU[ubase + (unsigned int)__popcll(um & ((1ull << lane) - 1ull))] = (unsigned int)(i * g.total + call);
+            if (undecided) s_ids[slot] = (unsigned int)(i * g.total + call);
         }
-        if (!walk) break;
+        made_before += made_all;
+        staged += und_all;
+        __syncthreads();
+        if (staged + blockDim.x > (unsigned int)STAGE) flush();
     }
+    if (staged) flush();
 }
 
 // Thread per undecided call: the standardised problem after the simulated update (registers), COVSRT in the thread's LDS
@@ -407,12 +420,20 @@ __global__ __launch_bounds__(256) void gen_build_kernel(ital_gscore_desc d, GPip
         integrate = !(flags & 6);
         regular = integrate && closes == (1u << T) - 1u;
     }
+    // list slots: one atomic per workgroup and list end (regular calls from the front, the others from the back)
+    __shared__ unsigned int s_reg[4], s_dep[4], s_lbase, s_cbase;
+    const int wid = threadIdx.x >> 6;
     const unsigned long long em = __ballot(regular), cm = __ballot(integrate && !regular);
-    unsigned int lbase = 0, cbase = 0;
-    if (lane == 0 && em) lbase = atomicAdd(g.count, (unsigned int)__popcll(em));
-    if (lane == 0 && cm) cbase = atomicAdd(g.count + 1, (unsigned int)__popcll(cm));
-    lbase = (unsigned int)__builtin_amdgcn_readfirstlane((int)lbase);
-    cbase = (unsigned int)__builtin_amdgcn_readfirstlane((int)cbase);
+    if (lane == 0) { s_reg[wid] = (unsigned int)__popcll(em); s_dep[wid] = (unsigned int)__popcll(cm); }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const unsigned int nr_ = s_reg[0] + s_reg[1] + s_reg[2] + s_reg[3], nd_ = s_dep[0] + s_dep[1] + s_dep[2] + s_dep[3];
+        s_lbase = nr_ ? atomicAdd(g.count, nr_) : 0u;
+        s_cbase = nd_ ? atomicAdd(g.count + 1, nd_) : 0u;
+    }
+    __syncthreads();
+    unsigned int lbase = s_lbase, cbase = s_cbase;
+    for (int w = 0; w < wid; w++) { lbase += s_reg[w]; cbase += s_dep[w]; }
     if (!mine) return;
     double* meta = g.meta + ((size_t)i * g.total + call) * 2;
     if (integrate) {
@@ -879,8 +900,16 @@ int ital_gen_pipeline(const ital_gscore_desc* d, hipStream_t stream) {
             (void)hipMemsetAsync(g.countU, 0, sizeof(unsigned int), ps->prep);
             GSeed sd = {*d, g.slab_lo, g.slab_n, g.cstate};
             ITAL_LAUNCH(gen_seed_kernel, dim3((unsigned)((g.slab_n + 255) / 256)), dim3(256), 0, ps->prep, sd);
-            const unsigned parts = d->mc_fb > 0 ? 1u : (unsigned)((pl.total + 255) / 256);
-            const dim3 vgrid((unsigned)g.slab_n, parts);
+            // workgroup width of the verdict kernel: the one that leaves the fewest lanes idle over a candidate's calls
+            unsigned vthreads = 256;
+            {
+                double best = 0;
+                for (unsigned w = 256; w >= 64; w -= 64) {
+                    const double eff = (double)pl.total / (double)(((pl.total + w - 1) / w) * w);
+                    if (eff > best + 1e-9) { best = eff; vthreads = w; }
+                }
+            }
+            const dim3 vgrid((unsigned)g.slab_n);
             const int stride_b = (n * (n + 1) / 2 + 2 * n) | 1;
             const size_t lds_b = (size_t)256 * stride_b * sizeof(double);
             if (lds_b > 48 * 1024) {       // six variables: 66 KB of per-thread slabs per workgroup
@@ -891,10 +920,10 @@ int ital_gen_pipeline(const ital_gscore_desc* d, hipStream_t stream) {
             }
             const int64_t nchunks = (g.slab_n * pl.total + ch - 1) / ch;
             switch (n) {
-                case 3: ITAL_LAUNCH(gen_verdict_kernel<3>, vgrid, dim3(256), 0, ps->prep, *d, g); break;
-                case 4: ITAL_LAUNCH(gen_verdict_kernel<4>, vgrid, dim3(256), 0, ps->prep, *d, g); break;
-                case 5: ITAL_LAUNCH(gen_verdict_kernel<5>, vgrid, dim3(256), 0, ps->prep, *d, g); break;
-                case 6: ITAL_LAUNCH(gen_verdict_kernel<6>, vgrid, dim3(256), 0, ps->prep, *d, g); break;
+                case 3: ITAL_LAUNCH(gen_verdict_kernel<3>, vgrid, dim3(vthreads), 0, ps->prep, *d, g); break;
+                case 4: ITAL_LAUNCH(gen_verdict_kernel<4>, vgrid, dim3(vthreads), 0, ps->prep, *d, g); break;
+                case 5: ITAL_LAUNCH(gen_verdict_kernel<5>, vgrid, dim3(vthreads), 0, ps->prep, *d, g); break;
+                case 6: ITAL_LAUNCH(gen_verdict_kernel<6>, vgrid, dim3(vthreads), 0, ps->prep, *d, g); break;
             }
             for (int64_t c = 0; c < nchunks; c++, nbuf++) {
                 const int buf = nbuf & 1;

@@ -552,8 +552,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(ITAL_QMC_WA
         pr = wave_sum(acc) / (16.0 * Q::PRIME);
         // label_estimation 'optimistic' / 'pessimistic' compare terms for exact equality: a sum this close to 0 or 1 is
         // formed again in the reference's own order (qmc_exact_kernel, right after this launch)
+#ifndef ITAL_NO_EXACT_FLAG      // (A/B switch: the flag costs nothing measurable, profiles/r4_exact_flag_ab.txt)
         if (label_mode != 0 && (pr > 1.0 - EXACT_BAND || pr < EXACT_BAND) && lane == 0)
             const_cast<double*>(rec)[Q::R_META] = __longlong_as_double(meta | META_EXACT);
+#endif
     }
     if (lane == 0) {
         const double pu = (meta & META_POST_ONE) ? 1.0 : 0.0;

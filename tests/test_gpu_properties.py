@@ -57,7 +57,8 @@ def test_scores_do_not_depend_on_the_workspace_slabs(dev, n, k):
             np.testing.assert_array_equal(a[live], b[live])
 
 
-@pytest.mark.parametrize("n,k,work_bytes", [(2500, 4, 1 << 30), (300, 6, 1 << 30), (3300, 4, 1 << 20), (33, 3, 1 << 30)])
+@pytest.mark.parametrize("n,k,work_bytes", [(2500, 4, 1 << 30), (300, 6, 1 << 30), (3300, 4, 1 << 20), (33, 3, 1 << 30),
+                                            (1500, 7, 1 << 19)])     # t = 7 in slabs of 8 candidates: more slabs than n / 32 + 64
 def test_selection_inside_the_scoring_launch_equals_the_separate_launch(dev, n, k, work_bytes):
     """One rank, small problems: the last block of a step's scoring launch selects (select_tail) instead of a launch of
     ital_select_fused.  Same picks, same batch state, same alive flags -- also with several slabs and with ties."""
@@ -334,6 +335,57 @@ def test_state_dict_resumes_a_session(dev):
     np.testing.assert_allclose(np.asarray(B.rel_mean), mean_a, rtol=0, atol=1e-12)
     with pytest.raises(ValueError):
         ITAL(X, length_scale=0.5, device=dev).load_state_dict(pickle.loads(blob))
+
+
+def test_state_dict_resumes_numpys_generator_too(dev):
+    """Options that draw from numpy's global legacy generator (here MCMI_min's subsample, np.random.choice as the reference,
+    mcmi.py:61-63): the saved session's generator state travels in the state_dict, the resumed session picks what the
+    uninterrupted one picks."""
+    import pickle
+    from ital_amd import MCMI_min
+    rng = np.random.default_rng(13)
+    X = rng.random((300, 6))
+    lab = lambda i: 1.0 if X[i, 0] > 0.5 else -1.0   # noqa: E731
+    np.random.seed(21)
+    A = MCMI_min(X, length_scale=0.7, subsample=60, device=dev)
+    A.update({4: 1, 7: -1})
+    r = A.fetch_unlabelled(3)
+    A.update({i: lab(i) for i in r})
+    blob = pickle.dumps(A.state_dict())
+    want = A.fetch_unlabelled(3)
+    np.random.seed(99)                                   # "another process": some other generator state
+    B = MCMI_min(X, length_scale=0.7, subsample=60, device=dev)
+    B.load_state_dict(pickle.loads(blob))
+    assert B.fetch_unlabelled(3) == want
+
+
+def test_unseen_bookkeeping_survives_sets_changed_behind_update(dev):
+    """relevant_ids / irrelevant_ids / unnameable_ids are public attributes as in the reference (which rebuilds the candidate
+    list from them on every call, retrieval_base.py:78-87): a set ASSIGNED anew, or ids moved between the sets, must show in
+    get_unseen() and in the next batch although update() was not involved."""
+    from ital_amd import ITAL, mvn_stream
+    rng = np.random.default_rng(14)
+    X = rng.random((200, 5))
+    mvn_stream.GLOBAL.reset()
+    L = ITAL(X, length_scale=0.6, device=dev)
+    L.update({3: 1, 9: -1})
+    first = L.fetch_unlabelled(3)
+    assert 50 in L.get_unseen()
+    L.unnameable_ids = {50, 51}                           # same-size replacement would not change the sizes check either
+    assert 50 not in L.get_unseen() and 51 not in L.get_unseen() and len(L.get_unseen()) == 196
+    L.unnameable_ids = {60, 61}
+    assert 50 in L.get_unseen() and 60 not in L.get_unseen() and len(L.get_unseen()) == 196
+    L.irrelevant_ids.add(70)                              # in-place change: the sizes differ
+    assert 70 not in L.get_unseen()
+    got = L.fetch_unlabelled(3)
+    assert not (set(got) & {3, 9, 60, 61, 70})
+    mvn_stream.GLOBAL.reset()
+    F = ITAL(X, length_scale=0.6, device=dev)
+    F.update({3: 1, 9: -1})
+    assert F.fetch_unlabelled(3) == first
+    F.unnameable_ids = {60, 61}
+    F.irrelevant_ids.add(70)
+    assert F.fetch_unlabelled(3) == got
 
 
 def test_fit_on_an_existing_learner_starts_over(dev):
