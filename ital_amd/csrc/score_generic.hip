@@ -47,7 +47,15 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(ITAL_GEN_WA
     int* usort = reinterpret_cast<int*>(SigU + ldS * ldS);
     int* ipos = usort + GN;
     double* tailq = SigU + ldS * ldS + (GN + GR + 1) / 2;
-    double* slabs = tailq + ITAL_GEN_TAILQ;
+    // more than 6 variables: the chains' conditioned values live in LDS (qmc_eval_lds: no 20-fold unrolled stage, no
+    // register arrays that end up in scratch memory)
+    constexpr int YL = NMAX > 6 ? 2 * (GN - 1) * 64 : 0;
+    double* yl = tailq + ITAL_GEN_TAILQ;
+    double* slabs = yl + YL;
+    auto lattice_sum = [&](int n_c, const double* slab_c, unsigned infi_c, unsigned closes_c) -> double {
+        if constexpr (NMAX > 6) return qmc_eval_lds(n_c, slab_c, infi_c, closes_c, slab_c + a.lat, lane, tailq, yl);
+        else return qmc_eval<NMAX, NH>(n_c, slab_c, infi_c, closes_c, slab_c + a.lat, lane, tailq);
+    };
 
     const int row = d.cand[p];
     const int64_t gi = d.row_offset + row;
@@ -174,7 +182,7 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(ITAL_GEN_WA
                         const unsigned infi_c = (unsigned)__builtin_amdgcn_readlane((int)gp.infi, cl);
                         const unsigned closes_c = (unsigned)__builtin_amdgcn_readlane((int)gp.closes, cl);
                         const double* slab_c = slabs + (size_t)cl * a.stride;
-                        const double v = qmc_eval<NMAX, NH>(n_c, slab_c, infi_c, closes_c, slab_c + a.lat, lane, tailq);
+                        const double v = lattice_sum(n_c, slab_c, infi_c, closes_c);
                         pairs += 16ull * P_TAB[(n_c - 1 < 10 ? n_c - 1 : 10) - 1] * (n_c - 1);
                         if (lane == cl) gval = v;
                     }
@@ -205,7 +213,7 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(ITAL_GEN_WA
                 value = (fl_c & 2) ? 1.0 : 0.0;
             } else {
                 const double* slab_c = slabs + (size_t)cl * a.stride;
-                value = qmc_eval<NMAX, NH>(n_c, slab_c, infi_c, closes_c, slab_c + a.lat, lane, tailq);
+                value = lattice_sum(n_c, slab_c, infi_c, closes_c);
                 pairs += 16ull * P_TAB[(n_c - 1 < 10 ? n_c - 1 : 10) - 1] * (n_c - 1);
             }
             const CallInfo ci = decode_call(d, p, chunk0 + cl, cpp, npre, nr, npat);
@@ -296,7 +304,7 @@ extern "C" int ital_score_generic(const ital_gscore_desc* d, hipStream_t stream)
     a.slab = slab;
     a.lat = slab + fs_doubles(nr);
     a.master = clip ? slab + fs_doubles(nr) + 16 * (nUmax - 1) : 0;
-    const int fixed = nUmax + nUmax * nUmax + (GN + GR + 1) / 2 + ITAL_GEN_TAILQ;
+    const int fixed = nUmax + nUmax * nUmax + (GN + GR + 1) / 2 + ITAL_GEN_TAILQ + (nUmax > 6 ? 2 * (GN - 1) * 64 : 0);
     a.ldS = nUmax;
     a.wave_doubles = fixed + chunk * stride;
     const size_t lds = (size_t)2 * a.wave_doubles * sizeof(double);
@@ -317,11 +325,11 @@ extern "C" int ital_score_generic(const ital_gscore_desc* d, hipStream_t stream)
     } while (0)
     if (clip) {     // grouped probabilities: the instantiations that carry the group passes
         if (nUmax <= 6) ITAL_GEN_LAUNCH(6, 2, true);
-        else if (nUmax <= 12) ITAL_GEN_LAUNCH(12, ITAL_GEN_NH12, true);
         else ITAL_GEN_LAUNCH(ITAL_GENERIC_MAX_DIM, 1, true);
     } else {
+        // up to 6 variables: two lattice items per lane and round, the chains' conditioned values in registers; beyond: one
+        // item, the values in LDS (one instantiation for 7 .. 20 variables: the loops run over the runtime dimension)
         if (nUmax <= 6) ITAL_GEN_LAUNCH(6, 2, false);
-        else if (nUmax <= 12) ITAL_GEN_LAUNCH(12, ITAL_GEN_NH12, false);
         else ITAL_GEN_LAUNCH(ITAL_GENERIC_MAX_DIM, 1, false);
     }
 #undef ITAL_GEN_LAUNCH
