@@ -231,11 +231,13 @@ def test_one_million_candidates(dev):
                                     (dict(monte_carlo_num_rel=1), 400, 9), (dict(label_estimation="pessimistic", mistake_prob=0.1), 150, 3),
                                     (dict(monte_carlo_num_rel=1), 250, 15)])    # 10-14 variables: three chains per lane
 def test_general_scorer_pipeline_equals_its_single_kernel(dev, kw, n, k):
-    """Plain mode of ital_score_generic: three kernels on internal streams (prepare / lattice sums / combine, slabs of the
-    workspace) against the one kernel that does everything per candidate -- same calls, same stream offsets, same order of
-    the terms.  The lattice sums run with more chains per lane in the pipeline (six up to 8 variables since round 3; the
-    single kernel keeps four / the runtime evaluator): last-bit differences, the lanes' partial sums are formed in another
-    order."""
+    """Plain mode of ital_score_generic: the pipeline of kernels on internal streams (gen_pipeline.hip: verdict / build /
+    lattice sums / combine up to 6 variables, prepare / lattice sums / combine beyond; slabs and chunks of the workspace)
+    against the one kernel that does everything per candidate -- same calls, same stream offsets, same order of the terms.
+    The lattice sums run with more chains per lane in the pipeline (the single kernel keeps the runtime evaluator):
+    last-bit differences, the lanes' partial sums are formed in another order.  (The fourth case passes the pipeline's
+    exact-order recomputation of sums near 0 / 1 -- label_estimation 'pessimistic', qmc_exact.h -- which the single kernel
+    does not have: no such sum occurs in it.)"""
     from ital_amd import ITAL, mvn_stream
     rng = np.random.default_rng(17)
     X = rng.random((n, 9))
