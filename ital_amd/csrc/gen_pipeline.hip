@@ -339,6 +339,53 @@ __global__ __launch_bounds__(256) void gen_verdict_kernel(ital_gscore_desc d, GP
     if (staged) flush();
 }
 
+// One or two variables (the first two greedy steps): every call is a closed form -- norm.cdf / Genz's BVU, exactly as
+// prepare_call / finish_call (gen_common.h) evaluate them -- so the step is this kernel and the combine: thread per
+// (candidate, call), one workgroup per candidate walking its calls; no lattice, no stream, no list.
+template <int T>
+__global__ __launch_bounds__(256) void gen_closed_kernel(ital_gscore_desc d, GPipe g) {
+    static_assert(T == 1 || T == 2, "closed forms exist for one and two variables");
+    const int64_t i = blockIdx.x;
+    const int64_t p = g.slab_lo + i;
+    if (!d.alive[p]) return;
+    const int row = d.cand[p];
+    double mu[T], Sg[T * (T + 1) / 2];
+    load_prior<T>(d, row, mu, Sg);
+    int ipos[T];
+#pragma unroll
+    for (int v = 0; v < T; v++) ipos[v] = v < d.n_picks ? d.pick_pos[v] : d.nE;
+    // two variables: an updated call takes them in the order of their data indices (ital.py:448)
+    bool swap = false;
+    if (T == 2) swap = d.row_offset + row < d.E_idx[0];
+    double* meta = g.meta + (size_t)i * g.total * 2;
+    for (int call = (int)threadIdx.x; call < g.total; call += (int)blockDim.x) {
+        const CallInfo ci = decode_call(d, p, call, g.cpp, 1, T, g.npat);
+        int flags = 16;
+        double value = 0.0;
+        if (ci.kind != K_SKIP) {
+            unsigned relU, Fm, Fp;
+            call_masks<T>(ci, ipos, relU, Fm, Fp);
+            double mean[T], cv[T * (T + 1) / 2];
+            masked_update<T, true>(mu, Sg, Fm, Fp, d.noise, mean, cv);
+            flags = 1;
+            if (T == 1) {
+                double var = cv[0];
+                if (ci.kind != K_UPDATED) var = fmax(0.0, var);          // first step: predict_stored 'diag' (gp.py:229, ital.py:558)
+                const double p_irr = norm_cdf0(mean[0], sqrt(var));       // prob_rel, ital.py:364-369
+                value = (relU & 1u) ? 1.0 - p_irr : p_irr;
+            } else {
+                const int a0 = (swap && ci.kind == K_UPDATED) ? 1 : 0, a1 = 1 - a0;       // variables at positions 0, 1 of the call
+                const double sd0 = sqrt(cv[a0 * (a0 + 1) / 2 + a0]), sd1 = sqrt(cv[a1 * (a1 + 1) / 2 + a1]);
+                const double l0 = -mean[a0] / sd0, l1 = -mean[a1] / sd1;
+                const double rho = cv[T > 1 ? 1 : 0] / (sd1 * sd0);
+                value = bvn_orthant(l0, l1, (relU >> a0) & 1u, (relU >> a1) & 1u, rho);
+            }
+        }
+        meta[2 * call] = __longlong_as_double(pack_meta(flags, T, 0, 0));
+        meta[2 * call + 1] = value;
+    }
+}
+
 // Thread per undecided call: the standardised problem after the simulated update (registers), COVSRT in the thread's LDS
 // slab, saturation test; a call that needs its lattice sum gets a record (its 8 lattices drawn at the stream position the
 // serial reference reaches) and an entry in the chunk's list.
@@ -805,7 +852,7 @@ struct PipePlan {
 PipePlan pipe_plan(const ital_gscore_desc* d) {
     PipePlan pl = {};
     const int nr = d->n_picks + 1, n = d->nE + 1;
-    if (d->subset_mode || n < 3 || n > ITAL_GEN_TFIX_MAX || nr != n) return pl;
+    if (d->subset_mode || n < 1 || n > ITAL_GEN_TFIX_MAX || nr != n) return pl;
     if (d->clip_cov > 0 && d->clip_cov < 1 && n > 5) return pl;
     const double npat = d->mc_rel > 0 ? (double)d->mc_rel : pow(2.0, nr);
     const double nfb = d->fb_mode == 3 ? 0.0 : d->fb_mode == 0 ? 1.0 : (d->mc_fb > 0 ? (double)d->mc_fb : (d->fb_mode == 1 ? pow(2.0, nr) : pow(3.0, nr) - 1));
@@ -817,7 +864,10 @@ PipePlan pipe_plan(const ital_gscore_desc* d) {
     pl.total = (int64_t)pl.npat * pl.cpp;
     pl.lat = 2 + n * (n + 1) / 2 + n;
     pl.R = pl.lat + 4 * (n - 1) + 8;
-    if (pl.fast) {
+    if (n <= 2) {                      // closed forms: the verdicts are the values
+        pl.per_cand = pl.total * 2;
+        pl.chunk_max = 0;
+    } else if (pl.fast) {
         pl.per_cand = 3 + pl.total * 2 + (pl.total + 1) / 2;
         pl.chunk_max = (int64_t)1 << 20;
     } else {
@@ -837,6 +887,7 @@ extern "C" int64_t ital_score_generic_workspace(const ital_gscore_desc* d) {
     const PipePlan pl = pipe_plan(d);
     if (!pl.ok) return 0;
     if (!pl.fast) return 2 * (1 + pl.per_cand * d->n_cand);
+    if (pl.n <= 2) return HDR + pl.per_cand * d->n_cand;
     int64_t ch = pl.chunk_max;
     while (ch > 4096 && ch / 2 >= d->n_cand * pl.total) ch >>= 1;
     return HDR + pl.per_cand * d->n_cand + 2 * (ch * pl.R + ch / 2 + 1);
@@ -845,11 +896,29 @@ extern "C" int64_t ital_score_generic_workspace(const ital_gscore_desc* d) {
 int ital_gen_pipeline(const ital_gscore_desc* d, hipStream_t stream) {
     const PipePlan pl = pipe_plan(d);
     if (!pl.ok || !d->work) return 1;
-    PipeStreams* ps = pipe_streams();
-    if (!ps) return ital_fail(-12, "ital_score_generic: cannot create the pipeline's streams");
     const int n = pl.n;
     GPipe g = {};
     g.total = (int)pl.total; g.npat = pl.npat; g.cpp = pl.cpp; g.n = n; g.R = pl.R; g.lat = pl.lat;
+    if (n <= 2) {
+        // ---- one or two variables: closed forms and combine on the caller's stream, slabs of the workspace
+        int64_t S = (d->work_doubles - HDR) / pl.per_cand;
+        if (S < 1) return 1;
+        if (S > d->n_cand) S = d->n_cand;
+        g.meta = d->work + HDR;
+        for (int64_t lo = 0; lo < d->n_cand; lo += S) {
+            g.slab_lo = lo;
+            g.slab_n = d->n_cand - lo < S ? d->n_cand - lo : S;
+            const unsigned threads = pl.total >= 256 ? 256u : (unsigned)((pl.total + 63) / 64 * 64);
+            if (n == 1) ITAL_LAUNCH(gen_closed_kernel<1>, dim3((unsigned)g.slab_n), dim3(threads), 0, stream, *d, g);
+            else ITAL_LAUNCH(gen_closed_kernel<2>, dim3((unsigned)g.slab_n), dim3(threads), 0, stream, *d, g);
+            ITAL_LAUNCH(gen_combine_kernel, dim3((unsigned)((g.slab_n + 3) / 4)), dim3(256), 0, stream, *d, g);
+            const int rc = ital_check_launch("ital_score_generic(closed forms)");
+            if (rc) return rc;
+        }
+        return 0;
+    }
+    PipeStreams* ps = pipe_streams();
+    if (!ps) return ital_fail(-12, "ital_score_generic: cannot create the pipeline's streams");
     const size_t lds_m = (size_t)4 * (pl.lat - 2 + 16 * (n - 1) + ITAL_GEN_TAILQ) * sizeof(double);
     const size_t lds_m0 = (size_t)(pl.lat - 2 + 16 * (n - 1) + ITAL_GEN_TAILQ + 2 * (GN - 1) * 64) * sizeof(double);   // one wave
     // label_estimation 'optimistic' / 'pessimistic' (plain mode only): sums that decide an exact comparison are formed again in
