@@ -844,11 +844,20 @@ def main():
         out["cpu_baseline"] = cpu_base
         if cpu_base:
             out["speedup_vs_cpu_baseline"] = out["value"] / cpu_base["value"]
-        print(json.dumps(out))
-    if world > 1:
+    # the JSON line is the LAST thing on stdout: RCCL prints a version banner through C stdio, which a redirected stdout holds
+    # back until the process ends -- every rank pushes its own out before the final barrier, rank 0 prints after it
+    try:
+        import ctypes
+        ctypes.CDLL(None).fflush(None)
+    except OSError:
+        pass
+    sys.stdout.flush()
+    if group is not None:
         import torch.distributed as dist
         dist.barrier()
         dist.destroy_process_group()
+    if out is not None:
+        print(json.dumps(out), flush=True)
     if not head_agree or (scale is not None and not scale["picks_agree_across_ranks"]):
         raise SystemExit("bench.py: the ranks did NOT pick the same batches -- the line above is not a valid measurement")
 
