@@ -14,7 +14,8 @@ equality test of label_estimation 'optimistic' / 'pessimistic' (a third limit un
    continuous function of the matrix, so a last-bit difference gives a candidate other, equally valid patterns (measured:
    1 of 191 candidates at 125 000 x 512, 2 of 1000 fuzz cases).  Rule: for the patterns the device sampled the oracle's
    estimate equals the device's for EVERY candidate (strict); the oracle's own sampling reproduces the device's value for
-   at least 98 % of the (step, candidate) pairs (loose).  Instances: fuzz cases 150 (seed 11), 87 (seed 13), 78 and 271 (seed 47), 13 (seed 59).
+   at least 98 % of the (step, candidate) pairs (loose).  Instances: fuzz cases 150 (seed 11), 87 (seed 13), 78 and 271 (seed 47), 13 (seed 59);
+   1050, 1298 and 1373 of seed 83 (round 4, the 2000-case campaign over all kinds).
 """
 import os
 import sys
@@ -182,7 +183,7 @@ def test_exact_equality_reset_of_label_estimation_follows_the_reference(monkeypa
     assert at_reset >= 2         # the case does contain scores that hang on the exact comparison
 
 
-@pytest.mark.parametrize("seed0,case", [(11, 150), (13, 87), (47, 78), (47, 271), (59, 13)])
+@pytest.mark.parametrize("seed0,case", [(11, 150), (13, 87), (47, 78), (47, 271), (59, 13), (83, 1050), (83, 1298), (83, 1373)])
 def test_resampled_monte_carlo_patterns(seed0, case):
     if not torch.cuda.is_available():
         pytest.skip("no GPU")
