@@ -31,6 +31,7 @@ class UnseenList(object):
         self.version = 0
         self.last_removed = ()               # the ids of the last remove() (version - 1 -> version)
         self._flat = base                    # the list as an array (None: not formed since the last removal)
+        self._prev_flat = None               # (array before the last removal, the ids it lost): one pass forms the next one
 
     def __len__(self):
         return len(self.base) - len(self.removed)
@@ -75,7 +76,7 @@ class UnseenList(object):
     def array(self):
         """The whole list as an int64 array (treat as read-only; the same object until the next removal)."""
         if self._flat is None:
-            prev = getattr(self, "_prev_flat", None)
+            prev = self._prev_flat
             if prev is not None:             # the array before the last removal is at hand: one pass over it
                 self._flat = np.delete(prev[0], np.searchsorted(prev[0], prev[1]))
             else:
