@@ -1,18 +1,23 @@
-// General scorer, plain mode (no change-estimation subset, no clip_cov) with 3 .. 16 variables, as a pipeline of kernels
+// General scorer, plain mode (no change-estimation subset, no clip_cov) with 1 .. 16 variables, as a pipeline of kernels
 // through a workspace in HBM -- the noisy user models (reference ital/ital.py:300-342 `fb_iter`, :453-481 `likelihood`), the
 // entropy baseline, the Monte-Carlo pattern switch up to batches of 16 (ital.py:293-297).  score_generic.hip's single
 // kernel prepares, integrates and accumulates inside one wave per candidate; here every phase has the parallelism and the
 // register allocation that suit it:
 //
+//   1, 2 variables (the first two greedy steps): closed forms -- gen_closed_kernel<T> (thread per (candidate, call)) + combine.
+//
 //   3 .. 6 variables (every shipped noisy-user configuration), "fast" form
 //     gen_seed_kernel        thread per candidate          generator state at the candidate's first call
 //     gen_verdict_kernel<T>  THREAD per (candidate, call)  decode, closed-form simulated update of the means and variances in
-//                                                          REGISTERS (compile-time T, the fed-back block as a mask), verdict
-//                                                          from the standardised limits; undecided calls -> list U
+//                            (workgroup per candidate)     REGISTERS (compile-time T, the fed-back block as a mask), verdict
+//                                                          from the standardised limits; undecided calls -> list U (one
+//                                                          append per candidate)
 //     gen_build_kernel<T>    THREAD per entry of U         the full updated covariance (registers), COVSRT (per-thread LDS
 //                                                          slab), saturation test, the call's 8 lattices -> packed record,
 //                                                          entry in the chunk's list (regular / linearly dependent variables)
 //     gen_main_kernel<T|0>   WAVE per record               the lattice sum (FP64-VALU bound: the perfect-user evaluator)
+//     gen_exact_kernel       wave per flagged record       label_estimation 'optimistic' / 'pessimistic' only: sums near 0 / 1
+//                                                          again in MVKBRV's serial order (qmc_exact.h)
 //     gen_combine_kernel     wave per candidate            the terms in the reference's order -> mi
 //   With the general user at t = 4 only 240 of a candidate's 1296 calls need a lattice sum: verdicts for all calls with full
 //   waves and no LDS, the expensive preparation (COVSRT, lattices) for the undecided ones only -- again with full waves (the
