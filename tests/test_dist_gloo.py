@@ -204,3 +204,34 @@ def test_two_rank_exchange_in_argpartition_order():
     expect = order[int(np.argmax(scores[order]))]
     assert expect == order[4]
     assert r0[0] == expect and r1[0] == expect
+
+
+def _bench_helpers_worker(rank, world, port, ret):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import sys
+        sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+        import bench
+        same_sha, same = bench.picks_digest([[5, 9, 2, 7], [1, 3, 8, 4]])
+        own_sha, own = bench.picks_digest([[5, 9, 2, 7], [1, 3, 8, 4 + rank]])
+        ret[rank] = (same_sha, bench.ranks_agree(same, "cpu", world), bench.ranks_agree(own, "cpu", world),
+                     bench.gather_floats(1.5 + rank, "cpu", world))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_bench_compares_the_ranks_picks():
+    """bench.py at N > 1: every rank must have picked the same batches (a digest of the rounds' picks, all-gathered); one
+    differing pick on one rank is seen by all of them.  (World size 2 over gloo; the GPU rehearsal of the whole line:
+    profiles/r4_bench_2rank_gloo_*.json.)"""
+    port = _free_port()
+    with mp.Manager() as mgr:
+        ret = mgr.dict()
+        mp.spawn(_bench_helpers_worker, args=(2, port, ret), nprocs=2, join=True)
+        res = dict(ret)
+    assert res[0][0] == res[1][0] and len(res[0][0]) == 16
+    for r in (0, 1):
+        assert res[r][1] is True and res[r][2] is False
+        assert res[r][3] == [1.5, 2.5]
