@@ -182,8 +182,8 @@ def test_against_oracle(dev, seed, n, d, k, mode):
     (13, 30, 3, 3, dict(change_estimation_subset=6, clip_cov=0.25, label_prob=0.7, mistake_prob=0.1)),
     # noisy users with the estimates that compare terms for exact equality, low dimension (saturated probabilities: the
     # pipeline's gen_exact_kernel forms those sums again in the reference's order)
-    (15, 40, 2, 4, dict(label_prob=0.7, mistake_prob=0.1, label_estimation="pessimistic")),
-    (16, 36, 3, 5, dict(mistake_prob=0.2, label_estimation="optimistic")),
+    (15, 24, 2, 4, dict(label_prob=0.7, mistake_prob=0.1, label_estimation="pessimistic")),
+    (16, 24, 3, 5, dict(mistake_prob=0.2, label_estimation="optimistic")),
 ])
 def test_general_scorer_against_oracle(dev, seed, n, d, k, kw):
     from oracle import mvn as omvn
