@@ -610,6 +610,62 @@ def scaling_workload(device, rank, world, group, rounds=3):
                     "rank: no collective)"}
 
 
+def launch_ranks(n, argv):
+    """`python bench.py --gpus N` without a launcher (WORLD_SIZE unset): this process -- which has made no GPU call and never
+    will -- starts the N ranks as FRESH child processes through torch.distributed.run (one per GPU, rendezvous on
+    127.0.0.1 and a free port), passes everything they print on stdout/stderr through to its own stderr, prints rank 0's
+    JSON line as ITS last stdout line and returns the launcher's exit code.  The counterpart of the reference spawning its
+    own workers (ital/ital.py:124-126); never exec: see the pool's rule about replacing a process."""
+    import socket
+    import subprocess
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ)
+    env.pop("RANK", None), env.pop("LOCAL_RANK", None)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+    print("bench.py: starting %d ranks: %s" % (n, " ".join(cmd)), file=sys.stderr, flush=True)
+    proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True, bufsize=1)
+    line_json = None
+    for line in proc.stdout:
+        s_ = line.strip()
+        if s_.startswith("{") and s_.endswith("}") and '"metric"' in s_:
+            line_json = s_
+        else:
+            sys.stderr.write(line)
+    rc = proc.wait()
+    sys.stderr.flush()
+    if line_json is not None:
+        print(line_json, flush=True)
+    if rc == 0 and line_json is None:
+        print("bench.py: the ranks exited 0 but printed no JSON line", file=sys.stderr)
+        rc = 1
+    return rc
+
+
+def dry_run(rank, world, args):
+    """The launch path without a GPU: rendezvous (gloo), the digest comparison of the ranks, one JSON line from rank 0."""
+    import torch
+    import torch.distributed as dist
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    if os.environ.get("ITAL_BENCH_DRY_FAIL_RANK") == str(rank):
+        raise SystemExit("bench.py --dry-run: rank %d fails on request" % rank)      # the launch test's failing rank
+    sha, words = picks_digest([[1, 2, 3, 4]])
+    agree = ranks_agree(words, torch.device("cpu"), world)
+    ranks = gather_floats(rank, torch.device("cpu"), world)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps({"metric": "MI-scored candidates/sec per fetch_unlabelled(k) round", "value": None, "dry_run": True,
+                          "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ranks_seen": ranks,
+                          "picks_agree_across_ranks": agree}), flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -625,20 +681,26 @@ def main():
                     "configs[3], ~5 s); c5k16 = 1 000 000 x 512, k = 16, monte_carlo_num_rel = 1 (configs[4] whole, ~2.5 min)")
     ap.add_argument("--force-collectives", action="store_true",
                     help="one rank, but through the exchange path of N > 1 (1-rank RCCL group): prices the per-step collective")
+    ap.add_argument("--dry-run", action="store_true",
+                    help="launch path only (no GPU): the ranks rendezvous over gloo, agree on a digest and rank 0 prints a "
+                         "line with dry_run: true -- what tests/test_bench_launch.py runs on CPU")
     args = ap.parse_args()
     globals().update(ROWS_PER_GPU=args.rows, BATCH=args.batch)
 
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        raise SystemExit(launch_ranks(args.gpus, sys.argv[1:]))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit("bench.py: --gpus %d but the launcher started %d rank(s)" % (args.gpus, world))
+    if args.dry_run:
+        return dry_run(rank, world, args)
     cpu_base = None
     if world == 1 and not args.no_cpu_baseline:
         # before anything touches the GPU: the baseline forks worker pools
         cpu_base = cpu_baseline(make_data(ROWS_PER_GPU, DIM, seed=0), os.cpu_count() or 1)
     import torch
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node %d for --gpus %d" % (args.gpus, args.gpus))
     if os.environ.get("ITAL_BENCH_ONE_DEVICE"):
         local_rank = 0      # debugging aid for a 1-GPU box: all ranks on cuda:0 (use with ITAL_BENCH_BACKEND=gloo)
     torch.cuda.set_device(local_rank)
