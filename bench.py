@@ -50,11 +50,12 @@ VALU_PER_PAIR_CHAIN = 47 + 0.85 * 45 + 0.15 * 121      # vector instructions of 
 FLOP_PER_MCMI_TERM = 53 + 2 * 44 + 6
 # committed counter summaries (rocprofv3 --pmc passes of this very command, tools/profile_gpu.sh + tools/pmc_summary.py):
 # HBM traffic and instruction counts per launch are read from these files and the file is named in the output
-PMC_FILES = {"headline": "profiles/r4_headline_pmc_summary.csv", "general": "profiles/r4_general_pmc_summary.csv",
-             "k8": "profiles/r4_k8_pmc_summary.csv"}
-ROUND_GAPS_FILE = "profiles/r4_round_gaps.json"   # launches / busy fraction of a round out of a committed kernel trace
+PMC_FILES = {"headline": "profiles/r5_headline_pmc_summary.csv", "general": "profiles/r5_general_pmc_summary.csv",
+             "k8": "profiles/r5_k8_pmc_summary.csv", "mcmi": "profiles/r5_mcmi_pmc_summary.csv",
+             "kcols": "profiles/r5_kcols_pmc_summary.csv", "c5": "profiles/r5_c5_pmc_summary.csv"}
+ROUND_GAPS_FILE = "profiles/r5_round_gaps.json"   # launches / busy fraction of a round out of a committed kernel trace
 CALIBRATION_FILE = "profiles/r4_oracle_calibration.json"
-STAMP_FILE = "profiles/r4_stamp.json"             # kernel sources each committed profile was taken with (tools/stamp.py)
+STAMP_FILE = "profiles/r5_stamp.json"             # kernel sources each committed profile was taken with (tools/stamp.py)
 PICKS_N1_FILE = "profiles/scaling_picks_n1.json"   # the batches the N = 1 run of scaling_workload picks (bench.py wrote it on one GPU)
 
 
@@ -138,9 +139,9 @@ def profile_is_current(rel_path):
             entry = json.load(f).get(rel_path)
         if entry is None:
             return False, "%s has no stamp in %s" % (rel_path, STAMP_FILE)
-        now = stamp.csrc_sha()
+        now = stamp.csrc_sha(entry.get("units"))      # the translation units the profiled workload runs (all of them: r4 stamps)
         if entry.get("csrc_sha") != now:
-            return False, "taken with other kernel sources (csrc_sha %s, this tree %s): re-run tools/profile_r4.sh" % (entry.get("csrc_sha"), now)
+            return False, "taken with other kernel sources (csrc_sha %s, this tree %s): re-run tools/profile_r5.sh" % (entry.get("csrc_sha"), now)
         return True, entry
     finally:
         sys.path.pop(0)
@@ -234,6 +235,27 @@ def gather_floats(value, device, world):
     return [float(g.item()) for g in got]
 
 
+def split_rounds(learner, label, k, rounds, barrier):
+    """fetch_unlabelled(k) and update() timed SEPARATELY ("fit / update reported separately"): `rounds` more
+    rounds, untimed for the headline, with the device drained around each call -- so the two do not overlap as they do in
+    the timed loop (the update's launches normally run under the host's bookkeeping).  Collective on several ranks."""
+    import torch
+    tf = tu = 0.0
+    for _ in range(rounds):
+        barrier()
+        t0 = time.perf_counter()
+        ret = learner.fetch_unlabelled(k)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        learner.update({int(i): label(int(i)) for i in ret})
+        torch.cuda.synchronize()
+        t2 = time.perf_counter()
+        tf += t1 - t0
+        tu += t2 - t1
+    return {"fetch_ms_per_round": tf / rounds * 1e3, "update_ms_per_round": tu / rounds * 1e3, "rounds": rounds,
+            "note": "drained device around each call (not the timed loop: there update() overlaps the host's bookkeeping)"}
+
+
 def transport_report(learner, group, device):
     """Which way the records of a greedy step travel on this rank, and what RCCL says about the communicator."""
     import ctypes
@@ -324,6 +346,8 @@ def other_workloads(X, rel, device):
                                        config="label_prob 0.5, mistake_prob 0.25: 3^t - 1 feedback configurations per pattern")
     del L
     out["ital_k8_25000x512"] = k8_workload(device)
+    out["ital_ce_subset5_iris_shaped_150x4"] = cesub_workload(device, 150, 4, rounds=5, length_scale=0.5)
+    out["ital_ce_subset5_9298x256"] = cesub_workload(device, ROWS_PER_GPU, DIM, length_scale=LENGTH_SCALE)
     np.random.seed(0)
     m = MCMI_min(X, length_scale=LENGTH_SCALE, subsample=1000, device=device)
     r, prof = timed(m, 20, BATCH, sample_rounds=5)
@@ -350,9 +374,10 @@ def other_workloads(X, rel, device):
         ach = terms * FLOP_PER_MCMI_TERM / sec / 1e12
         roofs["mcmi_score_kernel<%d>" % BATCH] = dict({"bound": "fp64-valu", "achieved": ach, "peak": FP64_VALU_PEAK_TFLOPS,
                                                        "unit": "TFLOP/s", "frac": ach / FP64_VALU_PEAK_TFLOPS,
-                                                       "avg_launch_ms": sec * 1e3, "terms_per_s": terms / sec, "traffic": None,
-                                                       "note": "counters: profiles/r2_mcmi_pmc_summary.csv (tools/mcmi_bench.py, "
-                                                               "launches of 1000 and 9273 candidates averaged)"})
+                                                       "avg_launch_ms": sec * 1e3, "terms_per_s": terms / sec},
+                                                      **pmc_fields("mcmi", "void ital::mcmi_score_kernel<%d>" % BATCH, sec),
+                                                      **{"pmc_note": "counters per launch of tools/mcmi_bench.py (launches of 1000 and "
+                                                                     "9273 candidates averaged), quoted only while their stamp matches"})
     out["mcmi_min_subsample1000_k4"] = dict(r, roofline=roofs, config="MCMI_min, subsample 1000 (reference configs/usps.conf)")
     # batches of 6 (reference configs/toy*.conf use batch_size = 6): the split scorer (preparation + workgroup per
     # candidate and group of 8 label patterns)
@@ -375,6 +400,46 @@ def other_workloads(X, rel, device):
                                                                            for key, v in sorted(prof6.items())},
                                             config="MCMI_min, subsample 1000, batch of 6")
     return out
+
+
+def cesub_workload(device, n, d, k=4, subset=5, rounds=3, length_scale=None, seed=5):
+    """The change-estimation subset (reference ital.py:103-108, :227-275 `_call_iter_sub`; BASELINE.json configs[0] is the
+    Iris-shaped case): every orthant spans the subset + the batch + the candidate (up to 5 + 4 + 1 variables here), one wave
+    per candidate in the monolithic score_generic_kernel -- the path no other workload of this file times."""
+    import torch
+    from ital_amd import ITAL, mvn_stream
+    X = make_data(n, d, seed=seed)
+    rel = np.where(X[:, 0] > 0.5, 1.0, -1.0)
+    mvn_stream.GLOBAL.reset()
+    np.random.seed(0)
+    L = ITAL(X, length_scale=length_scale or float(np.sqrt(d / 12.0)), change_estimation_subset=subset, device=device)
+    L.update({0: 1, 1: -1})
+    ret = L.fetch_unlabelled(k)                                  # warm-up round (code load)
+    L.update({int(i): float(rel[i]) for i in ret})
+    L.profile = []
+    L.event_pool = [torch.cuda.Event(enable_timing=True) for _ in range(8 * k * rounds + 16)]
+    for ev in L.event_pool:
+        ev.record()
+    torch.cuda.synchronize()
+    scored = 0
+    t0 = time.perf_counter()
+    for _ in range(rounds):
+        n_c = len(L.get_unseen())
+        ret = L.fetch_unlabelled(k)
+        L.update({int(i): float(rel[i]) for i in ret})
+        scored += sum(n_c - t for t in range(k))
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    prof = {}
+    for name, t, n_c, e0, e1 in L.profile:
+        prof.setdefault((name, t), []).append(e0.elapsed_time(e1))
+    res = {"ms_per_round": dt / rounds * 1e3, "candidates_per_s": scored / dt, "rounds": rounds,
+           "config": "synthetic %d x %d, k=%d, change_estimation_subset=%d, perfect user (reference ital.py:227-275)" % (n, d, k, subset),
+           "kernel_ms": {"%s_t%d" % key: float(np.mean(v)) for key, v in sorted(prof.items())}}
+    del L
+    gc.collect()
+    torch.cuda.empty_cache()
+    return res
 
 
 def k8_workload(device, n=25000, d=512, k=8):
@@ -511,7 +576,11 @@ def scaling_workload(device, rank, world, group, rounds=3):
     local = block_rows(row0, row1, d, seed=1)
     data = sharding.ShardedRows(local, n, row0)
     mvn_stream.GLOBAL.reset()
+    torch.cuda.synchronize()
+    t_fit0 = time.perf_counter()
     L = ITAL(data, length_scale=float(np.sqrt(d / 12.0)), device=device, rank=rank, world=world, group=group)
+    torch.cuda.synchronize()
+    t_fit1 = time.perf_counter()
     del local
 
     def barrier():
@@ -533,8 +602,10 @@ def scaling_workload(device, rank, world, group, rounds=3):
 
     picks = []
     L.update({0: 1})
+    torch.cuda.synchronize()
+    t_fit2 = time.perf_counter()
     picks.append(one_round())                              # warm-up
-    L.host_clock = dict(gap_s=0.0, gaps=0, enqueue_s=0.0, t_download=None)
+    L.host_clock = L.gp.host_clock = dict(gap_s=0.0, gaps=0, enqueue_s=0.0, t_download=None)
     L.profile = []
     L.event_pool = [torch.cuda.Event(enable_timing=True) for _ in range(6 * k * rounds + 16)]
     for ev in L.event_pool:
@@ -551,7 +622,8 @@ def scaling_workload(device, rank, world, group, rounds=3):
     barrier()
     dt = time.perf_counter() - t0
     launches = (_lib.lib().ital_launch_count() - launches0) / rounds
-    hc, L.host_clock = L.host_clock, None
+    hc, L.host_clock, L.gp.host_clock = L.host_clock, None, None
+    parts = split_rounds(L, label, k, 2, barrier)          # (after the timed rounds; the picks of these are not compared)
     # parity evidence of the run itself: every rank must have picked the same batches (digest compared across the ranks),
     # and the batches of the N = 1 run of this workload (committed: PICKS_N1_FILE) -- the picks do not depend on the sharding
     sha, words = picks_digest(picks)
@@ -567,6 +639,10 @@ def scaling_workload(device, rank, world, group, rounds=3):
             json.dump({key: {"picks_sha": sha, "picks": [[int(i) for i in r_] for r_ in picks]}}, f)
     host_ms = gather_floats(hc["gap_s"] / max(hc["gaps"], 1) * 1e3 if hc["gaps"] else float("nan"), device, world)
     enq_ms = gather_floats(hc["enqueue_s"] / max(hc["gaps"] + 1, 1) * 1e3, device, world)
+    # ... and what that host time is made of (per rank, per round; rounds - 1 gaps, rounds updates)
+    split = {name: gather_floats(hc.get(key, 0.0) / max(cnt, 1) * 1e3, device, world)
+             for name, key, cnt in (("update_append_ms", "append_s", rounds), ("means_allgather_ms", "means_s", rounds),
+                                    ("fetch_prologue_ms", "prologue_s", hc["gaps"]))}
     transport = transport_report(L, group, device)
     if world > 1:
         import torch.distributed as dist
@@ -594,9 +670,19 @@ def scaling_workload(device, rank, world, group, rounds=3):
     return {"workload": "synthetic %d x %d, k=%d, perfect user, full 2^t enumeration, fetch_unlabelled + update per round"
                         % (n, d, k), "scaling": "strong", "rows_per_rank": row1 - row0, "world_size": world,
             "backend": backend, "rounds": rounds, "ms_per_round": dt / rounds * 1e3, "candidates_per_s": scored / dt,
+            "fit_ms": {"construct_ms": (t_fit1 - t_fit0) * 1e3, "first_update_ms": (t_fit2 - t_fit1) * 1e3,
+                       "note": "construct = upload of this rank's rows (host -> device over PCIe: 4 GB at 1M x 512 on one rank) + "
+                               "row norms + buffers; the reference's fit forms the dense N x N kernel matrix here (gp.py:128), "
+                               "which at N = 1M does not exist on any machine"},
+            **{k_: parts[k_] for k_ in ("fetch_ms_per_round", "update_ms_per_round")},
             "picks_sha": sha, "picks_agree_across_ranks": agree,
             "picks_match_n1": (sha == ref["picks_sha"]) if ref else None, "picks_n1_file": PICKS_N1_FILE if ref else None,
-            "host_ms_per_round": host_ms, "host_enqueue_ms_per_round": enq_ms,
+            "host_ms_per_round": host_ms, "host_enqueue_ms_per_round": enq_ms, "host_ms_split": split,
+            "host_ms_split_note": "per rank, host-side time of one round's update(): the Cholesky append + whitening sweep calls "
+                                  "(update_append_ms), the replication of the refreshed means (means_allgather_ms: asynchronous on "
+                                  "RCCL; a gloo rehearsal stages 8 B per sample through the host and blocks), and of the next "
+                                  "fetch's prologue up to the call that enqueues the round (fetch_prologue_ms); the rest of "
+                                  "host_ms_per_round is the caller's feedback dictionary and the candidate bookkeeping of update()",
             "host_ms_note": "per rank: host time between the download of a round's picks and the call that enqueues the next "
                             "round (feedback, update(), fetch prologue) / time inside that call + the next round's descriptor "
                             "(GPU busy meanwhile); NaN: the rounds did not run as single calls",
@@ -724,8 +810,18 @@ def main():
     n_total = ROWS_PER_GPU * world
     X = make_data(n_total, DIM, seed=0)
     rel = np.where(X[:, 0] > 0.5, 1.0, -1.0)
+    torch.cuda.synchronize()
+    t_fit0 = time.perf_counter()
     learner = ITAL(X, length_scale=LENGTH_SCALE, label_prob=args.label_prob, mistake_prob=args.mistake_prob, device=device,
                    rank=rank, world=world, group=group)
+    torch.cuda.synchronize()
+    t_fit1 = time.perf_counter()
+    learner.update({0: 1})
+    torch.cuda.synchronize()
+    fit_ms = {"construct_ms": (t_fit1 - t_fit0) * 1e3, "first_update_ms": (time.perf_counter() - t_fit1) * 1e3,
+              "note": "first use in the process (library load, lazily initialised torch kernels, allocations): construct = upload of "
+                      "the rows + row norms + buffers, first update = Cholesky append + whitening sweep + means"}
+    learner.reset()
 
     def barrier():
         torch.cuda.synchronize()
@@ -803,6 +899,7 @@ def main():
         marks_u.append(time.perf_counter())
     barrier()
     dt_unfrozen = time.perf_counter() - tu
+    parts = split_rounds(learner, lambda i: float(rel[i]), BATCH, min(args.steps, 5), barrier)
     learner.profile = prof_timed
     if os.environ.get("ITAL_BENCH_STEP_TIMES"):
         print("step ms (timed):    " + " ".join("%.2f" % ((b_ - a_) * 1e3) for a_, b_ in zip([t0] + marks[:-1], marks)), file=sys.stderr)
@@ -885,6 +982,8 @@ def main():
                "roofline": roof, "roofline_hbm": hbm_stream_probe(device) if world == 1 else roof_hbm,
                "roofline_hbm_at_workload_size": roof_hbm,
                "kernel_ms": {"%s_t%d" % k: float(np.mean([d for d, _ in v])) * 1e3 for k, v in sorted(prof.items())},
+               "fit_ms": fit_ms, "fetch_ms_per_round": parts["fetch_ms_per_round"], "update_ms_per_round": parts["update_ms_per_round"],
+               "fetch_update_split_note": parts["note"],
                "ms_per_step_unfrozen_heap": dt_unfrozen / args.steps * 1e3, "preheat_rounds_before_warmup": preheat,
                "library_launches_per_step": launches, "round_gaps": round_gaps(),
                "picks_sha": head_sha, "picks_agree_across_ranks": head_agree, **head_transport,

@@ -257,6 +257,18 @@ int ital_score_step(const ital_score_desc* d, hipStream_t stream);
 /* Doubles of workspace that let ital_score_step(t >= 3) handle n_cand candidates in one slab (0 for t < 3). */
 int64_t ital_score_workspace(int t, int64_t n_cand);
 
+/* Sizes of the buffers a host owns, so that it need not re-derive them from the comments above (all in doubles):
+ *   ital_record_len       a selection record = ITAL_REC_HEADER + ldx + ldw + kmax (sel_record, `record` of ital_select_*,
+ *                         a row of records_all, rec_len of ital_select_exchange / ital_select_resolve);
+ *   ital_round_workspace  `step.work` of a round of k steps over n_cand candidates when the host grants at most cap_doubles
+ *                         (<= 0: no cap): one slab if that fits, else the cap (never below one candidate's need; 0 for k < 3);
+ *   ital_sel_parts_len    `step.sel_parts` for the steps 1 .. k of such a round with a workspace of work_doubles: three per
+ *                         block of the largest scoring launch plus one block per slab.
+ * Pure host arithmetic: no device call, valid without a GPU. */
+int ital_record_len(int ldx, int ldw, int kmax);
+int64_t ital_round_workspace(int k, int64_t n_cand, int64_t cap_doubles);
+int64_t ital_sel_parts_len(int k, int64_t n_cand, int64_t work_doubles);
+
 /* One whole round of the perfect-user path -- fetch_unlabelled(k), reference ital/ital.py:98-134 -- enqueued by ONE call:
  * candidate-list upkeep, then for t = 1 .. k ital_score_step (ending with the selection inside its last launch: `step.sel_*`
  * must be set) and, for t < k, the new member's cross-covariance column (ital_cross_cov_cols out of the batch state into
@@ -328,6 +340,15 @@ int ital_select_exchange(const double* record, double* records_all, int rec_len,
  * bookkeeping does (ital_amd.sharding.raw_comm agrees on the outcome across the ranks before any of them uses it).
  * how (optional, how_len bytes): where RCCL was found.  -38: no RCCL in the process; -22: null communicator. */
 int ital_exchange_info(void* nccl_comm, int* world, int* rank, char* how, int how_len);
+
+/* Health of the communicator the exchanges run on: ncclCommGetAsyncError of the RCCL already in the process.  0: no error
+ * (*async_error = ncclSuccess, or ncclInProgress on a non-blocking communicator); -5: RCCL's progress thread has recorded an
+ * error (a peer died, a link failed: *async_error = the ncclResult_t, message in ital_last_error()); -38: no RCCL / no such
+ * entry point.  Nothing is enqueued.  Collectives issued below torch.distributed are invisible to its watchdog: a host polls
+ * this while it waits for the picks of a round (and bounds that wait: a rank that dies mid-round leaves the others inside
+ * ncclAllGather) -- the failure detection the reference gets from multiprocessing.Pool raising in the parent when a worker
+ * dies, reference ital/ital.py:124-126. */
+int ital_exchange_error(void* nccl_comm, int* async_error);
 
 /* ital_select_local + ital_select_resolve for ONE rank in a single launch (small problems are launch-latency bound).
  * Same semantics; `record` is scratch of ITAL_REC_HEADER + ldx + ldw + kmax doubles. */

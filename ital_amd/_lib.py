@@ -140,6 +140,10 @@ SIGNATURES = {
                                   c_int64, c_int, c_int, ItalBatch, c_void_p, c_void_p, c_void_p, c_void_p]),
     "ital_select_exchange": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p]),
     "ital_exchange_info": (c_int, [c_void_p, c_void_p, c_void_p, ctypes.c_char_p, c_int]),
+    "ital_exchange_error": (c_int, [c_void_p, c_void_p]),
+    "ital_record_len": (c_int, [c_int, c_int, c_int]),
+    "ital_round_workspace": (c_int64, [c_int, c_int64, c_int64]),
+    "ital_sel_parts_len": (c_int64, [c_int, c_int64, c_int64]),
     "ital_mcmi_round": (c_int, [ctypes.POINTER(ItalMcmiRoundDesc), c_void_p]),
     "ital_gather_block": (c_int, [c_void_p, c_int64, c_int64, c_int64, c_void_p, c_void_p, c_int, c_void_p, c_int64, c_int,
                                   c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p]),

@@ -12,6 +12,7 @@
 #include <dlfcn.h>
 #include <hip/hip_runtime.h>
 #include <link.h>
+#include <mutex>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -23,12 +24,13 @@ namespace {
 
 typedef int (*all_gather_fn)(const void*, void*, size_t, int, void*, hipStream_t);   // ncclAllGather
 typedef const char* (*error_string_fn)(int);
-typedef int (*comm_int_fn)(void*, int*);                                              // ncclCommCount, ncclCommUserRank
+typedef int (*comm_int_fn)(void*, int*);                                              // ncclCommCount, ncclCommUserRank, ncclCommGetAsyncError
 constexpr int NCCL_FLOAT64 = 8;   // ncclDouble (nccl.h: ncclFloat64 = 8)
 
 all_gather_fn g_all_gather = nullptr;
 error_string_fn g_error_string = nullptr;
-comm_int_fn g_comm_count = nullptr, g_comm_rank = nullptr;
+comm_int_fn g_comm_count = nullptr, g_comm_rank = nullptr, g_comm_async_error = nullptr;
+constexpr int NCCL_SUCCESS = 0, NCCL_IN_PROGRESS = 7;   // nccl.h: ncclSuccess, ncclInProgress (a non-blocking communicator still connecting)
 char g_how[600] = "";
 
 int find_loaded_rccl(struct dl_phdr_info* info, size_t, void* out) {
@@ -41,7 +43,11 @@ int find_loaded_rccl(struct dl_phdr_info* info, size_t, void* out) {
     return 1;   // stop: first match
 }
 
+std::mutex g_resolve_lock;      // the entry points are resolved once, whichever thread asks first (a failed look-up may be
+                                // repeated later: the host can load RCCL after this library)
+
 bool resolve() {
+    std::lock_guard<std::mutex> hold(g_resolve_lock);
     if (g_all_gather) return true;
     void* handle = nullptr;
     void* sym = dlsym(RTLD_DEFAULT, "ncclAllGather");
@@ -62,11 +68,12 @@ bool resolve() {
         }
     }
     if (!sym) return false;
-    g_all_gather = reinterpret_cast<all_gather_fn>(sym);
     auto look = [&](const char* name) { return handle ? dlsym(handle, name) : dlsym(RTLD_DEFAULT, name); };
     g_error_string = reinterpret_cast<error_string_fn>(look("ncclGetErrorString"));
     g_comm_count = reinterpret_cast<comm_int_fn>(look("ncclCommCount"));
     g_comm_rank = reinterpret_cast<comm_int_fn>(look("ncclCommUserRank"));
+    g_comm_async_error = reinterpret_cast<comm_int_fn>(look("ncclCommGetAsyncError"));
+    g_all_gather = reinterpret_cast<all_gather_fn>(sym);      // last: what `resolve` tests first
     return true;
 }
 
@@ -98,5 +105,29 @@ extern "C" int ital_exchange_info(void* nccl_comm, int* world, int* rank, char* 
     if (rc) return ital_fail(-5, "ital_exchange_info: ncclCommCount / ncclCommUserRank failed");
     if (world) *world = w;
     if (rank) *rank = r;
+    return 0;
+}
+
+// What RCCL's progress thread says about the communicator (ncclCommGetAsyncError): calls issued below torch.distributed are
+// invisible to its watchdog, so the host polls this while it waits for a round's picks (ital_amd.ital: _await_picks).
+extern "C" int ital_exchange_error(void* nccl_comm, int* async_error) {
+    if (async_error) *async_error = -1;
+    if (!nccl_comm) return ital_fail(-22, "ital_exchange_error: communicator missing (ncclComm_t of this rank)");
+    if (!resolve()) return ital_fail(-38, "ital_exchange_error: no RCCL (ncclAllGather) loaded in this process");
+    if (!g_comm_async_error) return ital_fail(-38, "ital_exchange_error: the loaded RCCL lacks ncclCommGetAsyncError");
+    int err = -1;
+    const int rc = g_comm_async_error(nccl_comm, &err);
+    if (rc != NCCL_SUCCESS) {
+        char msg[256];
+        snprintf(msg, sizeof(msg), "ital_exchange_error: ncclCommGetAsyncError failed: %s", g_error_string ? g_error_string(rc) : "?");
+        return ital_fail(-5, msg);
+    }
+    if (async_error) *async_error = err;
+    if (err != NCCL_SUCCESS && err != NCCL_IN_PROGRESS) {
+        char msg[256];
+        snprintf(msg, sizeof(msg), "ital_exchange_error: the communicator reports an asynchronous error: %s",
+                 g_error_string ? g_error_string(err) : "?");
+        return ital_fail(-5, msg);
+    }
     return 0;
 }

@@ -30,34 +30,39 @@
                           // 197 -> 20 spilled VGPRs, 385 -> 193 spilled SGPRs in the t = 4 instantiation; noisy-user step 61.8 -> 59.1 ms)
 #endif
 #ifndef ITAL_GEN_BIG_NCB
-// chains per lane and round of the compile-time evaluator for 7 .. 16 variables, at two waves per SIMD: as many as the
-// 256 registers hold without spilling much -- the tail branch of Phi^-1 then runs on fuller waves.  Measured per step
-// (40 000 x 512, monte_carlo_num_rel = 1): 7 variables 57 -> 44 ms, 8: 122 -> 78, 9: 235 -> 160 (these ran two chains at
-// three waves per SIMD before), 10: 318 -> 282 (four chains), 11-14: three chains (-6 % .. -1 %; four lose 10 % at 12),
-// 15 / 16: two (three spill 63 / 76 registers: +3 % / +20 %)
-// Round 3: with the coefficients of the Phi^-1 tail branch materialised in place (device_math.h lit_s) every instantiation
-// lost ~70 registers and all scratch; chains per lane raised to what 256 registers hold now -- six at 7, 8 variables, five
-// at 9, 10, four at 11, 12, three beyond (40 000 x 512, k = 16, monte_carlo_num_rel = 1: 5.80 -> 5.53 s per round;
-// profiles/r3_general_variants.txt)
-// ... and then traded against occupancy where three waves per SIMD (168 registers) hold at least two chains without
-// scratch: per step at 40 000 x 512 (profiles/r3_general_variants.txt, second block) 8 variables 67.1 ms (six chains, two
-// waves) -> 59.7 (four chains, three waves), 10: 274.8 -> 250.8 (three), 13: 714.6 -> 691.9 (two), 14: 834.8 -> 816.2;
-// 11, 12 and 15, 16 stay at two waves (four / three chains: three waves would spill or lose)
-#define ITAL_GEN_BIG_NCB(T) ((T) <= 8 ? 4 : (T) <= 10 ? 3 : (T) <= 12 ? 4 : (T) <= 14 ? 2 : 3)
+// chains per lane and round of the compile-time evaluator for 7 .. 16 variables.
+// Rounds 2 - 4 sized these by what 256 / 168 registers held: two to four chains at two or three waves per SIMD (history of
+// the measurements: profiles/r3_general_variants.txt).  Round 5 found that most of those registers held nothing the loop
+// needs: the scheduler had sunk every chain's running product of interval widths to the end of the round and carried the
+// widths of all stages until then (qmc_common.h ITAL_QMC_PIN_FF: 90 of the 244 registers at T = 16).  With the product
+// formed per stage the instantiations take 111 (T = 7) .. 170 (T = 16, three chains) registers, and the table below is the
+// measured optimum of chains x waves per dimension (20 000 x 64, k = 16, monte_carlo_num_rel = 1, ms per step,
+// profiles/r5_variants_wide*.txt): more chains = fuller waves in the Phi^-1 tail branch (121 instructions per pass whatever
+// the number of lanes in it: 133 / 122 / 114 vector instructions per pair with 2 / 3 / 4 chains), more waves = more of the
+// issue slots filled (0.67 - 0.70 at two waves per SIMD, 0.77 - 0.81 at three, 0.87 at four).
+//   T      7     8     9     10    11    12    13    14    15    16
+//   r4    17.8  30.0  60.0  107.8 209.1 251.6 315.5 366.7 443.4 509.1   (4 4 3 3 4 4 2 2 3 3 chains at 3 3 3 3 2 2 3 3 2 2 waves)
+//   r5    16.5  27.4  54.9   98.6 178.1 214.2  ...   (4 4 3 4 4 4 4 4 4 3 chains at 4 4 4 3 3 3 3 3 3 3 waves)
+#define ITAL_GEN_BIG_NCB(T) ((T) == 9 || (T) == 16 ? 3 : 4)
 #endif
 #ifndef ITAL_GEN_BIG_HOTK
 #define ITAL_GEN_BIG_HOTK 1
 #endif
+#ifndef ITAL_GEN_BIG_KEN
+// exp coefficients (of ten) held in vector registers by the evaluator above, the rest materialised in place (HotKEn,
+// device_math.h): six where the registers are there, none from 13 variables on (four chains at three waves per SIMD)
+#define ITAL_GEN_BIG_KEN(T) ((T) >= 13 && (T) <= 15 ? 0 : 6)
+#endif
 #ifndef ITAL_GEN_BIG_COEF
-#define ITAL_GEN_BIG_COEF HotKE6     // six exp coefficients in registers, four in place (the logarithm of the tail branch takes
-                                    // its own in place anyway): what the three-wave instantiations need to stay without scratch
+#define ITAL_GEN_BIG_COEF(T) HotKEn<ITAL_GEN_BIG_KEN(T)>
 #endif
 #ifndef ITAL_GEN_FIXED_NH
 // lattice items per lane and round of the pipeline's evaluator for 3 .. 6 variables: three (six chains) at 5 and 6
 // variables, which then run at two waves per SIMD (per step at 40 000 x 512: 13.6 -> 11.3 ms, 26.5 -> 20.5 ms; four items
 // lose again); two at 3 and 4, three waves per SIMD
 // Round 3 (registers freed by lit_s): three items = six chains at every dimension, see ITAL_GEN_MAIN_WAVES
-#define ITAL_GEN_FIXED_NH(T) 3
+// Round 5: two items (four chains) at six variables, four waves per SIMD: as qmc_main_kernel<6> (score.hip ITAL_QMC_MAIN_NH)
+#define ITAL_GEN_FIXED_NH(T) ((T) == 6 ? 2 : 3)
 #endif
 #ifndef ITAL_GEN_ONE_TRIP
 // dimensions whose lattice-sum launch runs one call per wave (grid = capacity of the list; waves beyond its length leave
@@ -70,9 +75,9 @@
 #define ITAL_GEN_TAILQ 384     // doubles per wave of the Phi^-1 tail queue of the pipeline's lattice sums: up to 6 chains per lane
 #endif
 #ifndef ITAL_GEN_MAIN_WAVES
-// waves per SIMD the lattice-sum kernels aim at: four up to 4 variables (120 registers with six chains), three at 5 and 6,
-// two beyond (noisy-user round 41.0 -> 36.5 ms with six chains at these occupancies; four chains at four waves: 38.1)
-#define ITAL_GEN_MAIN_WAVES(T) ((T) > 0 && (T) < 5 ? 4 : (((T) >= 5 && (T) <= 10) || (T) == 13 || (T) == 14 ? 3 : 2))
+// waves per SIMD the lattice-sum kernels aim at: four up to 4 variables (120 registers with six chains), three at 5 and 6;
+// 6 .. 9 variables four again since round 5 (110 - 126 registers), three beyond (see ITAL_GEN_BIG_NCB)
+#define ITAL_GEN_MAIN_WAVES(T) ((T) > 0 && (T) < 5 ? 4 : ((T) >= 6 && (T) <= 9 ? 4 : 3))
 #endif
 #ifndef ITAL_GEN_TFIX_MAX
 #define ITAL_GEN_TFIX_MAX 16   // largest dimension the pipeline takes (plain mode)

@@ -73,8 +73,8 @@ __device__ __forceinline__ int calls_feedbacks(const ital_gscore_desc& d, int nr
 
 // Generator state `base` advanced by `before` uniforms (one 3x3 product mod m per set bit).
 __device__ __forceinline__ MrgState mrg_jump(const ital_gscore_desc& d, MrgState st, uint64_t before) {
-    for (int bit = 0; before != 0; bit++, before >>= 1)
-        if (before & 1u) mrg_apply(st, d.jump1 + bit * 18);
+    for (int bit = 0; before != 0 && bit < ITAL_JUMP_BITS; bit++, before >>= 1)      // (the table has ITAL_JUMP_BITS rows: the
+        if (before & 1u) mrg_apply(st, d.jump1 + bit * 18);                          // host rejects larger offsets, -22)
     return st;
 }
 
@@ -634,7 +634,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(ITAL_GEN_MA
     const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int lds_lat = g.lat - 2;                                   // slab (factor, limits), then the unpacked lattices
     // (T == 0: one wave per workgroup, which also holds the chains' conditioned values in LDS: qmc_eval_lds)
-    double* rec = lds_all + (size_t)wid * (lds_lat + 16 * (g.n - 1) + ITAL_GEN_TAILQ);
+    constexpr int YLD = T >= 7 ? ITAL_BIG_YLDS(T) * ITAL_GEN_BIG_NCB(T) * 64 : 0;   // conditioned values of the last stages (qmc_common.h)
+    constexpr int TQ = T >= 7 ? 64 * ITAL_GEN_BIG_NCB(T) : ITAL_GEN_TAILQ;           // tail queue: one slot per chain and lane
+    double* rec = lds_all + (size_t)wid * (lds_lat + 16 * (g.n - 1) + TQ + YLD);
     double* tailq = rec + lds_lat + 16 * (g.n - 1);
     const unsigned int count = g.count[T > 0 ? 0 : 1];
     const unsigned int nwaves = gridDim.x * (blockDim.x >> 6);
@@ -666,19 +668,21 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(ITAL_GEN_MA
         if (T >= 7) {
             constexpr int TB = T >= 7 ? T : 7, NDIMB = TB - 1;
 #if ITAL_GEN_BIG_HOTK
-            ITAL_GEN_BIG_COEF kk;      // exp coefficients as vector-register operands (device_math.h), as in the perfect-user kernel
+            ITAL_GEN_BIG_COEF(TB) kk;      // exp coefficients as vector-register operands (device_math.h), as in the perfect-user kernel
             kk.load();
-            value = wave_sum(qmc_lane_sum_big<TB, ITAL_GEN_BIG_NCB(TB), ITAL_GEN_BIG_COEF, FL>(rec + lds_lat, rec, infi, tailq, lane, kk)) /
+            value = wave_sum(qmc_lane_sum_big<TB, ITAL_GEN_BIG_NCB(TB), ITAL_GEN_BIG_COEF(TB), FL, ITAL_BIG_YLDS(TB), ITAL_BIG_GROUP(TB)>(
+                        rec + lds_lat, rec, infi, tailq, lane, kk, tailq + TQ)) /
                     (16.0 * P_TAB[(NDIMB < 10 ? NDIMB : 10) - 1]);
 #else
-            value = wave_sum(qmc_lane_sum_big<TB, ITAL_GEN_BIG_NCB(TB), LitK, FL>(rec + lds_lat, rec, infi, tailq, lane)) /
+            value = wave_sum(qmc_lane_sum_big<TB, ITAL_GEN_BIG_NCB(TB), LitK, FL, ITAL_BIG_YLDS(TB), ITAL_BIG_GROUP(TB)>(
+                        rec + lds_lat, rec, infi, tailq, lane, LitK(), tailq + TQ)) /
                     (16.0 * P_TAB[(NDIMB < 10 ? NDIMB : 10) - 1]);
 #endif
         } else if (T > 0) {
             constexpr int TF = T > 0 && T < 7 ? T : 3;
             value = qmc_eval_fixed_inl<TF, ITAL_GEN_FIXED_NH(TF), FL>(rec, infi, rec + lds_lat, lane, tailq);
         }
-        else value = qmc_eval_lds(n, rec, infi, (unsigned)((m >> 40) & 0xffffffu), rec + lds_lat, lane, tailq, tailq + ITAL_GEN_TAILQ);
+        else value = qmc_eval_lds(n, rec, infi, (unsigned)((m >> 40) & 0xffffffu), rec + lds_lat, lane, tailq, tailq + TQ);
         if (lane == 0) {
             g.meta[(size_t)id * 2 + 1] = value;
             // label_estimation 'optimistic' / 'pessimistic' compare terms for exact equality: a sum this close to 0 or 1 is
@@ -711,12 +715,14 @@ __global__ __launch_bounds__(64) void gen_exact_kernel(GPipe g, const double* __
     const int lane = threadIdx.x;
     // the block index runs over the chunk's list: regular calls from the front, the others from the back (records outside
     // the list are leftovers of an earlier chunk)
-    const unsigned int e = blockIdx.x;
-    if (e >= nrec || (e >= g.count[0] && e < nrec - g.count[1])) return;
+    // (a bounded grid strides over the list: with most calls decided before they reach a record, one workgroup per slot of the
+    // chunk's capacity -- up to 2^20, all but a handful leaving at once -- was launched for nothing)
+    for (unsigned int e = blockIdx.x; e < nrec; e += gridDim.x) {
+    if (e >= g.count[0] && e < nrec - g.count[1]) continue;
     const unsigned int r = g.list[e];
     const double* src = g.recs + (size_t)r * g.R;
     const long long m = __double_as_longlong(uniform_f64(src[0]));
-    if (!(m & GEN_FLAG_EXACT)) return;
+    if (!(m & GEN_FLAG_EXACT)) continue;
     const unsigned int id = (unsigned int)uniform_f64(src[1]);
     const int n = (int)((m >> 8) & 0xff);
     const unsigned infi = (unsigned)((m >> 16) & 0xffffffu), closes = (unsigned)((m >> 40) & 0xffffffu);
@@ -749,6 +755,8 @@ __global__ __launch_bounds__(64) void gen_exact_kernel(GPipe g, const double* __
     wave_sync();
     const double value = mvkbrv_serial(prime, vals, lane);
     if (lane == 0) g.meta[(size_t)id * 2 + 1] = value;
+    wave_sync();
+    }
 }
 
 // Wave per candidate: the lanes form the terms of 64 calls at a time, lane 0's order-preserving fold adds them up exactly
@@ -815,6 +823,18 @@ using namespace ital;
 
 static int fs_doubles(int nr) { return nr * nr + 2 * nr; }
 
+// LDS doubles per wave of gen_main_kernel<n> for its Phi^-1 tail queue and the conditioned values it keeps there
+// (ITAL_BIG_YLDS, qmc_common.h)
+static int gen_main_yld(int n) {
+    switch (n) {
+#define ITAL_YLD_CASE(T_) case T_: return 64 * ITAL_GEN_BIG_NCB(T_) + ITAL_BIG_YLDS(T_) * ITAL_GEN_BIG_NCB(T_) * 64;
+        ITAL_YLD_CASE(7) ITAL_YLD_CASE(8) ITAL_YLD_CASE(9) ITAL_YLD_CASE(10) ITAL_YLD_CASE(11) ITAL_YLD_CASE(12)
+        ITAL_YLD_CASE(13) ITAL_YLD_CASE(14) ITAL_YLD_CASE(15) ITAL_YLD_CASE(16)
+#undef ITAL_YLD_CASE
+    }
+    return ITAL_GEN_TAILQ;
+}
+
 // Streams and events of the pipeline (one set per device of the process, created on first use).
 struct PipeStreams {
     hipStream_t prep, main;
@@ -842,6 +862,16 @@ static PipeStreams* pipe_streams() {
 }
 
 namespace {
+
+// Error exit once kernels may be running on the internal streams: the caller's stream is made to wait for both of them
+// before the code is returned -- the caller may free or reuse the workspace as soon as ITS stream has drained.
+int pipe_bail(PipeStreams* ps, hipStream_t stream, int rc) {
+    (void)hipEventRecord(ps->built[0], ps->prep);
+    (void)hipStreamWaitEvent(ps->main, ps->built[0], 0);
+    (void)hipEventRecord(ps->combined, ps->main);
+    (void)hipStreamWaitEvent(stream, ps->combined, 0);
+    return rc;
+}
 
 struct PipePlan {
     bool ok;            // the step is the pipeline's
@@ -924,7 +954,7 @@ int ital_gen_pipeline(const ital_gscore_desc* d, hipStream_t stream) {
     }
     PipeStreams* ps = pipe_streams();
     if (!ps) return ital_fail(-12, "ital_score_generic: cannot create the pipeline's streams");
-    const size_t lds_m = (size_t)4 * (pl.lat - 2 + 16 * (n - 1) + ITAL_GEN_TAILQ) * sizeof(double);
+    const size_t lds_m = (size_t)4 * (pl.lat - 2 + 16 * (n - 1) + gen_main_yld(n)) * sizeof(double);   // (gen_main_yld: tail queue + conditioned values)
     const size_t lds_m0 = (size_t)(pl.lat - 2 + 16 * (n - 1) + ITAL_GEN_TAILQ + 2 * (GN - 1) * 64) * sizeof(double);   // one wave
     // label_estimation 'optimistic' / 'pessimistic' (plain mode only): sums that decide an exact comparison are formed again in
     // the reference's order
@@ -936,6 +966,16 @@ int ital_gen_pipeline(const ital_gscore_desc* d, hipStream_t stream) {
             return rc;
     }
 #define ITAL_GEN_MAIN(T_) case T_: ITAL_LAUNCH(gen_main_kernel<T_>, dim3(ITAL_GEN_ONE_TRIP(T_) ? (g.cap + 3) / 4 : 768), dim3(256), lds_m, ps->main, g, d->vk, d->pair_count, exact); break;
+#define ITAL_GEN_MAIN_LDS(T_) case T_: { static ItalLdsFlags f_; rc_lds = ital_raise_lds_limit(reinterpret_cast<const void*>(&gen_main_kernel<T_>), (int)lds_m, f_, "ital_score_generic"); } break;
+    if (lds_m > 48 * 1024) {       // conditioned values of the last stages in LDS (ITAL_BIG_YLDS) can take the workgroup beyond the default limit
+        int rc_lds = 0;
+        switch (n) {
+            ITAL_GEN_MAIN_LDS(7) ITAL_GEN_MAIN_LDS(8) ITAL_GEN_MAIN_LDS(9) ITAL_GEN_MAIN_LDS(10) ITAL_GEN_MAIN_LDS(11) ITAL_GEN_MAIN_LDS(12)
+            ITAL_GEN_MAIN_LDS(13) ITAL_GEN_MAIN_LDS(14) ITAL_GEN_MAIN_LDS(15) ITAL_GEN_MAIN_LDS(16)
+        }
+        if (rc_lds) return rc_lds;
+    }
+#undef ITAL_GEN_MAIN_LDS
 #define ITAL_GEN_MAINS()                                                                                                      \
     switch (n) {                                                                                                              \
         ITAL_GEN_MAIN(3) ITAL_GEN_MAIN(4) ITAL_GEN_MAIN(5) ITAL_GEN_MAIN(6) ITAL_GEN_MAIN(7) ITAL_GEN_MAIN(8) ITAL_GEN_MAIN(9)  \
@@ -943,7 +983,7 @@ int ital_gen_pipeline(const ital_gscore_desc* d, hipStream_t stream) {
         ITAL_GEN_MAIN(16)                                                                                                     \
     }                                                                                                                         \
     ITAL_LAUNCH(gen_main_kernel<0>, dim3(256), dim3(64), lds_m0, ps->main, g, d->vk, d->pair_count, exact);                      \
-    if (exact) ITAL_LAUNCH(gen_exact_kernel, dim3(g.cap), dim3(64), lds_x, ps->main, g, d->vk, g.cap)
+    if (exact) ITAL_LAUNCH(gen_exact_kernel, dim3(g.cap < 4096u ? g.cap : 4096u), dim3(64), lds_x, ps->main, g, d->vk, g.cap)
 
     if (pl.fast) {
         // ---- workspace: counters | per slab: generator states, meta, list U | two chunk buffers: records, list
@@ -963,6 +1003,14 @@ int ital_gen_pipeline(const ital_gscore_desc* d, hipStream_t stream) {
         double* chunk0 = base + pl.per_cand * S;
         g.countU = counters;
         g.cap = (unsigned int)ch;
+        const int stride_b = (n * (n + 1) / 2 + 2 * n) | 1;
+        const size_t lds_b = (size_t)256 * stride_b * sizeof(double);
+        if (lds_b > 48 * 1024) {       // six variables: 66 KB of per-thread slabs per workgroup (before anything is enqueued)
+            static ItalLdsFlags build_flags;
+            if (const int rc = ital_raise_lds_limit(reinterpret_cast<const void*>(&gen_build_kernel<6>), (int)lds_b, build_flags,
+                                                    "ital_score_generic"))
+                return rc;
+        }
         if (hipEventRecord(ps->start, stream) != hipSuccess || hipStreamWaitEvent(ps->prep, ps->start, 0) != hipSuccess ||
             hipStreamWaitEvent(ps->main, ps->start, 0) != hipSuccess)
             return ital_fail(-5, "ital_score_generic: stream synchronisation failed");
@@ -984,14 +1032,6 @@ int ital_gen_pipeline(const ital_gscore_desc* d, hipStream_t stream) {
                 }
             }
             const dim3 vgrid((unsigned)g.slab_n);
-            const int stride_b = (n * (n + 1) / 2 + 2 * n) | 1;
-            const size_t lds_b = (size_t)256 * stride_b * sizeof(double);
-            if (lds_b > 48 * 1024) {       // six variables: 66 KB of per-thread slabs per workgroup
-                static ItalLdsFlags build_flags;
-                if (const int rc = ital_raise_lds_limit(reinterpret_cast<const void*>(&gen_build_kernel<6>), (int)lds_b, build_flags,
-                                                        "ital_score_generic"))
-                    return rc;
-            }
             const int64_t nchunks = (g.slab_n * pl.total + ch - 1) / ch;
             switch (n) {
                 case 3: ITAL_LAUNCH(gen_verdict_kernel<3>, vgrid, dim3(vthreads), 0, ps->prep, *d, g); break;
@@ -1023,7 +1063,7 @@ int ital_gen_pipeline(const ital_gscore_desc* d, hipStream_t stream) {
             ITAL_LAUNCH(gen_combine_kernel, dim3((unsigned)((g.slab_n + 3) / 4)), dim3(256), 0, ps->main, *d, g);
             (void)hipEventRecord(ps->combined, ps->main);
             const int rc = ital_check_launch("ital_score_generic(pipeline)");
-            if (rc) return rc;
+            if (rc) return pipe_bail(ps, stream, rc);
         }
         (void)hipStreamWaitEvent(stream, ps->combined, 0);
         return 0;
@@ -1079,7 +1119,7 @@ int ital_gen_pipeline(const ital_gscore_desc* d, hipStream_t stream) {
         ITAL_LAUNCH(gen_combine_kernel, dim3((unsigned)((g.slab_n + 3) / 4)), dim3(256), 0, ps->main, *d, g);
         (void)hipEventRecord(ps->summed[buf], ps->main);
         const int rc = ital_check_launch("ital_score_generic(pipeline)");
-        if (rc) return rc;
+        if (rc) return pipe_bail(ps, stream, rc);
     }
     (void)hipEventRecord(ps->combined, ps->main);
     (void)hipStreamWaitEvent(stream, ps->combined, 0);

@@ -13,6 +13,12 @@
 #define ITAL_QMC_TRIM_LAST 1   // last round of a call's lattice points with only as many chains per lane as it needs
 #endif
 
+#ifndef ITAL_QMC_PIN_FF
+// The running product of a chain's interval widths is formed at every stage (an empty asm ties the value down).  Left to
+// itself the scheduler sinks the T multiplications of every chain to the end of the round and carries all the widths until
+// then: 2 registers per chain and stage (found in round 5: 90 of the 244 registers of the T = 16 lattice sums).
+#define ITAL_QMC_PIN_FF 1
+#endif
 #ifndef ITAL_QMC_FLIP
 // Every variable of an orthant call as an UPPER-bounded one (the compile-time lattice sums: perfect-user scorer, regular
 // calls of the general scorer): a variable bounded below enters negated -- its limit, its row and its column of the factor
@@ -54,7 +60,7 @@ __device__ __forceinline__ void flip_width(double (&w)[NCB], bool flipped) {
 // expensive log/sqrt branch runs on full waves of tail arguments only (typically once per 256 inversions instead of
 // once per 64).
 // q: wave-private LDS queue of 64*NC doubles.
-template <int NC, class K>
+template <int NC, class K, int GRP = 0>
 __device__ __forceinline__ void phinv_wave(const double (&p)[NC], double (&out)[NC], double* __restrict__ q, int lane,
                                            const K& kk) {
     bool need[NC];
@@ -62,6 +68,9 @@ __device__ __forceinline__ void phinv_wave(const double (&p)[NC], double (&out)[
     int total = 0;
 #pragma unroll
     for (int c = 0; c < NC; c++) {
+        // GRP > 0: the chains are evaluated in groups of GRP -- the scheduler may interleave the rationals of a group, not of
+        // all NC chains (whose temporaries would all be live at once: eval_chains_big)
+        if (GRP > 0 && c > 0 && c % GRP == 0) __builtin_amdgcn_sched_barrier(0);
         const double qc = p[c] - 0.5;
         need[c] = !(fabs(qc) <= 0.425);
         out[c] = phinv_central_q(qc);   // garbage (never a trap) for tail arguments: replaced below
@@ -121,6 +130,7 @@ __device__ __forceinline__ double eval_chains(const double (&xx)[NCB][(T - 1 > 0
             const double d = (!FL && lower) ? ph[c] : 0.0;
             const double w = (!FL && lower) ? 1.0 - ph[c] : ph[c];
             ff[c] *= w;
+            if (ITAL_QMC_PIN_FF) __asm__ volatile("" : "+v"(ff[c]));    // (the product is formed now: see eval_chains_big)
             if (i < T - 1) pin[c] = FL ? xx[c][i] * w : fma(xx[c][i], w, d);   // a dead chain (w == 0) just inverts d: finite, discarded
         }
         if (i < T - 1) {
@@ -266,6 +276,7 @@ __device__ __forceinline__ double eval_items_ps(const int (&kq)[NI], const int (
                 const double d = (!FL && lower) ? ph[c] : 0.0;
                 const double w = (!FL && lower) ? 1.0 - ph[c] : ph[c];
                 ff[c] *= w;
+                if (ITAL_QMC_PIN_FF) __asm__ volatile("" : "+v"(ff[c]));
                 if (i < T - 1) pin[c] = FL ? (a ? 1 - x0 : x0) * w : fma(a ? 1 - x0 : x0, w, d);
             }
         }
@@ -329,41 +340,97 @@ __device__ __forceinline__ double qmc_lane_sum_ps(const double* __restrict__ lat
 // LDS at use (`slab`: packed lower triangle with diagonal, then the limits -- the evaluator's record), the lattice
 // coordinates are formed per stage instead of up front; the conditioned values y (2 NH chains x T-1) stay in registers
 // because every index is a compile-time constant.
-template <int T, int NCB, class K, bool FL = false>
+#ifndef ITAL_BIG_HOIST0
+// The first variable's interval does not depend on the lattice point (no conditioning yet): its Phi is evaluated once per
+// call (qmc_lane_sum_big) instead of once per chain and round -- 1 of T Phi evaluations, 2.6 % (T = 16) .. 6 % (T = 7) of
+// the loop's vector instructions.  The compile-time evaluators with the factor in registers get this from the compiler
+// (loop-invariant code motion); here the factor is re-read from LDS behind a memory clobber, which pins it inside the loop.
+#define ITAL_BIG_HOIST0 1
+#endif
+#ifndef ITAL_BIG_PIN_FF
+#define ITAL_BIG_PIN_FF 1
+#endif
+#ifndef ITAL_BIG_PIN_LAT
+#define ITAL_BIG_PIN_LAT 1
+#endif
+#ifndef ITAL_BIG_GROUP
+// Chains of a lane evaluated together by the scheduler (0: all NCB): Phi and the central Phi^-1 of the NCB chains of a stage
+// in groups of this many, with a scheduling barrier between the groups.  All NCB chains interleaved keep NCB sets of
+// temporaries live; in groups the lane carries more chains (fuller waves in the Phi^-1 tail branch: 121 instructions per
+// pass whatever the number of lanes in it) at the register budget of three waves per SIMD.
+#define ITAL_BIG_GROUP(T) 0
+#endif
+#ifndef ITAL_BIG_ROWGRP
+#define ITAL_BIG_ROWGRP 2
+#endif
+#ifndef ITAL_BIG_YLDS
+// Conditioned values of the LAST ITAL_BIG_YLDS(T) stages in LDS instead of registers (`yl`: [YL][NCB][64] doubles of
+// wave-private memory): a value written at stage j is read once per later stage, so the latest ones are the cheapest to keep
+// there (YL (YL + 1) / 2 reads per chain and point) -- what lets an instantiation fit one more wave per SIMD.  0: none.
+#define ITAL_BIG_YLDS(T) ((T) == 14 ? 2 : (T) == 15 ? 4 : (T) == 16 ? 2 : 0)
+#endif
+
+template <int T, int NCB, class K, bool FL = false, int YL = 0, int GRP = 0>
 __device__ __forceinline__ double eval_chains_big(const int (&kk)[NCB], const int (&so)[NCB], const bool (&anti)[NCB],
                                                   const bool (&ok)[NCB], const double* __restrict__ lat,
                                                   const double* __restrict__ slab, unsigned infi_c, double* tailq, int lane,
-                                                  const K& coef) {
+                                                  const K& coef, double w0 = 0.0, double* __restrict__ yl = nullptr) {
     constexpr int NDIM = T - 1, NCOV = T * (T + 1) / 2;
-    double yy[NCB][NDIM], ff[NCB];
+    constexpr int NREG = NDIM - YL > 0 ? NDIM - YL : 1;      // stages 0 .. NDIM - YL - 1 keep their value in registers
+    double yy[NCB][NREG], ff[NCB];
 #pragma unroll
     for (int c = 0; c < NCB; c++) ff[c] = ok[c] ? 1.0 : 0.0;
 #pragma unroll
     for (int i = 0; i < T; i++) {
         const bool lower = (infi_c >> i) & 1u;
-        __asm__ volatile("" ::: "memory");   // keeps this row's factor loads here: hoisted out of the lattice loop they
-                                             // would occupy T(T+1)/2 register pairs
-        const double lmi = slab[NCOV + i];
-        double sc[NCB];
-#pragma unroll
-        for (int c = 0; c < NCB; c++) sc[c] = 0;
-#pragma unroll
-        for (int j = 0; j < i; j++) {
-            const double cij = slab[i * (i + 1) / 2 + j];
-#pragma unroll
-            for (int c = 0; c < NCB; c++) sc[c] = fma(cij, yy[c][j], sc[c]);
-        }
         double pin[NCB], ph[NCB];
+        if (ITAL_BIG_HOIST0 && i == 0) {
 #pragma unroll
-        for (int c = 0; c < NCB; c++) ph[c] = mvn_phi_lat(lmi - sc[c], coef);
-        if (FL) flip_width<NCB>(ph, lower);
+            for (int c = 0; c < NCB; c++) ph[c] = w0;           // already in its final form (flip_width applied)
+        } else {
+            __asm__ volatile("" ::: "memory");   // keeps this row's factor loads here: hoisted out of the lattice loop they
+                                                 // would occupy T(T+1)/2 register pairs
+            const double lmi = slab[NCOV + i];
+            double sc[NCB];
+#pragma unroll
+            for (int c = 0; c < NCB; c++) sc[c] = 0;
+#pragma unroll
+            for (int j = 0; j < i; j++) {
+                // (the factor row is read in groups of ITAL_BIG_ROWGRP values: all i loads of a row issued together would hold
+                // 2 i registers until their FMAs retire -- the register peak of the wide instantiations)
+                if (ITAL_BIG_ROWGRP > 0 && j > 0 && j % ITAL_BIG_ROWGRP == 0) __asm__ volatile("" ::: "memory");
+                const double cij = slab[i * (i + 1) / 2 + j];
+#pragma unroll
+                for (int c = 0; c < NCB; c++) {
+                    const double yj = (YL > 0 && j >= NDIM - YL) ? yl[((j - (NDIM - YL)) * NCB + c) * 64 + lane] : yy[c][j < NREG ? j : 0];
+                    sc[c] = fma(cij, yj, sc[c]);
+                }
+            }
+#pragma unroll
+            for (int c = 0; c < NCB; c++) {
+                if (GRP > 0 && c % GRP == 0) __builtin_amdgcn_sched_barrier(0);
+                ph[c] = mvn_phi_lat(lmi - sc[c], coef);
+            }
+            if (GRP > 0) __builtin_amdgcn_sched_barrier(0);
+            if (FL) flip_width<NCB>(ph, lower);
+        }
 #pragma unroll
         for (int c = 0; c < NCB; c++) {
             const double d = (!FL && lower) ? ph[c] : 0.0;
             const double w = (!FL && lower) ? 1.0 - ph[c] : ph[c];
             ff[c] *= w;
+            // (the running product is formed NOW: left alone, the scheduler sinks the T multiplications of a chain to the end
+            // of the round and keeps every stage's width alive until then -- 2 registers per chain and stage, 90 of the 244
+            // registers of the T = 16 instantiation with three chains)
+            if (ITAL_BIG_PIN_FF) __asm__ volatile("" : "+v"(ff[c]));
             if (i < T - 1) {
-                const double v = kk[c] * lat[so[c] + i] + lat[8 * NDIM + so[c] + i];
+                // the lattice is read HERE: `lat` is a noalias pointer, so the compiler may (and did) issue the 2 (T - 1)
+                // loads of every lattice item at the top of the round, across the clobbers above -- 4 registers per item
+                // and stage held to the end of the round (120 of the 244 registers of the T = 16 instantiation).  An
+                // offset the compiler cannot see through until this point keeps the loads in their stage.
+                int sof = so[c];
+                if (ITAL_BIG_PIN_LAT) __asm__ volatile("" : "+v"(sof));
+                const double v = kk[c] * lat[sof + i] + lat[8 * NDIM + sof + i];
                 const double fr = v - floor(v);
                 const double x0 = fabs(2 * fr - 1);
                 pin[c] = FL ? (anti[c] ? 1 - x0 : x0) * w : fma(anti[c] ? 1 - x0 : x0, w, d);
@@ -371,9 +438,12 @@ __device__ __forceinline__ double eval_chains_big(const int (&kk)[NCB], const in
         }
         if (i < T - 1) {
             double out[NCB];
-            phinv_wave<NCB>(pin, out, tailq, lane, coef);
+            phinv_wave<NCB, K, GRP>(pin, out, tailq, lane, coef);
 #pragma unroll
-            for (int c = 0; c < NCB; c++) yy[c][i] = out[c];
+            for (int c = 0; c < NCB; c++) {
+                if (YL > 0 && i >= NDIM - YL) yl[((i - (NDIM - YL)) * NCB + c) * 64 + lane] = out[c];   // (own lane only: no fence needed)
+                else yy[c][i < NREG ? i : 0] = out[c];
+            }
         }
     }
     double acc = 0.0;
@@ -384,11 +454,19 @@ __device__ __forceinline__ double eval_chains_big(const int (&kk)[NCB], const in
 
 // NCB chains per lane and round: whole lattice items (a point and its antithetic partner on the same lane) first; with an
 // odd NCB the last chain of lanes 2i and 2i + 1 is the point and the partner of one more item (32 NCB items per round).
-template <int T, int NCB, class K = LitK, bool FL = false>
+template <int T, int NCB, class K = LitK, bool FL = false, int YL = 0, int GRP = 0>
 __device__ __forceinline__ double qmc_lane_sum_big(const double* __restrict__ lat, const double* __restrict__ slab,
-                                                   unsigned infi_c, double* __restrict__ tailq, int lane, const K& coef = K()) {
-    constexpr int NDIM = T - 1, PRIME = P_TAB[(NDIM < 10 ? NDIM : 10) - 1];
+                                                   unsigned infi_c, double* __restrict__ tailq, int lane, const K& coef = K(),
+                                                   double* __restrict__ yl = nullptr) {
+    constexpr int NDIM = T - 1, PRIME = P_TAB[(NDIM < 10 ? NDIM : 10) - 1], NCOV = T * (T + 1) / 2;
     constexpr int NITEM = 8 * PRIME, PER_ROUND = 32 * NCB;
+    double w0 = 0.0;
+    if (ITAL_BIG_HOIST0) {
+        // (a variable bounded below outside the all-upper form contributes d = Phi, w = 1 - Phi: the loop forms both from ph)
+        double ph0[1] = {mvn_phi_lat(slab[NCOV], coef)};
+        if (FL) flip_width<1>(ph0, infi_c & 1u);
+        w0 = ph0[0];
+    }
     double acc = 0.0;
     for (int base = 0; base < NITEM; base += PER_ROUND) {
         int kk[NCB], so[NCB];
@@ -404,7 +482,7 @@ __device__ __forceinline__ double qmc_lane_sum_big(const double* __restrict__ la
             kk[c] = it - sft * PRIME + 1;
             so[c] = sft * NDIM;
         }
-        acc += eval_chains_big<T, NCB, K, FL>(kk, so, anti, ok, lat, slab, infi_c, tailq, lane, coef);
+        acc += eval_chains_big<T, NCB, K, FL, YL, GRP>(kk, so, anti, ok, lat, slab, infi_c, tailq, lane, coef, w0, yl);
     }
     return acc;
 }

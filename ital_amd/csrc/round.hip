@@ -147,16 +147,6 @@ __global__ __launch_bounds__(1024) void compact_rearm_kernel(uint8_t* __restrict
 
 using namespace ital;
 
-// Scratch of the long-list upkeep: one count per tile (ITAL_ROUND_MAX_CAND / 16 384 = 128 of them), per device.
-static int* compact_counts() {
-    static int* bufs[16] = {};
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return nullptr;
-    if (!bufs[dev] && hipMalloc(reinterpret_cast<void**>(&bufs[dev]), sizeof(int) * (ITAL_ROUND_MAX_CAND / COMPACT_TILE + 1)) != hipSuccess)
-        bufs[dev] = nullptr;
-    return bufs[dev];
-}
-
 extern "C" int ital_fetch_round(const ital_round_desc* r, hipStream_t stream) {
     if (!r) return ital_fail(-22, "ital_fetch_round: null descriptor");
     const ital_score_desc& tpl = r->step;
@@ -172,9 +162,13 @@ extern "C" int ital_fetch_round(const ital_round_desc* r, hipStream_t stream) {
     if (r->begin == 2 && (!r->cand_prev || r->n_prev < tpl.n_cand || r->n_prev > ITAL_ROUND_MAX_CAND || r->cand_prev == tpl.cand))
         return ital_fail(-22, "ital_fetch_round: begin = 2 needs the previous list in a buffer of its own");
     if (r->begin == 2 && r->n_prev >= COMPACT_FROM) {
-        int* counts = compact_counts();
-        if (!counts) return ital_fail(-12, "ital_fetch_round: no memory for the tile counts of the list upkeep");
+        // one count per tile (<= ITAL_ROUND_MAX_CAND / 16 384 + 1 = 129 ints) in the CALLER's memory: the head of step.sel_parts,
+        // which holds nothing between two rounds (every scoring launch writes its partials before the selecting block reads
+        // them) -- two learners on different streams of one device share no scratch of the library (round-4 advice)
         const unsigned ntiles = (unsigned)((r->n_prev + COMPACT_TILE - 1) / COMPACT_TILE);
+        if (!tpl.sel_parts || tpl.sel_parts_len * 2 < (int64_t)ntiles + 1)
+            return ital_fail(-22, "ital_fetch_round: step.sel_parts too small for the tile counts of the list upkeep (ital_sel_parts_len)");
+        int* counts = reinterpret_cast<int*>(tpl.sel_parts);
         uint8_t* alive = const_cast<uint8_t*>(tpl.alive);
         ITAL_LAUNCH(compact_count_kernel, dim3(ntiles), dim3(1024), 0, stream, alive, r->n_prev, counts);
         ITAL_LAUNCH(compact_scatter_kernel, dim3(ntiles), dim3(1024), 0, stream, r->cand_prev, alive, r->n_prev,

@@ -44,14 +44,20 @@
 // t = 7, 8: four chains -- what fits THREE waves per SIMD (168 registers, per-stage coordinates, factor in LDS): occupancy
 // is worth more there than fuller tail waves (25 000 x 512, `profiles/r3_k8_occupancy_variants.txt`: t = 8 steps 1216 ms
 // with six chains at two waves, 1249 with four at two, 1068 with four at three; t = 7 341 / 304)
-#define ITAL_QMC_MAIN_NH(T) ((T) >= 7 ? 2 : 3)
+// Round 5: with the running product of the interval widths formed per stage (qmc_common.h ITAL_QMC_PIN_FF) the instantiations
+// of t = 5 .. 8 lost 14 - 40 registers (145 / 167 / 162 / 161 -> 131 / 141 / 127 / 121) and the trade was measured again
+// (25 000 x 512, k = 8, profiles/r5_variants_wide2.txt, ms per step): t = 6 four chains at FOUR waves 71.2 (six at three: 73.7),
+// t = 7 six chains at three waves 280.8 (four at three: 303.0, four at four: 284.2), t = 8 four chains at four waves 965
+// (four at three: 1022, six at three: 977); t = 5 indifferent (21.2 - 21.8)
+#define ITAL_QMC_MAIN_NH(T) ((T) == 6 || (T) == 8 ? 2 : 3)
 #endif
 #ifndef ITAL_QMC_WAVES
 // waves per SIMD the register allocation aims at: four up to t = 4 (126 registers), three at t = 5, 6 (145 / 167: per step
 // 24.8 -> 21.1 ms, 95 -> 80 ms at 25 000 candidates) and at t = 7, 8 (168 each with four chains).  (Five at t = 3 fits
 // without scratch only without the width emulation of negated variables -- flip_width, qmc_common.h -- and was worth
 // 2 %: 0.386 -> 0.377 ms; with it 12 B of scratch: four.)
-#define ITAL_QMC_WAVES(T) ((T) <= 4 ? 4 : 3)
+// Round 5 (see ITAL_QMC_MAIN_NH): four also at t = 6 and t = 8 (110 / 121 registers with four chains).
+#define ITAL_QMC_WAVES(T) ((T) <= 4 || (T) == 6 || (T) == 8 ? 4 : 3)
 #endif
 #ifndef ITAL_QMC_MAIN_PS
 #define ITAL_QMC_MAIN_PS(T) ((T) >= 7)   // lattice coordinates formed per stage (qmc_lane_sum_ps): T = 7, 8 spill otherwise
@@ -726,6 +732,36 @@ using namespace ital;
 extern "C" int64_t ital_score_workspace(int t, int64_t n_cand) {
     if (t < 3 || t > ITAL_MAX_T || n_cand <= 0) return 0;
     return cand_doubles(t) * n_cand;
+}
+
+// ---- sizes a host needs for the buffers it owns (the prose of ital_hip.h as functions)
+extern "C" int ital_record_len(int ldx, int ldw, int kmax) {
+    if (ldx < 0 || ldw < 0 || kmax < 0) return 0;
+    return ITAL_REC_HEADER + ldx + ldw + kmax;
+}
+
+extern "C" int64_t ital_round_workspace(int k, int64_t n_cand, int64_t cap_doubles) {
+    if (k > ITAL_MAX_T) k = ITAL_MAX_T;
+    const int64_t one_slab = ital_score_workspace(k, n_cand > 0 ? n_cand : 1);     // steps t < k need less per candidate
+    if (one_slab == 0) return 0;
+    int64_t cap = cap_doubles > 0 ? cap_doubles : one_slab;
+    const int64_t least = ital_score_workspace(k, 1);
+    if (cap < least) cap = least;
+    return one_slab < cap ? one_slab : cap;
+}
+
+extern "C" int64_t ital_sel_parts_len(int k, int64_t n_cand, int64_t work_doubles) {
+    if (n_cand < 0) n_cand = 0;
+    if (k > ITAL_MAX_T) k = ITAL_MAX_T;
+    // blocks of the scoring launches of steps 1 .. k: n/256 at t = 1, n/32 at t = 2, n/256 + one (partial) block per slab of
+    // the workspace from t = 3 on (launch_qmc); every step re-uses the buffer, so the largest step counts
+    int64_t slabs = 0;
+    if (k >= 3 && n_cand > 0) {
+        const int64_t per = ital_score_workspace(k, 1);
+        const int64_t fit = work_doubles / per;
+        slabs = fit >= n_cand ? 1 : (fit < 1 ? n_cand : (n_cand + fit - 1) / fit);
+    }
+    return 3 * (n_cand / 32 + 64 + slabs);
 }
 
 // seeds_ready: the generator states of the candidates are already in the workspace (the round driver computed them in the

@@ -290,6 +290,13 @@ extern "C" int ital_score_generic(const ital_gscore_desc* d, hipStream_t stream)
             return ital_fail(-22, "ital_score_generic: more calls per candidate than ITAL_GENERIC_MAX_CALLS (use the monte-carlo switches)");
     }
     if (!d->jump1 || !d->vk) return ital_fail(-22, "ital_score_generic: stream tables missing");
+    // the jump-ahead table has ITAL_JUMP_BITS rows (one 3x3 matrix pair per bit of the offset): a candidate's offset is at most
+    // (its list position) x draws_out.  With explicit list positions (gpos) / offsets (draw_off) the caller vouches for them.
+    if (!d->gpos && !d->draw_off && d->draws_out > 0) {
+        const long double most = (long double)(d->pos_offset + d->n_cand) * (long double)d->draws_out;
+        if (most >= (long double)((uint64_t)1 << ITAL_JUMP_BITS))
+            return ital_fail(-22, "ital_score_generic: stream offset beyond 2^ITAL_JUMP_BITS uniforms (list position x draws per candidate)");
+    }
     GArgs a;
     a.d = *d;
     const int slab = nUmax * (nUmax + 1) / 2 + 2 * nUmax;

@@ -13,6 +13,7 @@ the HIP kernels of libital_hip.so; torch only owns the device buffers and the st
 """
 import ctypes
 import os
+import time
 
 import numpy as np
 import torch
@@ -200,6 +201,8 @@ class GaussianProcess(object):
             raise ValueError("ind and y differ in length")
         if len(ind) == 0:
             return self
+        hc = getattr(self, "host_clock", None)       # bench.py: where the host's time between two rounds goes
+        t0 = time.perf_counter() if hc is not None else 0.0
         if row_cache is not None and all(i in row_cache[1] for i in ind):
             if len(ind) <= 16:
                 self._append_staged(row_cache[0], [row_cache[1][i] for i in ind], y)
@@ -211,7 +214,11 @@ class GaussianProcess(object):
         self.ind += ind
         self.y = y.copy() if self.y is None else np.concatenate((self.y, y))
         self.appends.append(len(ind))
+        t1 = time.perf_counter() if hc is not None else 0.0
         self._replicate_mean()
+        if hc is not None:
+            hc["append_s"] = hc.get("append_s", 0.0) + (t1 - t0)
+            hc["means_s"] = hc.get("means_s", 0.0) + (time.perf_counter() - t1)
         return self
 
     def update_points(self, points, y, ind=None):

@@ -400,7 +400,7 @@ class ITAL(ActiveRetrievalBase):
                 # the reference's serial loop has now consumed this many uniforms of mvndst's stream
                 stream.advance(n_alive * (2 << t) * mvn_stream.draws_per_call(t))
                 n_alive -= 1
-            host = b["ret"].cpu().tolist()     # the only synchronisation of the round: the picks and the status word
+            host = self._download(b["ret"], "the picks of the round").tolist()     # the only synchronisation of the round: the picks and the status word
             ret, status = host[:k], host[b["kmax"]]   # status: OR over the greedy steps and over all ranks (same everywhere)
             if status & 6:
                 # linearly dependent variables inside a batch (duplicate samples), or a simulated update that does not pin the
@@ -430,6 +430,22 @@ class ITAL(ActiveRetrievalBase):
         bounds = [sharding.row_range(gp.n_total, gp.world, r)[0] for r in range(gp.world)] + [gp.n_total]
         sizes = np.diff([candidates.count_below(x) for x in bounds])
         return bool(sizes.min() >= 1 and sizes.max() <= _FUSED_SELECT_MAX)
+
+    def _download(self, tensor, what):
+        """Device -> host copy of a round's result.  On several ranks it is the point where this rank waits for the round's
+        collectives: bounded (ITAL_EXCHANGE_TIMEOUT_S) and with the raw communicator's asynchronous errors polled
+        (sharding.await_download) -- a rank that dies mid-round must not leave the others waiting for ever."""
+        gp = self.gp
+        if not gp.collective:
+            return tensor.cpu()
+        kind = getattr(self, "_transport", None)
+        kind = kind[1] if kind else None
+        comm = kind[1] if kind and kind[0] == "nccl" else None
+        if comm is None:
+            e = sharding._RAW_COMMS.get((id(gp.group), str(gp.device)))      # the step path uses the raw communicator as well
+            comm = e[1] if e else None
+        name = {"nccl": "raw_nccl", "host": "host"}[kind[0]] if kind else ("raw_nccl (per step)" if comm else "torch_dist")
+        return sharding.await_download(tensor, what, gp.group, gp.device, comm, gp.rank, gp.world, name)
 
     def _round_transport(self):
         """How ital_fetch_round exchanges the ranks' records: ("nccl", ncclComm_t of the process group -- the communicator
@@ -467,9 +483,8 @@ class ITAL(ActiveRetrievalBase):
                 try:
                     sharding.gather_records(b["rec"], b["rec_all"], group)
                     return 0
-                except Exception:      # noqa: BLE001 -- must not unwind through the C frames
-                    import traceback
-                    traceback.print_exc()
+                except Exception as e:      # noqa: BLE001 -- must not unwind through the C frames
+                    b["exchange_exc"] = e   # re-raised by the caller of ital_fetch_round (an ExchangeError: deadline / lost peer)
                     return -5
             b["exchange_cb"] = cb = _lib.EXCHANGE_FN(exchange)
         return cb
@@ -552,6 +567,7 @@ class ITAL(ActiveRetrievalBase):
         the list is the previous one minus the previous batch (the retrieval loop: fetch, label the batch, fetch), it is
         compacted there by its alive flags instead of being rebuilt and uploaded; and the descriptor of such a next round
         is filled in while the GPU still works on the current one."""
+        t_enter = time.perf_counter()
         lib = _lib.lib()
         gp = self.gp
         dev = gp.device
@@ -626,7 +642,12 @@ class ITAL(ActiveRetrievalBase):
                 if hc.get("t_download") is not None:
                     hc["gap_s"] += t_call - hc["t_download"]
                     hc["gaps"] += 1
-            check(lib.ital_fetch_round(ctypes.byref(r), st))
+                    hc["prologue_s"] = hc.get("prologue_s", 0.0) + (t_call - t_enter)
+            rc = lib.ital_fetch_round(ctypes.byref(r), st)
+            if rc and b.get("exchange_exc") is not None:      # the host transport's callback failed: its own error, not the C one
+                exc, b["exchange_exc"] = b["exchange_exc"], None
+                raise exc
+            check(rc)
             stream.state, stream.draws = p["state_after"], stream.draws + p["draws"]
             if self.profile is not None:
                 self.profile += p["events"]
@@ -638,7 +659,7 @@ class ITAL(ActiveRetrievalBase):
                                                       n_loc, n_loc if gp.collective else n - k, lo)
             if hc is not None:
                 hc["enqueue_s"] += time.perf_counter() - t_call     # the call itself + the next round's descriptor (GPU busy)
-            host = b["ret"].cpu().tolist()     # the only synchronisation of the round: the picks and the status word
+            host = self._download(b["ret"], "the picks of the round").tolist()     # the only synchronisation of the round: the picks and the status word
             if hc is not None:
                 hc["t_download"] = time.perf_counter()
             ret, status = host[:k], host[b["kmax"]]
@@ -947,7 +968,7 @@ class ITAL(ActiveRetrievalBase):
                                             _ptr(gp.V), gp.ldv, gp.m, gp.cap, _ptr(C), gp.ldv, nE, kmax, _ptr(gp.status),
                                             _ptr(b["work"]), _ptr(b["rec"]), st))
                 recs = sharding.gather_records(b["rec"], b["rec_all"], gp.group) if gp.collective else b["rec"].unsqueeze(0)
-                recs_h = recs.cpu().numpy()          # host synchronisation of this greedy step
+                recs_h = self._download(recs, "the records of greedy step %d" % t).numpy()          # host synchronisation of this greedy step
                 keep.clear()
                 w = sharding.winner(recs_h, 0)
                 rec = recs_h[w]
@@ -975,7 +996,7 @@ class ITAL(ActiveRetrievalBase):
                     pick_pos.append(nE)
                     E.append(pick)
             if not subset_mode:
-                host = b["ret"].cpu().tolist()        # picks and the status word (OR over steps and ranks)
+                host = self._download(b["ret"], "the picks of the round").tolist()        # picks and the status word (OR over steps and ranks)
                 picks, status = host[:k], host[kmax]
             else:
                 status = None                         # only the replicated Cholesky append reports here: same on all ranks

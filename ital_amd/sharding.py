@@ -178,6 +178,74 @@ def _raw_comm_probe(dev, world, rank, comm):
     return bool(torch.equal(recv.cpu(), want))
 
 
+class ExchangeError(RuntimeError):
+    """The record exchange of a greedy step did not complete: a deadline passed with the collective still pending (a rank
+    that died or never entered it), or RCCL reported an asynchronous error on the communicator.  The process should end
+    (a process that has touched the GPU is not restarted in place); the message names rank, world, transport and what the
+    rank was waiting for."""
+
+
+def exchange_timeout_s():
+    """Seconds a rank waits for a round's collectives before it gives up (ITAL_EXCHANGE_TIMEOUT_S, default 120; <= 0: no
+    deadline -- the behaviour before round 5)."""
+    import os
+    try:
+        return float(os.environ.get("ITAL_EXCHANGE_TIMEOUT_S", "120"))
+    except ValueError:
+        return 120.0
+
+
+def comm_error(comm):
+    """None, or what RCCL's progress thread reports on the raw communicator (ital_exchange_error -> ncclCommGetAsyncError)."""
+    if not comm:
+        return None
+    import ctypes
+    from . import _lib
+    err = ctypes.c_int(-1)
+    rc = _lib.lib().ital_exchange_error(comm, ctypes.byref(err))
+    if rc == -5:
+        return _lib.lib().ital_last_error().decode()
+    return None          # 0: healthy; -38: this RCCL has no such entry point (nothing to poll)
+
+
+def await_download(tensor, what, group=None, device=None, comm=None, rank=0, world=1, transport=None, timeout_s=None):
+    """`tensor.cpu()` with a deadline: the device-to-host copy of a round's picks is enqueued behind the round's kernels and
+    collectives; the host waits for it with an event it QUERIES (never an unbounded synchronize), polls the communicator's
+    asynchronous error state meanwhile and raises ExchangeError when the deadline passes or RCCL reports a failure.  One
+    rank without a collective: a plain synchronous copy (nothing can stall it but the device itself).
+    Counterpart of the parent noticing a dead worker of the reference's Pool (ital/ital.py:124-126)."""
+    import time
+    import torch
+    if world <= 1 and not comm:
+        return tensor.cpu()
+    limit = exchange_timeout_s() if timeout_s is None else timeout_s
+    if limit <= 0:
+        return tensor.cpu()
+    host = torch.empty(tensor.shape, dtype=tensor.dtype, pin_memory=True)
+    host.copy_(tensor, non_blocking=True)
+    done = torch.cuda.Event()
+    done.record(torch.cuda.current_stream(tensor.device))
+    t0 = time.perf_counter()
+    next_poll = 0.05
+    spins = 0
+    while not done.query():
+        spins += 1
+        waited = time.perf_counter() - t0
+        if waited >= next_poll:
+            next_poll = waited + 0.25
+            err = comm_error(comm)
+            if err:
+                raise ExchangeError("ital_amd: rank %d of %d: RCCL reports an error on the communicator while waiting for %s "
+                                    "(transport %s): %s" % (rank, world, what, transport, err))
+        if waited > limit:
+            raise ExchangeError("ital_amd: rank %d of %d: %s did not arrive within %.1f s (transport %s): a collective of the "
+                                "round is still pending -- another rank died or never entered it (ITAL_EXCHANGE_TIMEOUT_S "
+                                "sets the deadline).  This process should exit now." % (rank, world, what, limit, transport))
+        if spins > 2000:
+            time.sleep(0.0002)      # a long round: stop burning the core (the first ~ms are polled back to back)
+    return host
+
+
 def gather_records(record, out, group=None):
     """ONE collective per greedy step: every rank contributes its fixed-size record, all ranks receive all of them.
     `record` [R], `out` [world, R] (same dtype/device)."""
@@ -195,14 +263,33 @@ def gather_records(record, out, group=None):
             _lib.check(_lib.lib().ital_select_exchange(record.data_ptr(), out.data_ptr(), record.numel(), comm,
                                                        torch.cuda.current_stream(record.device).cuda_stream))
             return out
-    if _host_staged(record, group):
+    if _host_staged(record, group) or not record.is_cuda:
         host = [torch_like_cpu(record) for _ in range(world)]
-        dist.all_gather(host, record.cpu(), group=group)
+        _bounded(dist.all_gather(host, record.cpu(), group=group, async_op=True), "the all-gather of the ranks' records", group)
         for w in range(world):
             out[w].copy_(host[w])
         return out
     dist.all_gather_into_tensor(out.view(-1), record, group=group)   # one contiguous [world * R] receive buffer
     return out
+
+
+def _bounded(work, what, group=None):
+    """Waits for a host-side (gloo) collective with the exchange deadline; ExchangeError when it passes or the backend fails."""
+    import datetime
+    import torch.distributed as dist
+    limit = exchange_timeout_s()
+    try:
+        if limit > 0:
+            ok = work.wait(datetime.timedelta(seconds=limit))
+        else:
+            ok = work.wait()
+    except Exception as e:      # noqa: BLE001 -- gloo raises RuntimeError / DistBackendError on a time-out or a lost peer
+        raise ExchangeError("ital_amd: rank %d of %d: %s did not complete within %.1f s (%s: %s)"
+                            % (dist.get_rank(group), dist.get_world_size(group), what, limit, type(e).__name__,
+                               str(e).splitlines()[0] if str(e) else "")) from e
+    if ok is False:
+        raise ExchangeError("ital_amd: rank %d of %d: %s did not complete within %.1f s"
+                            % (dist.get_rank(group), dist.get_world_size(group), what, limit))
 
 
 def torch_like_cpu(t):
@@ -215,7 +302,7 @@ def all_reduce_sum(t, group=None):
     import torch.distributed as dist
     if _host_staged(t, group):
         h = t.cpu()
-        dist.all_reduce(h, op=dist.ReduceOp.SUM, group=group)
+        _bounded(dist.all_reduce(h, op=dist.ReduceOp.SUM, group=group, async_op=True), "an all-reduce of replicated rows", group)
         t.copy_(h)
         return t
     dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
@@ -228,7 +315,7 @@ def broadcast(t, src, group=None):
     src_global = dist.get_global_rank(group, src) if group is not None else src
     if _host_staged(t, group):
         h = t.cpu()
-        dist.broadcast(h, src=src_global, group=group)
+        _bounded(dist.broadcast(h, src=src_global, group=group, async_op=True), "a broadcast", group)
         t.copy_(h)
         return t
     dist.broadcast(t, src=src_global, group=group)
@@ -241,7 +328,7 @@ def all_gather_parts(loc, sizes, group=None):
     import torch.distributed as dist
     if _host_staged(loc, group):
         parts = [torch.empty(s, dtype=loc.dtype) for s in sizes]
-        dist.all_gather(parts, loc.cpu().contiguous(), group=group)
+        _bounded(dist.all_gather(parts, loc.cpu().contiguous(), group=group, async_op=True), "the all-gather of the means", group)
         return torch.cat(parts).to(loc.device)
     parts = [torch.empty(s, dtype=loc.dtype, device=loc.device) for s in sizes]
     dist.all_gather(parts, loc.contiguous(), group=group)

@@ -235,3 +235,57 @@ def test_bench_compares_the_ranks_picks():
     for r in (0, 1):
         assert res[r][1] is True and res[r][2] is False
         assert res[r][3] == [1.5, 2.5]
+
+
+# ---------------------------------------------------------------------------------------------- failure detection (round 5)
+def _stall_worker(rank, world, port, ret):
+    """Rank 1 never enters the exchange (it 'died' mid-round): rank 0 must raise within the deadline, not wait for ever."""
+    import time
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ["ITAL_EXCHANGE_TIMEOUT_S"] = "2"
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    rec = torch.full((REC,), float(rank), dtype=torch.float64)
+    out = torch.zeros((world, REC), dtype=torch.float64)
+    sharding.gather_records(rec, out, None)                      # a healthy exchange first
+    assert out[:, 0].tolist() == [0.0, 1.0]
+    if rank == 1:
+        time.sleep(8)                                            # stalls "inside the round"
+        ret[rank] = "stalled"
+        os._exit(0)                                              # (no orderly shutdown of the group: the peer has given up)
+    t0 = time.time()
+    try:
+        sharding.gather_records(rec, out, None)
+        ret[rank] = "no error"
+    except sharding.ExchangeError as e:
+        ret[rank] = ("ExchangeError", time.time() - t0, str(e))
+    os._exit(0)
+
+
+def test_stalled_rank_raises_within_the_deadline():
+    """SURVEY section 5 'failure detection': the record exchange is bounded (ITAL_EXCHANGE_TIMEOUT_S) -- the counterpart of
+    multiprocessing.Pool raising in the parent when a worker dies (reference ital/ital.py:124-126)."""
+    port = _free_port()
+    with mp.Manager() as mgr:
+        ret = mgr.dict()
+        ctx = mp.spawn(_stall_worker, args=(2, port, ret), nprocs=2, join=False)
+        import time
+        deadline = time.time() + 60
+        while time.time() < deadline and not all(not p.is_alive() for p in ctx.processes):
+            time.sleep(0.2)
+        for p in ctx.processes:
+            if p.is_alive():
+                p.kill()
+        got = dict(ret)
+    assert got.get(0) is not None and got[0][0] == "ExchangeError", got
+    assert got[0][1] < 6.0, got            # within the 2 s deadline (plus slack), not gloo's 30 minutes
+    assert "rank 0 of 2" in got[0][2] and "all-gather" in got[0][2]
+
+
+def test_exchange_timeout_setting(monkeypatch):
+    monkeypatch.setenv("ITAL_EXCHANGE_TIMEOUT_S", "7.5")
+    assert sharding.exchange_timeout_s() == 7.5
+    monkeypatch.setenv("ITAL_EXCHANGE_TIMEOUT_S", "nonsense")
+    assert sharding.exchange_timeout_s() == 120.0
+    monkeypatch.delenv("ITAL_EXCHANGE_TIMEOUT_S")
+    assert sharding.exchange_timeout_s() == 120.0

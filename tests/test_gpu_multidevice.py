@@ -23,9 +23,24 @@ import test_gpu_multirank as mr  # noqa: E402
 import test_gpu_multirank_scale as mrs  # noqa: E402
 
 NDEV = _ranks.device_count()
-# at most 4 ranks + the runner: the boxes allow few processes on the GPUs at once
-WORLDS = [pytest.param(w, marks=pytest.mark.skipif(NDEV < w, reason="%d GPUs visible, %d needed (one device per rank)" % (NDEV, w)))
-          for w in (2, 4)]
+# (the pool's one-GPU boxes allow few processes on a card at once; here every rank has a card of its own)
+def _worlds(sizes):
+    return [pytest.param(w, marks=pytest.mark.skipif(NDEV < w, reason="%d GPUs visible, %d needed (one device per rank)" % (NDEV, w)))
+            for w in sizes]
+
+
+WORLDS = _worlds((2, 4))
+# the communicator size of the scaling run (bench.py --gpus 8): one cheap golden session and the scaling workload itself --
+# one process per device (each card hosts one rank; the runner itself never initialises a GPU)
+WORLDS_8 = _worlds((2, 4, 8))
+
+
+@pytest.mark.skipif(NDEV < 8, reason="%d GPUs visible, 8 needed (one device per rank)" % NDEV)
+def test_eight_ranks_on_their_own_devices_match_golden():
+    """The golden USPS session with the rows over EIGHT devices: the world size of the scaling run."""
+    res = _ranks.spawn(mr._worker, 8, "usps500", "rccl")
+    mr.check_golden("usps500", res)
+    assert all(r[5] == "nccl" for r in res)
 
 
 @pytest.mark.parametrize("world", WORLDS)
@@ -88,7 +103,7 @@ def test_one_rank_declining_the_raw_communicator_keeps_all_on_torch_distributed(
     assert "rank 1" in res[1][2] and "another rank" in res[0][2]
 
 
-@pytest.mark.parametrize("world", WORLDS)
+@pytest.mark.parametrize("world", WORLDS_8)
 def test_one_million_x512_k4_over_rccl(world):
     """The scaling curve's workload (bench.py `scaling_workload`) on `world` devices against the one-rank run: identical
     picks, sampled MI to 1e-12, both random streams at the same position."""

@@ -283,7 +283,7 @@ def test_c5_share_125000x512_k16_monte_carlo(dev):
     _monte_carlo_k16_case(dev, 125_000, {1: 48, 2: 48, 3: 32, 5: 24, 8: 16, 12: 8, 16: 8}, "C5' share")
 
 
-@pytest.mark.skipif(not os.environ.get("ITAL_TEST_C5_FULL"), reason="2.5 minutes of GPU: set ITAL_TEST_C5_FULL=1 (log: profiles/r4_c5_full.log)")
+@pytest.mark.skipif(bool(os.environ.get("ITAL_TEST_SKIP_C5_FULL")), reason="ITAL_TEST_SKIP_C5_FULL set (~2 minutes of GPU)")
 def test_c5_whole_one_million_x512_k16_monte_carlo(dev):
     """BASELINE configs[4] in one piece on ONE GPU: 1 000 000 x 512, k = 16, monte_carlo_num_rel = 1 -- the N = 1 anchor of
     the k = 16 curve (8 GPUs take an eighth each).  Oracle checks at steps 1, 4, 8, 16."""

@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Which kernels a committed profile was taken with: sha256 over the kernel sources (ital_amd/csrc/*, include/ital_hip.h --
-stable across rebuilds of the same code, unlike the bytes of a rebuilt .so) plus, for the record, the commit and the sha256
+stable across rebuilds of the same code, unlike the bytes of a rebuilt .so; since round 5 over the include closure of the
+translation units the profiled workload runs, so that a change to another scorer does not void a profile) plus, for the record, the commit and the sha256
 of the library binary that ran.  bench.py quotes counters out of committed files only while `csrc_sha` still matches.
 
     python tools/stamp.py profiles/r4_stamp.json profiles/r4_headline_pmc_summary.csv profiles/r4_round_gaps.json ...
@@ -17,15 +18,49 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def csrc_sha():
+CSRC = os.path.join(ROOT, "ital_amd", "csrc")
+HEADER = os.path.join(ROOT, "include", "ital_hip.h")
+# translation units whose kernels a profile's numbers come from (by the workload in the file name, profiles/r5_<workload>_*);
+# anything else: every source of the library
+UNITS = {"headline": ["score.hip", "round.hip", "rbf.hip", "chol.hip", "select.hip"], "k8": ["score.hip", "round.hip", "rbf.hip"],
+         "general": ["gen_pipeline.hip", "score_generic.hip"], "c5": ["gen_pipeline.hip", "score_generic.hip"],
+         "mcmi": ["mcmi.hip"], "kcols": ["rbf.hip"], "cesub": ["score_generic.hip"], "round": ["score.hip", "round.hip", "rbf.hip", "chol.hip", "select.hip"]}
+
+
+def closure(units):
+    """The units and every file of ital_amd/csrc / include they include, transitively (sorted base names -> paths)."""
+    import re
+    todo, seen = [os.path.join(CSRC, u) for u in units], {}
+    while todo:
+        path = todo.pop()
+        base = os.path.basename(path)
+        if base in seen or not os.path.isfile(path):
+            continue
+        seen[base] = path
+        with open(path) as f:
+            for inc in re.findall(r'^\s*#\s*include\s+"([^"]+)"', f.read(), flags=re.M):
+                todo.append(HEADER if inc == "ital_hip.h" else os.path.join(CSRC, inc))
+    return dict(sorted(seen.items()))
+
+
+def units_of(profile_name):
+    """Translation units behind a committed profile, from the workload in its file name (r5_<workload>_...)."""
+    parts = os.path.basename(profile_name).split("_")
+    return UNITS.get(parts[1]) if len(parts) > 1 else None
+
+
+def csrc_sha(units=None):
+    """sha256 (16 hex digits) over the kernel sources: the include closure of `units`, or all of ital_amd/csrc + the header."""
     h = hashlib.sha256()
-    d = os.path.join(ROOT, "ital_amd", "csrc")
-    for name in sorted(os.listdir(d)) + [os.path.join("..", "..", "include", "ital_hip.h")]:
-        path = os.path.join(d, name)
-        if os.path.isfile(path):
-            h.update(os.path.basename(name).encode() + b"\0")
-            with open(path, "rb") as f:
-                h.update(f.read())
+    if units:
+        files = closure(units)
+    else:
+        files = {name: os.path.join(CSRC, name) for name in sorted(os.listdir(CSRC)) if os.path.isfile(os.path.join(CSRC, name))}
+        files["ital_hip.h"] = HEADER
+    for name, path in files.items():
+        h.update(name.encode() + b"\0")
+        with open(path, "rb") as f:
+            h.update(f.read())
     return h.hexdigest()[:16]
 
 
@@ -50,8 +85,10 @@ def main():
     if os.path.exists(out):
         with open(out) as f:
             stamp = json.load(f)
-    entry = {"csrc_sha": csrc_sha(), "lib_sha256": lib_sha(), "commit": commit() or os.environ.get("ITAL_COMMIT")}
+    entry = None
     for name in files:
+        units = units_of(name)
+        entry = {"csrc_sha": csrc_sha(units), "units": units, "lib_sha256": lib_sha(), "commit": commit() or os.environ.get("ITAL_COMMIT")}
         stamp["profiles/" + os.path.basename(name)] = entry
     with open(out, "w") as f:
         json.dump(stamp, f, indent=1, sort_keys=True)
