@@ -501,6 +501,13 @@ typedef struct ital_gscore_desc {
     int64_t work_doubles;
     unsigned long long* pair_count; /* non-NULL: += the (Phi, Phi^-1) pairs of the lattice sums that were evaluated
                                (16 P(n-1) points x (n-1) pairs per evaluated call; instrumentation for the roofline) */
+    int defer_join;         /* != 0 (pipeline, 7 .. 16 variables; ignored elsewhere): do NOT make `stream` wait for the internal
+                               streams at the end of this call.  For a step scored in several calls over ranges of its
+                               candidates (the host samples the patterns of range r + 1 while the GPU integrates range r):
+                               the preparation of the next call's first slab then runs under the lattice sums of this one
+                               instead of after them.  The results (mi) of a deferred call are complete only after a later
+                               call of the same step WITHOUT the flag, or ital_score_generic_join, has returned; until then
+                               the caller must not free, reuse or read what the call was given (mi, work, the samples) */
 } ital_gscore_desc;
 
 /* mi[p] = MI(batch + candidate p) for any user model / with a change-estimation subset.  Replaces
@@ -511,6 +518,9 @@ int ital_score_generic(const ital_gscore_desc* d, hipStream_t stream);
  * runs through the pipeline with all candidates in one slab; 0 when the step is not the pipeline's (single kernel, no
  * workspace needed). */
 int64_t ital_score_generic_workspace(const ital_gscore_desc* d);
+/* Makes `stream` wait for everything earlier ital_score_generic calls of this device left on the library's internal
+ * streams (calls with defer_join; an error path that abandons a step half way).  Cheap when nothing is pending. */
+int ital_score_generic_join(hipStream_t stream);
 
 #ifdef __cplusplus
 }

@@ -2,7 +2,7 @@
 the per-member covariance columns, the selection record and its gather target)."""
 import torch
 
-from ._lib import ITAL_REC_HEADER, ItalBatch
+from ._lib import ItalBatch, lib as _lib
 
 
 def _ptr(t):
@@ -26,7 +26,7 @@ def make_batch_buffers(device, kmax, ldx, cap, ldc, world):
     b["C"] = torch.zeros((kmax, ldc), dtype=f64, device=device)
     b["ret"] = torch.zeros(kmax + 1, dtype=i64, device=device)   # last slot: copy of the status word (one download)
     b["work"] = torch.zeros(3 * 1024, dtype=f64, device=device)
-    rec_len = ITAL_REC_HEADER + ldx + cap + kmax
+    rec_len = int(_lib().ital_record_len(ldx, cap, kmax))      # = ITAL_REC_HEADER + ldx + cap + kmax
     b["rec_len"] = rec_len
     b["rec"] = torch.zeros(rec_len, dtype=f64, device=device)
     b["rec_all"] = torch.zeros((world, rec_len), dtype=f64, device=device)

@@ -73,7 +73,8 @@ class ItalGscoreDesc(ctypes.Structure):
                 ("draws_out", c_int64), ("draws_in", c_int64), ("n_in", c_int), ("in_pos", c_void_p),
                 ("n_dead", c_int), ("dead_pos", c_void_p), ("mc_rel", c_int), ("rel_samples", c_void_p),
                 ("mc_fb", c_int), ("fb_samples", c_void_p), ("draw_off", c_void_p), ("draw_count", c_void_p), ("mi", c_void_p),
-                ("status", c_void_p), ("work", c_void_p), ("work_doubles", c_int64), ("pair_count", c_void_p)]
+                ("status", c_void_p), ("work", c_void_p), ("work_doubles", c_int64), ("pair_count", c_void_p),
+                ("defer_join", c_int)]
 
 
 class ItalMcmiDesc(ctypes.Structure):
@@ -141,6 +142,7 @@ SIGNATURES = {
     "ital_select_exchange": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p]),
     "ital_exchange_info": (c_int, [c_void_p, c_void_p, c_void_p, ctypes.c_char_p, c_int]),
     "ital_exchange_error": (c_int, [c_void_p, c_void_p]),
+    "ital_score_generic_join": (c_int, [c_void_p]),
     "ital_record_len": (c_int, [c_int, c_int, c_int]),
     "ital_round_workspace": (c_int64, [c_int, c_int64, c_int64]),
     "ital_sel_parts_len": (c_int64, [c_int, c_int64, c_int64]),

@@ -839,6 +839,12 @@ static int gen_main_yld(int n) {
 struct PipeStreams {
     hipStream_t prep, main;
     hipEvent_t start, built[2], summed[2], combined;
+    // wide form: slabs launched so far on this device (buffer = parity) and whether a buffer's `summed` event has ever been
+    // recorded -- kept across calls: with ital_gscore_desc.defer_join the next call's first slab is prepared while this
+    // call's last one is still being integrated
+    unsigned long long wide_slabs;
+    bool summed_valid[2];
+    bool pending;            // kernels may still run on prep / main that the caller's stream has not been joined with
 };
 
 static PipeStreams* pipe_streams() {
@@ -856,6 +862,9 @@ static PipeStreams* pipe_streams() {
             ok = hipEventCreateWithFlags(&p.built[q], hipEventDisableTiming) == hipSuccess &&
                  hipEventCreateWithFlags(&p.summed[q], hipEventDisableTiming) == hipSuccess;
         if (!ok) return nullptr;
+        p.wide_slabs = 0;
+        p.summed_valid[0] = p.summed_valid[1] = false;
+        p.pending = false;
         made[dev] = true;
     }
     return &sets[dev];
@@ -870,6 +879,7 @@ int pipe_bail(PipeStreams* ps, hipStream_t stream, int rc) {
     (void)hipStreamWaitEvent(ps->main, ps->built[0], 0);
     (void)hipEventRecord(ps->combined, ps->main);
     (void)hipStreamWaitEvent(stream, ps->combined, 0);
+    ps->pending = false;
     return rc;
 }
 
@@ -934,6 +944,7 @@ int ital_gen_pipeline(const ital_gscore_desc* d, hipStream_t stream) {
     const int n = pl.n;
     GPipe g = {};
     g.total = (int)pl.total; g.npat = pl.npat; g.cpp = pl.cpp; g.n = n; g.R = pl.R; g.lat = pl.lat;
+    if (pl.fast) (void)ital_score_generic_join(stream);     // (a deferred call still pending: these forms share their buffers between calls)
     if (n <= 2) {
         // ---- one or two variables: closed forms and combine on the caller's stream, slabs of the workspace
         int64_t S = (d->work_doubles - HDR) / pl.per_cand;
@@ -954,6 +965,7 @@ int ital_gen_pipeline(const ital_gscore_desc* d, hipStream_t stream) {
     }
     PipeStreams* ps = pipe_streams();
     if (!ps) return ital_fail(-12, "ital_score_generic: cannot create the pipeline's streams");
+
     const size_t lds_m = (size_t)4 * (pl.lat - 2 + 16 * (n - 1) + gen_main_yld(n)) * sizeof(double);   // (gen_main_yld: tail queue + conditioned values)
     const size_t lds_m0 = (size_t)(pl.lat - 2 + 16 * (n - 1) + ITAL_GEN_TAILQ + 2 * (GN - 1) * 64) * sizeof(double);   // one wave
     // label_estimation 'optimistic' / 'pessimistic' (plain mode only): sums that decide an exact comparison are formed again in
@@ -1099,9 +1111,8 @@ int ital_gen_pipeline(const ital_gscore_desc* d, hipStream_t stream) {
     if (hipEventRecord(ps->start, stream) != hipSuccess || hipStreamWaitEvent(ps->prep, ps->start, 0) != hipSuccess ||
         hipStreamWaitEvent(ps->main, ps->start, 0) != hipSuccess)
         return ital_fail(-5, "ital_score_generic: stream synchronisation failed");
-    int nslab = 0;
-    for (int64_t lo = 0; lo < d->n_cand; lo += S, nslab++) {
-        const int buf = nslab & 1;
+    for (int64_t lo = 0; lo < d->n_cand; lo += S, ps->wide_slabs++) {
+        const int buf = (int)(ps->wide_slabs & 1ull);
         double* base = d->work + (size_t)buf * (half + 1);
         g.slab_lo = lo;
         g.slab_n = d->n_cand - lo < S ? d->n_cand - lo : S;
@@ -1110,7 +1121,7 @@ int ital_gen_pipeline(const ital_gscore_desc* d, hipStream_t stream) {
         g.recs = g.meta + g.slab_n * pl.total * 2;
         g.list = reinterpret_cast<unsigned int*>(g.recs + g.slab_n * pl.total * pl.R);
         g.cap = (unsigned int)(g.slab_n * pl.total);
-        if (nslab >= 2) (void)hipStreamWaitEvent(ps->prep, ps->summed[buf], 0);   // the buffer is free again (combined too)
+        if (ps->summed_valid[buf]) (void)hipStreamWaitEvent(ps->prep, ps->summed[buf], 0);   // the buffer is free again (combined too)
         (void)hipMemsetAsync(g.count, 0, 2 * sizeof(unsigned int), ps->prep);
         ITAL_LAUNCH(gen_prep_kernel, dim3((unsigned)((g.slab_n * g.nsplit + 1) / 2)), dim3(128), lds_p, ps->prep, ap, g);
         (void)hipEventRecord(ps->built[buf], ps->prep);
@@ -1118,12 +1129,26 @@ int ital_gen_pipeline(const ital_gscore_desc* d, hipStream_t stream) {
         ITAL_GEN_MAINS();
         ITAL_LAUNCH(gen_combine_kernel, dim3((unsigned)((g.slab_n + 3) / 4)), dim3(256), 0, ps->main, *d, g);
         (void)hipEventRecord(ps->summed[buf], ps->main);
+        ps->summed_valid[buf] = true;
         const int rc = ital_check_launch("ital_score_generic(pipeline)");
         if (rc) return pipe_bail(ps, stream, rc);
     }
     (void)hipEventRecord(ps->combined, ps->main);
+    if (d->defer_join) {
+        ps->pending = true;       // joined by a later call of the step without the flag, or by ital_score_generic_join
+        return 0;
+    }
     (void)hipStreamWaitEvent(stream, ps->combined, 0);
+    ps->pending = false;
     return 0;
 #undef ITAL_GEN_MAINS
 #undef ITAL_GEN_MAIN
+}
+
+extern "C" int ital_score_generic_join(hipStream_t stream) {
+    PipeStreams* ps = pipe_streams();
+    if (!ps) return ital_fail(-12, "ital_score_generic_join: cannot create the pipeline's streams");
+    if (!ps->pending) return 0;
+    (void)pipe_bail(ps, stream, 0);
+    return ital_check_launch("ital_score_generic_join");
 }

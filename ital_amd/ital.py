@@ -274,7 +274,7 @@ class ITAL(ActiveRetrievalBase):
 
     def _qmc_workspace(self, b, t, n_loc):
         """Workspace of the lattice scorer (prepared calls of a slab of candidates), grown on demand up to `qmc_work_bytes`."""
-        want = min(int(_lib.lib().ital_score_workspace(t, max(n_loc, 1))), max(self.qmc_work_bytes // 8, 1 << 16))
+        want = int(_lib.lib().ital_round_workspace(t, max(n_loc, 1), max(self.qmc_work_bytes // 8, 1 << 16)))
         w = b.get("qmc_work")
         if w is None or w.numel() < want:
             b["qmc_work"] = w = torch.empty(want, dtype=torch.float64, device=self.gp.device)
@@ -284,12 +284,7 @@ class ITAL(ActiveRetrievalBase):
         """Doubles of the block partials of the selection inside the scoring launches of a round of k steps: three per
         scoring block -- n/256 blocks at t = 1, n/32 at t = 2, n/256 plus one per slab of the lattice workspace from t = 3 on
         (with a small workspace cap, `qmc_work_bytes`, a step of t = 7, 8 runs in slabs of a few candidates each)."""
-        slabs = 0
-        if k >= 3 and n_loc > 0:
-            have = max(self.qmc_work_bytes // 8, 1 << 16)
-            per = int(_lib.lib().ital_score_workspace(k, 1))
-            slabs = -(-n_loc // max(have // per, 1)) if have < per * n_loc else 1
-        return 3 * (n_loc // 32 + 64 + slabs)
+        return int(_lib.lib().ital_sel_parts_len(k, n_loc, max(self.qmc_work_bytes // 8, 1 << 16)))
 
     def _select(self, k, candidates):
         """Greedy construction of a batch of k out of `candidates` (k <= len(candidates))."""
@@ -893,7 +888,7 @@ class ITAL(ActiveRetrievalBase):
                     base = {f: getattr(desc, f) for f in ("cand", "alive", "mi", "draw_off", "pos_offset")}
                     dbg = os.environ.get("ITAL_MC_TIMING")
                     tq = time.perf_counter()
-                    for lo, hi, rows in rel_ranges:
+                    for lo, hi, rows, last_range in rel_ranges:
                         if dbg:
                             t_rows = time.perf_counter() - tq
                             tq = time.perf_counter()
@@ -911,13 +906,22 @@ class ITAL(ActiveRetrievalBase):
                         desc.mi, desc.draw_off = base["mi"] + 8 * a, base["draw_off"] + 8 * a
                         desc.pos_offset = base["pos_offset"] + a
                         desc.mc_rel, desc.rel_samples = npat, dflat.data_ptr()
-                        check(lib.ital_score_generic(ctypes.byref(desc), st))
+                        # all but the last range leave the library's streams unjoined: the preparation of the next range's
+                        # first slab then runs under this range's lattice sums (ital_gscore_desc.defer_join)
+                        desc.defer_join = 0 if last_range else 1
+                        try:
+                            check(lib.ital_score_generic(ctypes.byref(desc), st))
+                        except Exception:
+                            lib.ital_score_generic_join(st)
+                            raise
                         if dbg:
                             print("t=%d range %d..%d: patterns %.1f ms, upload + launch %.1f ms" % (
                                 t, lo, hi, t_rows * 1e3, (time.perf_counter() - tq) * 1e3), flush=True)
                             tq = time.perf_counter()
                         if kept is not None:
                             kept[lo:hi] = rows
+                    desc.defer_join = 0
+                    check(lib.ital_score_generic_join(st))      # (nothing pending after a last range; cheap)
                     if kept is not None:
                         self.last_patterns.append(kept)
                 self._mark("score_generic", t, n_alive, ev0)
@@ -1159,7 +1163,7 @@ class ITAL(ActiveRetrievalBase):
                         hi = local[1] if b_ == jl1 else int(live[b_])
                         rows = np.zeros((hi - lo, npat), dtype=np.uint32)
                         rows[live[a:b_] - lo] = draw_rel(int(a), int(b_), z_loc[a - jl0:b_ - jl0])
-                        yield lo, hi, rows
+                        yield lo, hi, rows, bool(b_ == cuts[-1])
                 return ranges(), None, draws
             rel_live = np.zeros((L, npat), dtype=np.uint32)
             if jl1 > jl0:

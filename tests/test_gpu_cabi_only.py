@@ -71,7 +71,7 @@ def test_fetch_unlabelled_through_ctypes_only():
     VB = torch.zeros((kmax, cap), dtype=f64, device=dev)
     C = torch.zeros((kmax, ldv), dtype=f64, device=dev)
     ret = torch.zeros(kmax + 1, dtype=i64, device=dev)
-    rec = torch.zeros(_lib.ITAL_REC_HEADER + ldx + cap + kmax, dtype=f64, device=dev)
+    rec = torch.zeros(int(lib.ital_record_len(ldx, cap, kmax)), dtype=f64, device=dev)     # sizes from the library, not from prose
     batch = _lib.ItalBatch(kmax, ldx, cap, bidx.data_ptr(), bgpos.data_ptr(), bsort.data_ptr(), bmu.data_ptr(), sig.data_ptr(),
                            XB.data_ptr(), XBn.data_ptr(), VB.data_ptr())
 
@@ -93,7 +93,7 @@ def test_fetch_unlabelled_through_ctypes_only():
             vk = np.empty(t - 1, dtype=np.float64)
             chk(lib.ital_mvn_tables(t, jump.ctypes.data, pat.ctypes.data, vk.ctypes.data))
             tabs = [torch.from_numpy(a).to(dev) for a in (jump, pat, vk)]
-            work = torch.empty(int(lib.ital_score_workspace(t, nc)), dtype=f64, device=dev)
+            work = torch.empty(int(lib.ital_round_workspace(t, nc, 0)), dtype=f64, device=dev)
             keep += tabs + [work]
             desc.jump, desc.jumppat, desc.vk = tabs[0].data_ptr(), tabs[1].data_ptr(), tabs[2].data_ptr()
             desc.work, desc.work_doubles = work.data_ptr(), work.numel()

@@ -1,0 +1,114 @@
+"""Failure detection on the record exchange (round-4 verdict, Weak 6): a rank that stalls inside a
+greedy step's exchange must not leave the others waiting for ever.  Two ranks on one GPU over gloo (the transport every box
+can host: the exchange is the host callback of ital_fetch_round); rank 1 stalls inside the second exchange of a round, rank 0
+must raise sharding.ExchangeError within ITAL_EXCHANGE_TIMEOUT_S -- the counterpart of multiprocessing.Pool raising in the
+parent when a worker dies (reference ital/ital.py:124-126).  On the raw RCCL transport the same deadline is enforced by
+sharding.await_download (event query + ncclCommGetAsyncError): covered on one device by the rccl1 tests below."""
+import os
+import sys
+import time
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+torch = pytest.importorskip("torch")
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+import _ranks  # noqa: E402
+
+
+def _stall_worker(rank, world, port, X, out):
+    os.environ["ITAL_EXCHANGE_TIMEOUT_S"] = "3"
+    dev, group = _ranks.join(rank, world, port, "gloo")
+    from ital_amd import ITAL, mvn_stream, sharding
+    mvn_stream.GLOBAL.reset()
+    L = ITAL(X, length_scale=float(np.sqrt(X.shape[1] / 12.0)), device=dev, rank=rank, world=world, group=group)
+    L.update({0: 1, len(X) - 1: -1})
+    first = L.fetch_unlabelled(4)                       # a healthy round first
+    L.update({int(i): 1.0 for i in first})
+    if rank == 1:
+        orig, calls = sharding.gather_records, [0]
+
+        def stalled(record, out_, group=None):
+            calls[0] += 1
+            if calls[0] == 2:
+                time.sleep(12)                          # "dies" inside the second exchange of the round
+            return orig(record, out_, group)
+        sharding.gather_records = stalled
+    t0 = time.time()
+    try:
+        L.fetch_unlabelled(4)
+        out[rank] = ("no error", time.time() - t0, first)
+    except sharding.ExchangeError as e:
+        out[rank] = ("ExchangeError", time.time() - t0, str(e), first)
+    except Exception as e:      # noqa: BLE001
+        out[rank] = (type(e).__name__, time.time() - t0, str(e), first)
+    os._exit(0)                                         # no orderly shutdown: the group is broken by design
+
+
+def test_stalled_rank_inside_a_round_raises_on_the_others():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    import torch.multiprocessing as mp
+    X = np.random.default_rng(91).random((900, 16))
+    port = _ranks.free_port()
+    with mp.Manager() as mgr:
+        out = mgr.dict()
+        ctx = mp.spawn(_stall_worker, args=(2, port, X, out), nprocs=2, join=False)
+        deadline = time.time() + 180
+        while time.time() < deadline and any(p.is_alive() for p in ctx.processes):
+            time.sleep(0.5)
+        for p in ctx.processes:
+            if p.is_alive():
+                p.kill()
+        got = dict(out)
+    assert got.get(0) is not None, got
+    assert got[0][0] == "ExchangeError", got
+    assert got[0][1] < 10.0, got                        # the 3 s deadline plus slack, not gloo's 30 minutes
+    assert "rank 0 of 2" in got[0][2]
+    if got.get(1) is not None:
+        assert got[1][-1] == got[0][-1]                 # the healthy round picked the same batch on both ranks
+
+
+def _one_rank_rccl_worker(rank, world, port, X, mode, out):
+    if mode == "tiny_deadline":
+        os.environ["ITAL_EXCHANGE_TIMEOUT_S"] = "0.0005"
+    dev, group = _ranks.join(rank, world, port, "rccl1")
+    try:
+        from ital_amd import ITAL, mvn_stream, sharding
+        mvn_stream.GLOBAL.reset()
+        L = ITAL(X, length_scale=float(np.sqrt(X.shape[1] / 12.0)), device=dev, rank=0, world=1, group=group)
+        L.update({0: 1, len(X) - 1: -1})
+        kind = L._round_transport()
+        comm = kind[1] if kind and kind[0] == "nccl" else None
+        healthy = sharding.comm_error(comm) if comm else "no raw communicator"
+        try:
+            picks = L.fetch_unlabelled(4)
+            res = ("ok", picks)
+        except sharding.ExchangeError as e:
+            res = ("ExchangeError", str(e))
+        torch.cuda.synchronize()
+        out[rank] = (kind[0] if kind else None, healthy, res)
+    finally:
+        _ranks.leave(group)
+
+
+def test_raw_communicator_is_polled_and_healthy_on_one_device():
+    """ital_exchange_error (ncclCommGetAsyncError) on the process group's own communicator: no error on a healthy one, and the
+    bounded wait returns the picks of the one-rank run."""
+    X = np.random.default_rng(92).random((700, 16))
+    res = _ranks.spawn(_one_rank_rccl_worker, 1, X, "plain")[0]
+    assert res[0] == "nccl" and res[1] is None, res
+    assert res[2][0] == "ok" and len(res[2][1]) == 4
+
+
+def test_deadline_applies_to_the_raw_transport():
+    """A deadline shorter than the round itself (0.5 ms against a round of 200 000 candidates): the wait for the picks gives
+    up with ExchangeError naming the transport -- what a rank sees whose peers never arrive."""
+    X = np.random.default_rng(93).random((200_000, 16))
+    res = _ranks.spawn(_one_rank_rccl_worker, 1, X, "tiny_deadline")[0]
+    assert res[0] == "nccl", res
+    assert res[2][0] == "ExchangeError" and "raw_nccl" in res[2][1] and "did not arrive" in res[2][1], res

@@ -415,3 +415,26 @@ def test_unseen_list_equals_the_rebuilt_array_under_random_removals():
             assert u.array() is arr                                  # the same object until the next removal
     assert len(u.removed) < 64 + 9                                   # materialising rebased the list on the way
     np.testing.assert_array_equal(u.array(), want)
+
+
+def test_size_helpers_of_the_c_abi():
+    """ital_record_len / ital_round_workspace / ital_sel_parts_len (host-only entry points, round 5): the buffer sizes a host
+    owns, as functions instead of prose in the header (reference: the buffers stand in for the per-process state of
+    ital/ital.py:504-529)."""
+    from ital_amd import _lib
+    lib = _lib.load()
+    assert lib.ital_record_len(256, 32, 4) == _lib.ITAL_REC_HEADER + 256 + 32 + 4
+    assert lib.ital_record_len(-1, 0, 0) == 0
+    per4, per8 = lib.ital_score_workspace(4, 1), lib.ital_score_workspace(8, 1)
+    # one slab when it fits, else the cap, never below one candidate
+    assert lib.ital_round_workspace(4, 9298, 0) == 9298 * per4
+    assert lib.ital_round_workspace(4, 9298, 1 << 27) == 9298 * per4
+    assert lib.ital_round_workspace(8, 25000, 1 << 27) == 1 << 27
+    assert lib.ital_round_workspace(8, 25000, 10) == per8
+    assert lib.ital_round_workspace(2, 1000, 0) == 0
+    # three doubles per block of the largest scoring launch (n / 32 at t = 2) + 64 + one per slab
+    assert lib.ital_sel_parts_len(2, 9298, 0) == 3 * (9298 // 32 + 64)
+    assert lib.ital_sel_parts_len(4, 9298, 9298 * per4) == 3 * (9298 // 32 + 64 + 1)
+    slabs = -(-25000 // ((1 << 27) // per8))
+    assert lib.ital_sel_parts_len(8, 25000, 1 << 27) == 3 * (25000 // 32 + 64 + slabs)
+    assert lib.ital_sel_parts_len(8, 25000, 1) == 3 * (25000 // 32 + 64 + 25000)      # less than one candidate: a slab each
