@@ -42,16 +42,17 @@
 // issue slots filled (0.67 - 0.70 at two waves per SIMD, 0.77 - 0.81 at three, 0.87 at four).
 //   T      7     8     9     10    11    12    13    14    15    16
 //   r4    17.8  30.0  60.0  107.8 209.1 251.6 315.5 366.7 443.4 509.1   (4 4 3 3 4 4 2 2 3 3 chains at 3 3 3 3 2 2 3 3 2 2 waves)
-//   r5    16.5  27.4  54.9   98.6 178.1 214.2  ...   (4 4 3 4 4 4 4 4 4 3 chains at 4 4 4 3 3 3 3 3 3 3 waves)
-#define ITAL_GEN_BIG_NCB(T) ((T) == 9 || (T) == 16 ? 3 : 4)
+//   r5    16.5  27.4  53.3   96.1 176.1 211.3 261.5 316.9 373.4 430.6   (4 4 5 5 4 4 4 4 4 3 chains at 4 4 3 3 3 3 3 3 3 3 waves)
+#define ITAL_GEN_BIG_NCB(T) ((T) == 9 || (T) == 10 ? 5 : (T) == 16 ? 3 : 4)
 #endif
 #ifndef ITAL_GEN_BIG_HOTK
 #define ITAL_GEN_BIG_HOTK 1
 #endif
 #ifndef ITAL_GEN_BIG_KEN
 // exp coefficients (of ten) held in vector registers by the evaluator above, the rest materialised in place (HotKEn,
-// device_math.h): six where the registers are there, none from 13 variables on (four chains at three waves per SIMD)
-#define ITAL_GEN_BIG_KEN(T) ((T) >= 13 && (T) <= 15 ? 0 : 6)
+// device_math.h): six where the registers are there, two at 13 variables, none at 14 and 15 (four chains at three waves per
+// SIMD without scratch; T = 13: 269 -> 261.5 ms with two against none)
+#define ITAL_GEN_BIG_KEN(T) ((T) == 13 ? 2 : (T) == 14 || (T) == 15 ? 0 : 6)
 #endif
 #ifndef ITAL_GEN_BIG_COEF
 #define ITAL_GEN_BIG_COEF(T) HotKEn<ITAL_GEN_BIG_KEN(T)>
@@ -76,8 +77,8 @@
 #endif
 #ifndef ITAL_GEN_MAIN_WAVES
 // waves per SIMD the lattice-sum kernels aim at: four up to 4 variables (120 registers with six chains), three at 5 and 6;
-// 6 .. 9 variables four again since round 5 (110 - 126 registers), three beyond (see ITAL_GEN_BIG_NCB)
-#define ITAL_GEN_MAIN_WAVES(T) ((T) > 0 && (T) < 5 ? 4 : ((T) >= 6 && (T) <= 9 ? 4 : 3))
+// 6 .. 8 variables four again since round 5 (110 - 126 registers), three beyond (see ITAL_GEN_BIG_NCB)
+#define ITAL_GEN_MAIN_WAVES(T) ((T) > 0 && (T) < 5 ? 4 : ((T) >= 6 && (T) <= 8 ? 4 : 3))
 #endif
 #ifndef ITAL_GEN_TFIX_MAX
 #define ITAL_GEN_TFIX_MAX 16   // largest dimension the pipeline takes (plain mode)
