@@ -120,10 +120,13 @@ def hbm_stream_probe(device, rows=1_000_000, d=DIM, m=21, reps=10):
         sec = e0.elapsed_time(e1) * 1e-3 / reps
     nbytes = 8.0 * rows * (d + m + 2)
     ach = nbytes / sec / 1e9
-    return {"bound": "hbm", "kernel": "kcols_kernel (ital_cross_cov_cols, c=1)", "achieved": ach, "peak": HBM_PEAK_GBS,
-            "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": None, "avg_launch_ms": sec * 1e3,
-            "rows": rows, "d": d, "m": m, "algorithmic_bytes_per_launch": nbytes,
-            "note": "same kernel as the greedy steps' cross-covariance column, at 1M rows (2.2 GB per launch)"}
+    pm = pmc_fields("kcols", "ital::kcols_kernel", sec)      # counters of this very probe (tools/kcols_probe.py under rocprofv3)
+    pm.pop("valu_issue_frac", None)
+    return dict({"bound": "hbm", "kernel": "kcols_kernel (ital_cross_cov_cols, c=1)", "achieved": ach, "peak": HBM_PEAK_GBS,
+                 "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "avg_launch_ms": sec * 1e3,
+                 "rows": rows, "d": d, "m": m, "algorithmic_bytes_per_launch": nbytes,
+                 "note": "same kernel as the greedy steps' cross-covariance column, at 1M rows (2.2 GB per launch); traffic = "
+                         "FETCH_SIZE (corrected) + WRITE_SIZE per launch from the committed counter pass of this probe"}, **pm)
 
 
 def profile_is_current(rel_path):

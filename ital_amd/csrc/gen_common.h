@@ -86,6 +86,9 @@
 #ifndef ITAL_GEN_PREP_SPLIT
 #define ITAL_GEN_PREP_SPLIT 4   // preparation waves per candidate in the pipeline
 #endif
+#ifndef ITAL_GEN_PREP_PU
+#define ITAL_GEN_PREP_PU 1   // wide form, perfect user, <= 16 patterns per candidate: the cooperative preparation (gen_prep_pu_kernel)
+#endif
 #ifndef ITAL_GEN_PIPELINE
 #define ITAL_GEN_PIPELINE 1   // plain mode, 3 .. 16 variables: prepare / lattice sums / combine as three kernels on streams of their own
 #endif

@@ -60,6 +60,7 @@ struct GPipe {
     unsigned int cap;          // records in this buffer
     unsigned int chunk_lo;     // fast form: the chunk covers entries [chunk_lo, chunk_lo + cap) of list U
     int nsplit;                // wide form: waves a candidate's calls are spread over in the preparation
+    unsigned char* redo;       // wide form, perfect user: [slab_n] candidates gen_prep_pu_kernel left to gen_prep_kernel (NULL: all)
 };
 
 __device__ __forceinline__ long long pack_meta(int flags, int n, unsigned infi, unsigned closes) {
@@ -520,6 +521,7 @@ __global__ __launch_bounds__(128) void gen_prep_kernel(GArgs a, GPipe g) {
     if (i >= g.slab_n) return;
     const int64_t p = g.slab_lo + i;
     if (!d.alive[p]) return;
+    if (g.redo && !g.redo[i]) return;        // prepared by gen_prep_pu_kernel already
     double* W = lds_all + (size_t)wid * a.wave_doubles;
     double* muU = W;
     const int ldS = a.ldS;
@@ -618,6 +620,173 @@ __global__ __launch_bounds__(128) void gen_prep_kernel(GArgs a, GPipe g) {
         }
         rng = mrg_jump(d, rng, (uint64_t)total_draws);
         wave_sync();
+    }
+}
+
+// Wide form with the PERFECT user and at most 16 patterns per candidate (fb_mode 0: monte_carlo_num_rel x t sampled patterns,
+// BASELINE config 5): every pattern makes one prior call and one call after the simulated update with ALL variables fed
+// back.  gen_prep_kernel lets every lane redo the O(n^3) algebra of that update -- W = (Sigma_U + s I)^-1 does not depend on
+// the pattern -- in a private LDS scratch that limits a wave to 8 of its 64 lanes at 16 variables (four waves per
+// candidate, 0.8 M candidates per second on the whole chip: a tenth of the step, taking a wave slot from the lattice sums
+// wherever it runs).  Here ONE wave per candidate
+//   A  forms W once, cooperatively (Cholesky by columns with the lanes over the rows, the inverse factor with the lanes over
+//      the columns, W = X^T X with the lanes over the pairs: the sums in prepare_call's order);
+//   B  lanes 32 + l: the updated call of pattern l is decided from g = W (f - mu): mean' = f - s g, var' = s (1 - s W_aa),
+//      early_decision -- n^2 operations on the shared W.  A call this does not decide (noise large against the variances)
+//      hands the WHOLE candidate to gen_prep_kernel (redo flag), which runs behind this kernel for the flagged ones only;
+//   C  lanes l: the prior call of pattern l through prepare_call as before (COVSRT in the lane's slab), its lattices, its
+//      record.
+// Stream offsets as in gen_prep_kernel: call c of a candidate starts c x 8 (2 (n - 1) - 1) uniforms behind the candidate's.
+__global__ __launch_bounds__(128) void gen_prep_pu_kernel(GArgs a, GPipe g) {
+    extern __shared__ double lds_all[];
+    const ital_gscore_desc& d = a.d;
+    const int lane = threadIdx.x & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int64_t i = (int64_t)blockIdx.x * 2 + wid;
+    if (i >= g.slab_n) return;
+    const int64_t p = g.slab_lo + i;
+    if (!d.alive[p]) return;
+    const int n = g.n;                 // plain mode: U = batch so far + candidate, all of them enumerated
+    const int ldS = a.ldS;
+    double* W0 = lds_all + (size_t)wid * a.wave_doubles;
+    double* muU = W0;
+    double* SigU = muU + ldS;
+    double* Lm = SigU + ldS * ldS;      // lower factor of Sigma_U + s I
+    double* Xm = Lm + ldS * ldS;        // its inverse
+    double* Wm = Xm + ldS * ldS;        // W, full symmetric
+    int* usort = reinterpret_cast<int*>(Wm + ldS * ldS);
+    int* ipos = usort + GN;
+    double* slabs = Wm + ldS * ldS + (GN + GR + 1) / 2;
+    const int row = d.cand[p];
+    const int64_t gi = d.row_offset + row;
+    const int nE = d.nE;
+    const double s = d.noise;
+    for (int idx = lane; idx < n * n; idx += 64) {
+        const int r = idx / n, c = idx - r * n;
+        double v;
+        if (r < nE && c < nE) v = d.E_sig[r * d.ldE + c];
+        else if (r == c) v = d.s2[row];                         // not clamped (gp.py:254)
+        else v = d.C[(int64_t)(r < c ? r : c) * d.ldc + row];
+        SigU[r * ldS + c] = v;
+    }
+    for (int e = lane; e < n; e += 64) muU[e] = e < nE ? d.E_mu[e] : d.mu[row];
+    if (lane == 0) {
+        int rank = 0;
+        for (int e = 0; e < nE; e++) rank += (d.E_idx[e] < gi) ? 1 : 0;
+        for (int sidx = 0; sidx < n; sidx++)
+            usort[sidx] = sidx < rank ? d.E_sort[sidx] : (sidx == rank ? nE : d.E_sort[sidx - 1]);
+        for (int v = 0; v < n; v++) ipos[v] = v < d.n_picks ? d.pick_pos[v] : nE;
+    }
+    wave_sync();
+    // ---- A: W = (Sigma_U + s I)^-1.  Column j of the factor: lane i forms row i's entry (prepare_call's sums, q ascending)
+    for (int j = 0; j < n; j++) {
+        double v = 0.0;
+        if (lane >= j && lane < n) {
+            v = SigU[lane * ldS + j] + (lane == j ? s : 0.0);
+            for (int q = 0; q < j; q++) v -= Lm[lane * ldS + q] * Lm[j * ldS + q];
+        }
+        const double dj = sqrt(readlane_f64(v, j));
+        if (lane >= j && lane < n) Lm[lane * ldS + j] = lane == j ? dj : v / dj;
+        wave_sync();
+    }
+    if (lane < n) {      // column `lane` of the inverse factor, top to bottom
+        const int c = lane;
+        Xm[c * ldS + c] = 1.0 / Lm[c * ldS + c];
+        for (int r = c + 1; r < n; r++) {
+            double sm = 0;
+            for (int q = c; q < r; q++) sm += Lm[r * ldS + q] * Xm[q * ldS + c];
+            Xm[r * ldS + c] = -sm / Lm[r * ldS + r];
+        }
+    }
+    wave_sync();
+    for (int idx = lane; idx < n * (n + 1) / 2; idx += 64) {      // W[r][c] = sum_{k >= r} X[k][c] X[k][r], c <= r
+        int r = 0;
+        while ((r + 1) * (r + 2) / 2 <= idx) r++;
+        const int c = idx - r * (r + 1) / 2;
+        double w = 0;
+        for (int k = r; k < n; k++) w += Xm[k * ldS + c] * Xm[k * ldS + r];
+        Wm[r * ldS + c] = w;
+        Wm[c * ldS + r] = w;
+    }
+    wave_sync();
+    // ---- B: the updated calls (lane 32 + l: pattern l), decided from their standardised limits
+    const int npat = g.npat;
+    const bool upd = lane >= 32 && lane - 32 < npat;
+    const int pl_ = upd ? lane - 32 : lane;                     // pattern of this lane
+    unsigned relU = 0;
+    if (pl_ < npat) {
+        const unsigned pat = d.mc_rel > 0 ? d.rel_samples[p * d.mc_rel + pl_] : (unsigned)pl_;
+        for (int v = 0; v < n; v++) relU |= ((pat >> (n - 1 - v)) & 1u) << ipos[v];
+    }
+    int eflag = 1;                                              // (lanes without an updated call count as decided)
+    if (upd) {
+        const double thr = 37.0 + 9.0 * sqrt((double)(n - 1));
+        bool all_full = true, any_empty = false;
+        for (int ua = 0; ua < n; ua++) {
+            double acc = 0;
+            for (int ub = 0; ub < n; ub++) acc += Wm[ua * ldS + ub] * ((((relU >> ub) & 1u) ? 1.0 : -1.0) - muU[ub]);
+            const double mean = (((relU >> ua) & 1u) ? 1.0 : -1.0) - s * acc;
+            const double var = s * (1.0 - s * Wm[ua * ldS + ua]);
+            const double lim = -mean / sqrt(var);
+            const double l = ((relU >> ua) & 1u) ? lim : -lim;      // early_decision (gen_common.h)
+            if (l > thr) any_empty = true;
+            if (!(l < -thr)) all_full = false;
+        }
+        eflag = any_empty ? 4 : (all_full ? 2 : 0);
+    }
+    const bool redo = __ballot(eflag == 0) != 0ull;
+    if (lane == 0) g.redo[i] = redo ? 1 : 0;
+    if (redo) return;                                           // (wave-uniform) gen_prep_kernel takes this candidate
+    const int total = g.total;
+    double* meta = g.meta + (size_t)i * total * 2;
+    if (upd) {
+        unsigned infi = 0;                                      // limit types in the call's own order (by data index, ital.py:448)
+        for (int q = 0; q < n; q++) infi |= ((relU >> usort[q]) & 1u) << q;
+        const int call = 2 * pl_ + 1;
+        meta[2 * call] = __longlong_as_double(pack_meta(eflag, n, infi, 0));
+        meta[2 * call + 1] = (eflag & 2) ? 1.0 : 0.0;
+    }
+    // ---- C: the prior calls (lane l: pattern l)
+    const bool pri = lane < npat;
+    Prep pp;
+    pp.n = 0; pp.infi = 0; pp.flags = 16; pp.value = 0; pp.closes = 0; pp.ng = 0; pp.gdraws = 0;
+    double* slab = slabs + (size_t)(pri ? lane : 0) * a.stride;
+    if (pri) {
+        const CallInfo ci = decode_call(d, p, 2 * lane, 2, 1, n, npat);
+        pp = prepare_call<false>(d, ci, n, n, ldS, muU, SigU, usort, ipos, false, slab, slab, nullptr);
+    }
+    const bool integrate = pri && !(pp.flags & (1 | 6 | 16));
+    const bool regular = integrate && pp.closes == (1u << pp.n) - 1u;
+    const unsigned long long em = __ballot(regular), cm = __ballot(integrate && !regular);
+    unsigned int lbase = 0, cbase = 0;
+    if (lane == 0 && em) lbase = atomicAdd(g.count, (unsigned int)__popcll(em));
+    if (lane == 0 && cm) cbase = atomicAdd(g.count + 1, (unsigned int)__popcll(cm));
+    lbase = (unsigned int)__builtin_amdgcn_readfirstlane((int)lbase);
+    cbase = (unsigned int)__builtin_amdgcn_readfirstlane((int)cbase);
+    if (pri) {
+        const int call = 2 * lane;
+        if (integrate) {
+            // stream position of this call: the candidate's offset in the reference's serial order + `call` calls of this size
+            MrgState rng = {d.seed[0], d.seed[1], d.seed[2], d.seed[3], d.seed[4], d.seed[5]};
+            const int64_t gpos = d.gpos ? d.gpos[p] : d.pos_offset + p;
+            int64_t before = gpos;
+            for (int q = 0; q < d.n_dead; q++) before -= (d.dead_pos[q] < gpos) ? 1 : 0;
+            uint64_t off = (uint64_t)before * (uint64_t)d.draws_out;
+            if (d.draw_off) off = (uint64_t)d.draw_off[p];
+            off += (uint64_t)call * (uint64_t)(8 * (2 * (n - 1) - 1));
+            const unsigned int id = (unsigned int)(i * total + call);
+            double* rec = g.recs + (size_t)id * g.R;
+            rec[0] = __longlong_as_double(pack_meta(pp.flags, pp.n, pp.infi, pp.closes));
+            rec[1] = (double)id;
+            write_slab(pp.n, slab, (regular && ITAL_QMC_FLIP) ? pp.infi : 0u, rec + 2);
+            make_lattice_packed(mrg_jump(d, rng, off), pp.n, slab, rec + g.lat);      // the slab is free now
+            if (regular) g.list[lbase + (unsigned int)__popcll(em & ((1ull << lane) - 1ull))] = id;
+            else g.list[g.cap - 1u - cbase - (unsigned int)__popcll(cm & ((1ull << lane) - 1ull))] = id;
+        }
+        double value = pp.value;
+        if (!(pp.flags & 1) && (pp.flags & 6)) value = (pp.flags & 2) ? 1.0 : 0.0;
+        meta[2 * call] = __longlong_as_double(pack_meta(pp.flags, pp.n, pp.infi, pp.closes));
+        meta[2 * call + 1] = value;
     }
 }
 
@@ -916,7 +1085,7 @@ PipePlan pipe_plan(const ital_gscore_desc* d) {
         pl.per_cand = 3 + pl.total * 2 + (pl.total + 1) / 2;
         pl.chunk_max = (int64_t)1 << 20;
     } else {
-        pl.per_cand = pl.total * (2 + (int64_t)pl.R) + (pl.total + 1) / 2;
+        pl.per_cand = pl.total * (2 + (int64_t)pl.R) + (pl.total + 1) / 2 + 1;      // meta, records, list, the redo flag
     }
     return pl;
 }
@@ -1108,6 +1277,20 @@ int ital_gen_pipeline(const ital_gscore_desc* d, hipStream_t stream) {
     static ItalLdsFlags prep_flags;
     if (const int rc = ital_raise_lds_limit(reinterpret_cast<const void*>(&gen_prep_kernel), 160 * 1024, prep_flags, "ital_score_generic"))
         return rc;
+    // perfect user with a few patterns per candidate (sampled patterns): the cooperative preparation, gen_prep_kernel behind it
+    // for the candidates it flags
+    const bool pu = ITAL_GEN_PREP_PU && d->fb_mode == 0 && d->mc_fb == 0 && pl.cpp == 2 && pl.npat <= 16;
+    GArgs apu = ap;
+    size_t lds_pu = 0;
+    if (pu) {
+        apu.stride = slab | 1;
+        apu.wave_doubles = n + 4 * n * n + (GN + GR + 1) / 2 + pl.npat * apu.stride;
+        lds_pu = (size_t)2 * apu.wave_doubles * sizeof(double);
+        static ItalLdsFlags pu_flags;
+        if (lds_pu > 48 * 1024)
+            if (const int rc = ital_raise_lds_limit(reinterpret_cast<const void*>(&gen_prep_pu_kernel), 160 * 1024, pu_flags, "ital_score_generic"))
+                return rc;
+    }
     if (hipEventRecord(ps->start, stream) != hipSuccess || hipStreamWaitEvent(ps->prep, ps->start, 0) != hipSuccess ||
         hipStreamWaitEvent(ps->main, ps->start, 0) != hipSuccess)
         return ital_fail(-5, "ital_score_generic: stream synchronisation failed");
@@ -1121,8 +1304,10 @@ int ital_gen_pipeline(const ital_gscore_desc* d, hipStream_t stream) {
         g.recs = g.meta + g.slab_n * pl.total * 2;
         g.list = reinterpret_cast<unsigned int*>(g.recs + g.slab_n * pl.total * pl.R);
         g.cap = (unsigned int)(g.slab_n * pl.total);
+        g.redo = pu ? reinterpret_cast<unsigned char*>(g.list + ((size_t)g.cap + 1) / 2 * 2) : nullptr;     // (slab_n bytes <= slab_n doubles)
         if (ps->summed_valid[buf]) (void)hipStreamWaitEvent(ps->prep, ps->summed[buf], 0);   // the buffer is free again (combined too)
         (void)hipMemsetAsync(g.count, 0, 2 * sizeof(unsigned int), ps->prep);
+        if (pu) ITAL_LAUNCH(gen_prep_pu_kernel, dim3((unsigned)((g.slab_n + 1) / 2)), dim3(128), lds_pu, ps->prep, apu, g);
         ITAL_LAUNCH(gen_prep_kernel, dim3((unsigned)((g.slab_n * g.nsplit + 1) / 2)), dim3(128), lds_p, ps->prep, ap, g);
         (void)hipEventRecord(ps->built[buf], ps->prep);
         (void)hipStreamWaitEvent(ps->main, ps->built[buf], 0);

@@ -185,12 +185,27 @@ def test_exact_equality_reset_of_label_estimation_follows_the_reference(monkeypa
 
 @pytest.mark.parametrize("seed0,case", [(11, 150), (13, 87), (47, 78), (47, 271), (59, 13), (83, 1050), (83, 1298), (83, 1373)])
 def test_resampled_monte_carlo_patterns(seed0, case):
+    _resampled_case(seed0, case, "mc")
+
+
+def test_resampled_patterns_that_decide_a_pick(monkeypatch):
+    """Limit 2 changing a PICK (round 5, FUZZ_KINDS=mcwide campaign, seed 201 case 133: 22 x 5, k = 10, one sampled pattern
+    set per step): at step 6 the candidate the oracle's own sampling makes the arg-max is one whose patterns its LAPACK draws
+    differently -- device batch [7, 9, 15, 2, 6, 13, ...], oracle [7, 9, 15, 2, 6, 3, ...], the device's pick 9e-2 below the
+    maximum of the oracle's own vector.  With the device's patterns given to the oracle every score agrees and every device
+    pick is the arg-max (the strict rule below; steps 7 .. 10 run on the pipeline's wide form: gen_prep_pu_kernel,
+    gen_main_kernel<7 .. 10>)."""
+    monkeypatch.setenv("FUZZ_KINDS", "mcwide")
+    _resampled_case(201, 133, "mcwide", max_share=0.2)
+
+
+def _resampled_case(seed0, case, kind, max_share=0.02):
     if not torch.cuda.is_available():
         pytest.skip("no GPU")
     from oracle import mvn as omvn
     c, A, B = _pair(seed0, case)
     X, k = c["X"], c["k"]
-    assert c["kind"] == "mc" and c["kw"]["monte_carlo_num_rel"] in (1, 2)
+    assert c["kind"] == kind and c["kw"]["monte_carlo_num_rel"] in (1, 2)
     pairs = resampled = 0
     for rnd in range(2):
         np.random.seed(case * 7 + rnd)
@@ -221,5 +236,5 @@ def test_resampled_monte_carlo_patterns(seed0, case):
         fb = {i: (1 if X[i, 0] > 0.5 else -1) for i in got}
         A.update(fb)
         B.update(fb)
-    assert resampled <= 0.02 * pairs, (resampled, pairs)
+    assert resampled <= max_share * pairs, (resampled, pairs)
     print("fuzz case %d / seed %d: %d of %d (step, candidate) estimates re-sampled by the oracle's LAPACK" % (case, seed0, resampled, pairs))

@@ -65,6 +65,13 @@ def make_case(seed0, case):
     elif kind == "mc":
         kw = dict(monte_carlo_num_rel=int(rng.integers(1, 3)))
         k = int(rng.integers(3, 7))
+    elif kind == "mcwide":                        # (FUZZ_KINDS only: not in KINDS, whose order the pinned cases depend on)
+        # sampled patterns with batches of 7 .. 10: the pipeline's wide form (gen_prep_pu_kernel / gen_prep_kernel,
+        # gen_main_kernel<7 .. 10>) on a small candidate set
+        kw = dict(monte_carlo_num_rel=int(rng.integers(1, 3)))
+        k = int(rng.integers(7, 11))
+        n = int(rng.integers(k + 6, k + 22))
+        X = X[:n] if n <= len(X) else rng.random((n, d))
     elif kind == "clip":
         kw = dict(clip_cov=float(rng.uniform(0.1, 0.6)), change_estimation_subset=int(rng.integers(3, 6)))
     elif kind == "optimistic":
@@ -94,6 +101,20 @@ def tie_check(trace, got):
         # arg-max among them is decided by that noise
         out.append(0.0 if (np.isnan(v) or v == top) else abs(top - v) / max(abs(top), 1.0))
     return out
+
+
+def pattern_lists(A, cand0):
+    """The sign patterns the device learner sampled in its last fetch, per greedy step and candidate, as the oracle takes
+    them (`patterns=`): step t -> {candidate: [tuple of t booleans per sample]} (None for enumerated steps)."""
+    given = []
+    for t_, words in enumerate(A.last_patterns, start=1):
+        if words is None:
+            given.append(None)
+            continue
+        words = np.asarray(words)
+        given.append({int(cnd): [tuple(bool((int(w) >> (t_ - 1 - v)) & 1) for v in range(t_)) for w in words[p_]]
+                      for p_, cnd in enumerate(cand0)})
+    return given
 
 
 def main():
@@ -166,6 +187,7 @@ def main():
                     note = " [duplicate sample in the batch from step %d on: compared up to there]" % ndeg
                     if got[:ndeg] == want[:ndeg]:
                         same_rows = True
+                pick_by_patterns = False
                 if got != want and not same_rows and isinstance(B, OracleITAL):
                     # judge the device's batch against the oracle's MI GIVEN that batch: second oracle run from the same
                     # stream positions with the device's picks forced; everything below compares against it
@@ -175,8 +197,32 @@ def main():
                     _, err_f = fetch(B, forced=got)
                     extra_draws += consumed
                     dist = tie_check(B.trace, got)
+                    if (err_f or max(dist) > TIE_RTOL) and kw.get("monte_carlo_num_rel") is not None \
+                            and getattr(A, "last_patterns", None):
+                        # LIMIT 2 deciding a PICK (first met in round 5, seed 201 case 133 of kind mcwide): a candidate whose sign
+                        # patterns the oracle's LAPACK samples differently (see below) can be the arg-max on one side only.
+                        # STRICT rule, for the pick as for the scores: with the DEVICE's patterns given to the oracle, every
+                        # device pick must be an arg-max of the oracle's vector (ties as above) -- the scores are compared
+                        # against the same run further down
+                        given = pattern_lists(A, B.trace[0][0])
+                        consumed = omvn.rng_draws() - o_draws
+                        omvn.rng_set_state(o_state)
+                        o_draws = omvn.rng_draws()
+                        np.random.seed(case * 7 + rnd)
+                        B.fetch_unlabelled(k, forced=got, patterns=given)
+                        extra_draws += consumed
+                        loose, dist = max(dist), tie_check(B.trace, got)
+                        err_f = None
+                        if max(dist) <= TIE_RTOL:
+                            resampled += 1
+                            pick_by_patterns = True
+                            note += (" [a PICK decided by Monte-Carlo patterns the oracle's LAPACK re-sampled (own patterns: the "
+                                     "device pick %.1e below the maximum); an arg-max for the device's patterns, batch %s vs %s]"
+                                     % (loose, got, want))
                     if err_f or max(dist) > TIE_RTOL:
                         status = "PICKS %s != %s (oracle MI of the device pick below its maximum by %.1e)" % (got, want, max(dist))
+                    elif pick_by_patterns:
+                        pass
                     else:
                         ties += 1
                         note = " [numerical tie at step %d: oracle MI equal to %.1e, batch %s vs %s]" % (
@@ -222,15 +268,7 @@ def main():
                     # conventions (LAPACK) flip under a last-bit difference -- the candidate then receives other, equally valid
                     # patterns.  STRICT rule: for the patterns the DEVICE sampled the oracle's estimate must equal the device's
                     # for every candidate -- the oracle runs the round again with them
-                    cand0 = B.trace[0][0]
-                    given = []
-                    for t_, words in enumerate(A.last_patterns, start=1):
-                        if words is None:
-                            given.append(None)
-                            continue
-                        words = np.asarray(words)
-                        given.append({int(cnd): [tuple(bool((int(w) >> (t_ - 1 - v)) & 1) for v in range(t_)) for w in words[p_]]
-                                      for p_, cnd in enumerate(cand0)})
+                    given = pattern_lists(A, B.trace[0][0])
                     consumed = omvn.rng_draws() - o_draws
                     omvn.rng_set_state(o_state)
                     o_draws = omvn.rng_draws()

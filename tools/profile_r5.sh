@@ -6,7 +6,7 @@
 #   general   bench.py --label-prob 0.5 --mistake-prob 0.25 (noisy user: the pipeline of gen_pipeline.hip)
 #   c5        tools/scale_probe.py 125000 512 16 1 (BASELINE configs[4] as one of 8 ranks sees it: gen_main_kernel<3..16>)
 #   mcmi      tools/mcmi_bench.py (MCMI_min, subsample 1000 and all candidates)
-#   kcols     tools/stream_bench.py (the HBM-bound streaming kernel at 1M rows)
+#   kcols     tools/kcols_probe.py (the HBM-bound streaming kernel at 1M rows: bench.py's roofline_hbm probe)
 #   cesub     tools/cesub_bench.py (change_estimation_subset: the monolithic score_generic_kernel)
 # Summaries land in gpurun_out/prof_r5/ together with r5_stamp.json (tools/stamp.py: the kernel sources they were taken
 # with); copy the r5_* files to profiles/.
@@ -44,8 +44,8 @@ for w in $WHICH; do
               python3 $ROOT/tools/step_shares.py $(find $OUT/c5_stats -name "*kernel_trace.csv" | head -1) > $OUT/r5_c5_step_shares.txt ;;
     mcmi)     passes mcmi python3 $ROOT/tools/mcmi_bench.py
               grep -v "^[EW]20" $OUT/mcmi_stats.log | tail -3 > $OUT/r5_mcmi_probe.log ;;
-    kcols)    passes kcols python3 $ROOT/tools/stream_bench.py
-              grep -v "^[EW]20" $OUT/kcols_stats.log | tail -6 > $OUT/r5_kcols_probe.log ;;
+    kcols)    passes kcols python3 $ROOT/tools/kcols_probe.py
+              grep '^{"bound"' $OUT/kcols_stats.log > $OUT/r5_kcols_probe.json ;;
     cesub)    passes cesub python3 $ROOT/tools/cesub_bench.py
               grep -v "^[EW]20" $OUT/cesub_stats.log | tail -6 > $OUT/r5_cesub_probe.log ;;
   esac
