@@ -30,7 +30,7 @@ _LABEL_MODES = {"mean": 0, "optimistic": 1, "pessimistic": 2}
 _HOST_THREADS = max(1, min(16, os.cpu_count() or 1))   # host share of one GPU (Monte-Carlo pattern sampling)
 # pattern sampling: ranges of candidates per greedy step (host / GPU overlap), their minimum size, and the number of
 # variables from which a step is split at all (below, the step's lattice sums are shorter than the host's decompositions:
-# measured at 125 000 x 512, nothing to hide behind)
+# measured at 125 000 x 512, nothing to hide behind; on shards of 262 144 candidates and more from 7 variables on)
 _MC_CHUNKS, _MC_CHUNK_MIN, _MC_CHUNK_FROM = 4, 8192, 10
 _POOL = None
 
@@ -763,8 +763,9 @@ class ITAL(ActiveRetrievalBase):
                         e_sig[: t - 1, : t - 1] = b["sig"].view(kmax, kmax)[: t - 1, : t - 1].cpu().numpy()
                     # pattern sampling alone on a large shard: the step is scored in ranges of candidates, the SVDs of the
                     # next range on the host under the lattice sums of the current one
-                    n_chunks = _MC_CHUNKS if (rel_mc and not fb_mc and not subset_mode and not clip_count and runs
-                                              and gpos_d is None and nr >= _MC_CHUNK_FROM
+                    n_chunks = (_MC_CHUNKS + (2 if n_loc >= 32 * _MC_CHUNK_MIN else 0)) if (rel_mc and not fb_mc and not subset_mode and not clip_count and runs
+                                              and gpos_d is None
+                                              and (nr >= _MC_CHUNK_FROM or (nr >= 7 and n_loc >= 32 * _MC_CHUNK_MIN))
                                               and n_loc >= _MC_CHUNK_MIN * _MC_CHUNKS) else 0
                     mc = self._mc_samples(nr, npat, rel_mc, fb_mc, nfb, fb_mode, cand, picks, pos_of,
                                           E if subset_mode else picks, pick_pos, e_mu, e_sig, C, subset_mode, z_next,
@@ -1157,7 +1158,14 @@ class ITAL(ActiveRetrievalBase):
                 draws[live] = npat * (npre_draws[live] + nfb * d_full[live])
 
                 def ranges():
-                    cuts = np.unique(np.linspace(jl0, jl1, chunks + 1).astype(np.int64))
+                    # a SHORT first range: the GPU idles while the host decomposes it (the pick of the step before, the new
+                    # member's covariance column and the SVDs of its candidates: 0.17 s per step at 1M x 512 with four equal
+                    # ranges, 2.8 s of a 101 s round), every later range is decomposed under the lattice sums of the one before
+                    # -- as long as a range is not much longer than the one before (the host decomposes ~1.4 M candidates per
+                    # second on 16 threads, the GPU integrates 1.6 M (7 variables) .. 47 k (16) per second): sizes 1 : 2 : 4 : ...
+                    span = jl1 - jl0
+                    cuts = jl0 + (span * ((1 << np.arange(chunks + 1)) - 1)) // ((1 << chunks) - 1)
+                    cuts = np.unique(np.concatenate(([jl0], cuts[cuts - jl0 >= min(_MC_CHUNK_MIN, span)], [jl1])).astype(np.int64))
                     for a, b_ in zip(cuts[:-1], cuts[1:]):
                         lo = local[0] if a == jl0 else int(live[a])
                         hi = local[1] if b_ == jl1 else int(live[b_])
