@@ -522,6 +522,39 @@ int64_t ital_score_generic_workspace(const ital_gscore_desc* d);
  * streams (calls with defer_join; an error path that abandons a step half way).  Cheap when nothing is pending. */
 int ital_score_generic_join(hipStream_t stream);
 
+/* ---- context-style convenience layer ------------------------------------------------------------
+ * A learner whose device buffers the LIBRARY owns (hipMalloc), for hosts that do not want to manage the buffers of the
+ * descriptor entry points above themselves: the perfect-user path of ITAL -- fit, update, fetch_unlabelled(k <= ITAL_MAX_T)
+ * with full sign-pattern enumeration, predict_stored.  Host code over the descriptor API of this same library (csrc/ctx.hip);
+ * one context per learner, not thread-safe per context; the calls that return results to host memory synchronise `stream`.
+ * Several ranks: rows sharded contiguously (rank r holds rows [n_total r / world, n_total (r + 1) / world)), one
+ * ncclAllGather of a selection record per greedy step on `nccl_comm` (ital_select_local -> _exchange -> _resolve); with
+ * world == 1 a non-NULL communicator sends the single rank through that same path.  ital_amd's Python learners do not use
+ * this layer (their buffers are torch tensors). */
+typedef struct ital_ctx ital_ctx;
+/* capacity: most labelled samples (<= 0: 256).  Replaces ITAL.__init__ / ActiveRetrievalBase.__init__ + GaussianProcess.__init__,
+ * reference ital/ital.py:15-81, ital/retrieval_base.py:7-31, ital/gp.py:99-139. */
+int ital_ctx_create(int64_t n_total, int d, double length_scale, double var, double noise, int capacity, int rank, int world,
+                    void* nccl_comm, ital_ctx** out);
+int ital_ctx_destroy(ital_ctx* ctx);
+/* rows: this rank's rows, [n_local][d] row-major (host memory, or device memory with on_device != 0); forgets every label.
+ * Replaces ActiveRetrievalBase.fit / reset, reference ital/retrieval_base.py:34-61 (the dense kernel matrix of gp.py:128 is
+ * never formed). */
+int ital_ctx_fit(ital_ctx* ctx, const double* rows, int on_device, hipStream_t stream);
+/* Labels c samples (global indices, y = +1 / -1).  Replaces ActiveRetrievalBase.update / GaussianProcess.update, reference
+ * ital/retrieval_base.py:105-126, ital/gp.py:164-200.  -22 for a sample labelled before ("Cannot change feedback once
+ * given."), -12 beyond the capacity, -38 on several ranks for samples that are neither local nor in the batch just fetched. */
+int ital_ctx_update(ital_ctx* ctx, const int64_t* idx, const double* y, int c, hipStream_t stream);
+/* picks[0 .. k) <- the batch (global indices, selection order); returns the number of picks (k clamped to the unlabelled
+ * samples) or a negative code: -71 when the round needs the general scorer (ital_score_generic: duplicates in the batch,
+ * noise too large for the limit verdicts).  Replaces ITAL.fetch_unlabelled, reference ital/ital.py:84-134. */
+int ital_ctx_fetch(ital_ctx* ctx, int k, int64_t* picks, hipStream_t stream);
+/* mean / variance [n_local] of this rank's rows (host memory; either may be NULL), the variance clamped at 0.  Replaces
+ * GaussianProcess.predict_stored(cov_mode='diag') / rel_mean, reference ital/gp.py:203-232, ital/retrieval_base.py:58. */
+int ital_ctx_predict_stored(ital_ctx* ctx, double* mean, double* variance, hipStream_t stream);
+/* Rows this rank holds; *row0 (optional) <- the global index of its first row. */
+int64_t ital_ctx_local_rows(const ital_ctx* ctx, int64_t* row0);
+
 #ifdef __cplusplus
 }
 #endif

@@ -143,6 +143,13 @@ SIGNATURES = {
     "ital_exchange_info": (c_int, [c_void_p, c_void_p, c_void_p, ctypes.c_char_p, c_int]),
     "ital_exchange_error": (c_int, [c_void_p, c_void_p]),
     "ital_score_generic_join": (c_int, [c_void_p]),
+    "ital_ctx_create": (c_int, [c_int64, c_int, c_double, c_double, c_double, c_int, c_int, c_int, c_void_p, c_void_p]),
+    "ital_ctx_destroy": (c_int, [c_void_p]),
+    "ital_ctx_fit": (c_int, [c_void_p, c_void_p, c_int, c_void_p]),
+    "ital_ctx_update": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
+    "ital_ctx_fetch": (c_int, [c_void_p, c_int, c_void_p, c_void_p]),
+    "ital_ctx_predict_stored": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p]),
+    "ital_ctx_local_rows": (c_int64, [c_void_p, c_void_p]),
     "ital_record_len": (c_int, [c_int, c_int, c_int]),
     "ital_round_workspace": (c_int64, [c_int, c_int64, c_int64]),
     "ital_sel_parts_len": (c_int64, [c_int, c_int64, c_int64]),

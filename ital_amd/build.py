@@ -8,7 +8,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 INCLUDE = os.path.join(os.path.dirname(HERE), "include")
 LIB = os.path.join(HERE, "libital_hip.so")
-SOURCES = ["api.hip", "rbf.hip", "chol.hip", "score.hip", "select.hip", "mcmi.hip", "score_generic.hip", "gen_pipeline.hip", "topk.hip", "exchange.hip", "round.hip",
+SOURCES = ["api.hip", "rbf.hip", "chol.hip", "score.hip", "select.hip", "mcmi.hip", "score_generic.hip", "gen_pipeline.hip", "topk.hip", "exchange.hip", "round.hip", "ctx.hip",
            "mvn_stream.cpp", "np_legacy.cpp"]    # .cpp: host-only translation units (no HIP), also built by tools/asan_host.sh
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 EXTRA = os.environ.get("ITAL_HIPCC_EXTRA", "").split()          # added to every .hip compile (kernel-variant experiments)

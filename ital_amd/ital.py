@@ -440,7 +440,9 @@ class ITAL(ActiveRetrievalBase):
             e = sharding._RAW_COMMS.get((id(gp.group), str(gp.device)))      # the step path uses the raw communicator as well
             comm = e[1] if e else None
         name = {"nccl": "raw_nccl", "host": "host"}[kind[0]] if kind else ("raw_nccl (per step)" if comm else "torch_dist")
-        return sharding.await_download(tensor, what, gp.group, gp.device, comm, gp.rank, gp.world, name)
+        if getattr(self, "_pinned", None) is None:
+            self._pinned = {}
+        return sharding.await_download(tensor, what, gp.group, gp.device, comm, gp.rank, gp.world, name, pinned=self._pinned)
 
     def _round_transport(self):
         """How ital_fetch_round exchanges the ranks' records: ("nccl", ncclComm_t of the process group -- the communicator

@@ -208,7 +208,7 @@ def comm_error(comm):
     return None          # 0: healthy; -38: this RCCL has no such entry point (nothing to poll)
 
 
-def await_download(tensor, what, group=None, device=None, comm=None, rank=0, world=1, transport=None, timeout_s=None):
+def await_download(tensor, what, group=None, device=None, comm=None, rank=0, world=1, transport=None, timeout_s=None, pinned=None):
     """`tensor.cpu()` with a deadline: the device-to-host copy of a round's picks is enqueued behind the round's kernels and
     collectives; the host waits for it with an event it QUERIES (never an unbounded synchronize), polls the communicator's
     asynchronous error state meanwhile and raises ExchangeError when the deadline passes or RCCL reports a failure.  One
@@ -221,7 +221,13 @@ def await_download(tensor, what, group=None, device=None, comm=None, rank=0, wor
     limit = exchange_timeout_s() if timeout_s is None else timeout_s
     if limit <= 0:
         return tensor.cpu()
-    host = torch.empty(tensor.shape, dtype=tensor.dtype, pin_memory=True)
+    # (`pinned`: a dict the caller keeps -- the page-locked landing buffer is allocated once per shape, not per round)
+    key = (tuple(tensor.shape), tensor.dtype)
+    host = pinned.get(key) if pinned is not None else None
+    if host is None:
+        host = torch.empty(tensor.shape, dtype=tensor.dtype, pin_memory=True)
+        if pinned is not None:
+            pinned[key] = host
     host.copy_(tensor, non_blocking=True)
     done = torch.cuda.Event()
     done.record(torch.cuda.current_stream(tensor.device))
@@ -243,7 +249,7 @@ def await_download(tensor, what, group=None, device=None, comm=None, rank=0, wor
                                 "sets the deadline).  This process should exit now." % (rank, world, what, limit, transport))
         if spins > 2000:
             time.sleep(0.0002)      # a long round: stop burning the core (the first ~ms are polled back to back)
-    return host
+    return host.clone() if pinned is not None else host      # (the landing buffer is reused by the next round)
 
 
 def gather_records(record, out, group=None):

@@ -44,7 +44,39 @@ static T* dev_zeros(size_t count) {
     return p;
 }
 
+// The same round through the context-style layer (ital_ctx_*: the library owns the device buffers; csrc/ctx.hip).
+static int run_ctx(const std::vector<double>& X, int64_t n, int d, double ls, double var, double noise, int query, int k,
+                   char** want) {
+    ital_ctx* ctx = nullptr;
+    ITAL_OK(ital_ctx_create(n, d, ls, var, noise, 64, 0, 1, nullptr, &ctx));
+    ITAL_OK(ital_ctx_fit(ctx, X.data(), 0, nullptr));
+    const int64_t q = query;
+    const double one = 1.0;
+    ITAL_OK(ital_ctx_update(ctx, &q, &one, 1, nullptr));
+    std::vector<int64_t> picks(k);
+    const int got = ital_ctx_fetch(ctx, k, picks.data(), nullptr);
+    if (got != k) {
+        fprintf(stderr, "ital_ctx_fetch -> %d: %s\n", got, ital_last_error());
+        return 2;
+    }
+    int bad = 0;
+    printf("picks (context API):");
+    for (int t = 0; t < k; t++) {
+        printf(" %lld", (long long)picks[t]);
+        if (picks[t] != atoll(want[t])) bad = 1;
+    }
+    printf("  %s\n", bad ? "MISMATCH" : "ok (the reference's batch)");
+    ITAL_OK(ital_ctx_destroy(ctx));
+    return bad;
+}
+
 int main(int argc, char** argv) {
+    bool use_ctx = false;
+    if (argc > 1 && strcmp(argv[1], "--ctx") == 0) {      // host_gpu_driver --ctx X.f64 ...: the context-style layer
+        use_ctx = true;
+        argv++;
+        argc--;
+    }
     if (argc < 10) {
         fprintf(stderr, "usage: %s X.f64 n d length_scale var noise query k picks...\n", argv[0]);
         return 2;
@@ -64,6 +96,7 @@ int main(int argc, char** argv) {
         return 2;
     }
     fclose(f);
+    if (use_ctx) return run_ctx(X, n, d, ls, var, noise, query, k, argv + 9);
     hipStream_t st = nullptr;
     HIP_OK(hipStreamCreate(&st));
 

@@ -41,3 +41,8 @@ def test_cpp_host_replays_the_golden_round(tmp_path):
     print(run.stdout, run.stderr[-2000:])
     assert run.returncode == 0, (run.stdout, run.stderr[-2000:])
     assert "ok (the reference's batch)" in run.stdout
+    # ... and through the context-style layer (ital_ctx_*: six calls, no buffer of its own)
+    args = [exe, "--ctx"] + run.args[1:]
+    run2 = subprocess.run(args, capture_output=True, text=True, timeout=600)
+    print(run2.stdout, run2.stderr[-2000:])
+    assert run2.returncode == 0 and "picks (context API)" in run2.stdout and "ok (the reference's batch)" in run2.stdout
