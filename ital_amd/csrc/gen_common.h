@@ -86,6 +86,9 @@
 #ifndef ITAL_GEN_PREP_SPLIT
 #define ITAL_GEN_PREP_SPLIT 4   // preparation waves per candidate in the pipeline
 #endif
+#ifndef ITAL_GEN_PIPE_SUBSET
+#define ITAL_GEN_PIPE_SUBSET 1   // change-estimation subsets (without clip_cov, up to 16 variables) through the pipeline's wide form
+#endif
 #ifndef ITAL_GEN_PREP_PU
 #define ITAL_GEN_PREP_PU 1   // wide form, perfect user, <= 16 patterns per candidate: the cooperative preparation (gen_prep_pu_kernel)
 #endif

@@ -34,6 +34,8 @@
 // as MVNUNI's 32-bit integers, the 8 permuted generator vectors as 4-bit indices (a 64-bit word per shift).
 // the kernels of this unit call each of the larger helpers once: inlined (an out-of-line callee saves registers on a stack)
 #define ITAL_GEN_FN __device__ __forceinline__
+#include <algorithm>
+
 #include "gen_common.h"
 #include "qmc_exact.h"
 
@@ -61,6 +63,10 @@ struct GPipe {
     unsigned int chunk_lo;     // fast form: the chunk covers entries [chunk_lo, chunk_lo + cap) of list U
     int nsplit;                // wide form: waves a candidate's calls are spread over in the preparation
     unsigned char* redo;       // wide form, perfect user: [slab_n] candidates gen_prep_pu_kernel left to gen_prep_kernel (NULL: all)
+    int npre;                  // prior calls per pattern: 1, or 2 with a change-estimation subset (the enumerated variables alone,
+                               // then all of U: reference ital.py:227-275)
+    int mixed;                 // the calls of a step differ in their number of variables (subset mode): gen_main_kernel<T> takes
+                               // the records of T variables out of the list, one launch per dimension that occurs
 };
 
 __device__ __forceinline__ long long pack_meta(int flags, int n, unsigned infi, unsigned closes) {
@@ -533,7 +539,15 @@ __global__ __launch_bounds__(128) void gen_prep_kernel(GArgs a, GPipe g) {
     const int row = d.cand[p];
     const int64_t gi = d.row_offset + row;
     const int nE = d.nE;
-    const int nU = nE + 1;            // plain mode: U = batch so far + candidate
+    const bool subset = d.subset_mode != 0;
+    // plain mode: U = batch so far + candidate.  With a change-estimation subset U = E (subset + picks), plus the candidate
+    // unless it is a member of E itself (score_generic_kernel, the single-kernel form, is the statement this follows)
+    int epos = -1;
+    if (subset)
+        for (int e = 0; e < nE; e++)
+            if (d.E_idx[e] == gi) epos = e;
+    const int nU = epos >= 0 ? nE : nE + 1;
+    const int cpos = epos >= 0 ? epos : nE;
     const int nr = d.n_picks + 1;
     for (int idx = lane; idx < nU * nU; idx += 64) {
         const int r = idx / nU, c = idx - r * nU;
@@ -545,11 +559,15 @@ __global__ __launch_bounds__(128) void gen_prep_kernel(GArgs a, GPipe g) {
     }
     for (int e = lane; e < nU; e += 64) muU[e] = e < nE ? d.E_mu[e] : d.mu[row];
     if (lane == 0) {
-        int rank = 0;
-        for (int e = 0; e < nE; e++) rank += (d.E_idx[e] < gi) ? 1 : 0;
-        for (int sidx = 0; sidx < nU; sidx++)
-            usort[sidx] = sidx < rank ? d.E_sort[sidx] : (sidx == rank ? nE : d.E_sort[sidx - 1]);
-        for (int v = 0; v < nr; v++) ipos[v] = v < d.n_picks ? d.pick_pos[v] : nE;
+        if (epos >= 0) {
+            for (int sidx = 0; sidx < nE; sidx++) usort[sidx] = d.E_sort[sidx];
+        } else {
+            int rank = 0;
+            for (int e = 0; e < nE; e++) rank += (d.E_idx[e] < gi) ? 1 : 0;
+            for (int sidx = 0; sidx < nU; sidx++)
+                usort[sidx] = sidx < rank ? d.E_sort[sidx] : (sidx == rank ? nE : d.E_sort[sidx - 1]);
+        }
+        for (int v = 0; v < nr; v++) ipos[v] = v < d.n_picks ? d.pick_pos[v] : cpos;
     }
     const int total = g.total;
     // this wave's share of the candidate's calls: whole passes of a.chunk calls
@@ -560,15 +578,17 @@ __global__ __launch_bounds__(128) void gen_prep_kernel(GArgs a, GPipe g) {
     MrgState rng = {d.seed[0], d.seed[1], d.seed[2], d.seed[3], d.seed[4], d.seed[5]};
     {
         const int64_t gpos = d.gpos ? d.gpos[p] : d.pos_offset + p;
-        int64_t before = gpos;
+        int64_t before = gpos, n_in = 0;
         for (int q = 0; q < d.n_dead; q++) before -= (d.dead_pos[q] < gpos) ? 1 : 0;
-        uint64_t off = (uint64_t)before * (uint64_t)d.draws_out;
+        for (int q = 0; q < d.n_in; q++) n_in += (d.in_pos[q] < gpos) ? 1 : 0;      // members of E ahead consume draws_in each
+        uint64_t off = (uint64_t)(before - n_in) * (uint64_t)d.draws_out + (uint64_t)n_in * (uint64_t)d.draws_in;
         if (d.draw_off) off = (uint64_t)d.draw_off[p];
+        // (several shares per candidate only where every call draws the same: never with a subset, nsplit == 1 there)
         off += (uint64_t)pass_lo * (uint64_t)a.chunk * (uint64_t)(nU >= 3 ? 8 * (2 * (nU - 1) - 1) : 0);
         rng = mrg_jump(d, rng, off);
     }
     wave_sync();
-    const bool clamp_prior = nr == 1;
+    const bool clamp_prior = !subset && nr == 1;
     double* meta = g.meta + (size_t)i * total * 2;
     for (int chunk0 = pass_lo * a.chunk; chunk0 < pass_hi * a.chunk && chunk0 < total; chunk0 += a.chunk) {
         Prep pp;
@@ -577,7 +597,7 @@ __global__ __launch_bounds__(128) void gen_prep_kernel(GArgs a, GPipe g) {
         const bool mine = lane < a.chunk && call < total;
         double* slab = slabs + (size_t)lane * a.stride;
         if (mine) {
-            const CallInfo ci = decode_call(d, p, call, g.cpp, 1, nr, g.npat);
+            const CallInfo ci = decode_call(d, p, call, g.cpp, g.npre, nr, g.npat);
             if (ci.kind != K_SKIP)
                 pp = prepare_call<false>(d, ci, nU, nr, ldS, muU, SigU, usort, ipos, clamp_prior, slab, slab + a.slab, nullptr);
         }
@@ -816,6 +836,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(ITAL_GEN_MA
         const long long m = __double_as_longlong(uniform_f64(src[0]));
         const unsigned int id = (unsigned int)uniform_f64(src[1]);
         const int n = (int)((m >> 8) & 0xff);
+        if (T > 0 && n != T) return;          // (wave-uniform; subset mode: another launch takes the records of n variables)
         const unsigned infi = (unsigned)((m >> 16) & 0xffffffu);
         const int ns = n * (n + 1) / 2 + n, ndim = n - 1;
         // the compile-time evaluators take every variable as bounded above (ITAL_QMC_FLIP): the record holds the factor and
@@ -870,7 +891,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(ITAL_GEN_MA
         // every regular call of this launch has the same size: one atomic for the whole list instead of one per wave
         // (185 k waves adding to one address cost 1.7 ms per noisy-user step)
         constexpr int ND = T > 1 ? T - 1 : 1;
-        pairs = (blockIdx.x == 0 && wid == 0) ? (unsigned long long)count * (16ull * P_TAB[(ND < 10 ? ND : 10) - 1] * ND) : 0ull;
+        if (!g.mixed)      // (mixed dimensions: every wave reports what it integrated -- instrumentation, off the timed path)
+            pairs = (blockIdx.x == 0 && wid == 0) ? (unsigned long long)count * (16ull * P_TAB[(ND < 10 ? ND : 10) - 1] * ND) : 0ull;
     } else {
         for (unsigned int e = blockIdx.x * (blockDim.x >> 6) + wid; e < count; e += nwaves) integrate(e);
     }
@@ -950,7 +972,7 @@ __global__ __launch_bounds__(256) void gen_combine_kernel(ital_gscore_desc d, GP
             const int fl = (int)(__double_as_longlong(meta[2 * call]) & 0xff);
             if (!(fl & 16)) {
                 const double value = meta[2 * call + 1];
-                const CallInfo ci = decode_call(d, p, call, cpp, 1, nr, npat);
+                const CallInfo ci = decode_call(d, p, call, cpp, g.npre, nr, npat);
                 if (entropy) {
                     if (nr == 1) {
                         if (ci.pat == 0) {
@@ -963,9 +985,14 @@ __global__ __launch_bounds__(256) void gen_combine_kernel(ital_gscore_desc d, GP
                         kind = 2;
                     }
                 } else if (ci.kind == K_UPDATED) {
-                    const double pr = meta[2 * (call / cpp) * cpp + 1];       // the pattern's prior probability
-                    const double cur = (log(value + d.eps) - log(pr + d.eps)) * ci.weight;
-                    term = (d.label_mode != 0 || d.mc_rel > 0) ? cur : cur * pr;   // sampled patterns are not weighted
+                    // the pattern's prior probability: of the enumerated variables alone (the weight) and -- with a
+                    // change-estimation subset -- of all of U (the reference of the logarithm), ital.py:227-275
+                    const int base = (call / cpp) * cpp;
+                    const double pr = meta[2 * base + 1];
+                    const double prl = g.npre == 2 ? meta[2 * (base + 1) + 1] : pr;
+                    const double cur = (log(value + d.eps) - log(prl + d.eps)) * ci.weight;
+                    const bool lm = d.label_mode != 0 && g.npre == 1;          // (label estimates: plain mode only)
+                    term = (lm || d.mc_rel > 0) ? cur : cur * pr;   // sampled patterns are not weighted
                     kind = 1;
                 }
             }
@@ -976,8 +1003,8 @@ __global__ __launch_bounds__(256) void gen_combine_kernel(ital_gscore_desc d, GP
             const double t_l = readlane_f64(term, l);
             if (k_l == 3) mi = t_l;
             else if (k_l == 2) mi += t_l;
-            else if (d.label_mode == 1) { if (t_l > mi) mi = t_l; }
-            else if (d.label_mode == 2) { if (mi == 0 || t_l < mi) mi = t_l; }
+            else if (d.label_mode == 1 && g.npre == 1) { if (t_l > mi) mi = t_l; }
+            else if (d.label_mode == 2 && g.npre == 1) { if (mi == 0 || t_l < mi) mi = t_l; }
             else mi += t_l;
         }
     }
@@ -1055,6 +1082,8 @@ int pipe_bail(PipeStreams* ps, hipStream_t stream, int rc) {
 struct PipePlan {
     bool ok;            // the step is the pipeline's
     bool fast;          // 3 .. 6 variables
+    bool sub;           // change-estimation subset (wide form whatever the dimension)
+    int npre;
     int n, nr;
     int64_t total;      // calls per candidate
     int npat, cpp;
@@ -1065,20 +1094,25 @@ struct PipePlan {
 
 PipePlan pipe_plan(const ital_gscore_desc* d) {
     PipePlan pl = {};
-    const int nr = d->n_picks + 1, n = d->nE + 1;
-    if (d->subset_mode || n < 1 || n > ITAL_GEN_TFIX_MAX || nr != n) return pl;
+    const int nr = d->n_picks + 1, n = d->nE + 1;      // n: the most variables a call of this step has (U = E + candidate)
+    const bool subset = d->subset_mode != 0;
+    if (n < 1 || n > ITAL_GEN_TFIX_MAX || nr < 1 || (subset ? nr > n : nr != n)) return pl;
+    if (subset && (!ITAL_GEN_PIPE_SUBSET || d->fb_mode == 3)) return pl;
     if (d->clip_cov > 0 && d->clip_cov < 1 && n > 5) return pl;
     const double npat = d->mc_rel > 0 ? (double)d->mc_rel : pow(2.0, nr);
     const double nfb = d->fb_mode == 3 ? 0.0 : d->fb_mode == 0 ? 1.0 : (d->mc_fb > 0 ? (double)d->mc_fb : (d->fb_mode == 1 ? pow(2.0, nr) : pow(3.0, nr) - 1));
-    if (npat * (1 + nfb) > (double)ITAL_GENERIC_MAX_CALLS) return pl;
+    const int npre = subset ? 2 : 1;                   // prior calls per pattern (ital.py:227-275: enumerated variables, then all of U)
+    if (npat * (npre + nfb) > (double)ITAL_GENERIC_MAX_CALLS) return pl;
     pl.ok = true;
-    pl.fast = n <= 6;
+    pl.sub = subset;
+    pl.npre = npre;
+    pl.fast = !subset && n <= 6;                       // (a subset always takes the wide form: its calls differ in dimension)
     pl.n = n; pl.nr = nr;
-    pl.npat = (int)npat; pl.cpp = 1 + (int)nfb;
+    pl.npat = (int)npat; pl.cpp = npre + (int)nfb;
     pl.total = (int64_t)pl.npat * pl.cpp;
     pl.lat = 2 + n * (n + 1) / 2 + n;
     pl.R = pl.lat + 4 * (n - 1) + 8;
-    if (n <= 2) {                      // closed forms: the verdicts are the values
+    if (n <= 2 && !subset) {           // closed forms: the verdicts are the values
         pl.per_cand = pl.total * 2;
         pl.chunk_max = 0;
     } else if (pl.fast) {
@@ -1100,7 +1134,7 @@ extern "C" int64_t ital_score_generic_workspace(const ital_gscore_desc* d) {
     if (!d || d->n_cand <= 0) return 0;
     const PipePlan pl = pipe_plan(d);
     if (!pl.ok) return 0;
-    if (!pl.fast) return 2 * (1 + pl.per_cand * d->n_cand);
+    if (!pl.fast && (pl.sub || pl.n > 2)) return 2 * (1 + pl.per_cand * d->n_cand);
     if (pl.n <= 2) return HDR + pl.per_cand * d->n_cand;
     int64_t ch = pl.chunk_max;
     while (ch > 4096 && ch / 2 >= d->n_cand * pl.total) ch >>= 1;
@@ -1113,8 +1147,9 @@ int ital_gen_pipeline(const ital_gscore_desc* d, hipStream_t stream) {
     const int n = pl.n;
     GPipe g = {};
     g.total = (int)pl.total; g.npat = pl.npat; g.cpp = pl.cpp; g.n = n; g.R = pl.R; g.lat = pl.lat;
-    if (pl.fast) (void)ital_score_generic_join(stream);     // (a deferred call still pending: these forms share their buffers between calls)
-    if (n <= 2) {
+    g.npre = pl.npre; g.mixed = pl.sub ? 1 : 0;
+    if (pl.fast || (n <= 2 && !pl.sub)) (void)ital_score_generic_join(stream);     // (a deferred call still pending: these forms share their buffers between calls)
+    if (n <= 2 && !pl.sub) {
         // ---- one or two variables: closed forms and combine on the caller's stream, slabs of the workspace
         int64_t S = (d->work_doubles - HDR) / pl.per_cand;
         if (S < 1) return 1;
@@ -1135,11 +1170,28 @@ int ital_gen_pipeline(const ital_gscore_desc* d, hipStream_t stream) {
     PipeStreams* ps = pipe_streams();
     if (!ps) return ital_fail(-12, "ital_score_generic: cannot create the pipeline's streams");
 
-    const size_t lds_m = (size_t)4 * (pl.lat - 2 + 16 * (n - 1) + gen_main_yld(n)) * sizeof(double);   // (gen_main_yld: tail queue + conditioned values)
+    // dimensions of the calls that may need a lattice sum: n in plain mode; with a subset the enumerated variables alone (nr),
+    // E (nE = n - 1: a candidate that is a member of E) and E + candidate (n) -- one gen_main_kernel<T> launch each
+    int dims[3] = {n, 0, 0};
+    int ndims = 1;
+    if (pl.sub) {
+        ndims = 0;
+        const int cands[3] = {pl.nr, n - 1, n};
+        for (int q = 0; q < 3; q++) {
+            bool dup = cands[q] < 3;
+            for (int r_ = 0; r_ < ndims; r_++) dup = dup || dims[r_] == cands[q];
+            if (!dup) dims[ndims++] = cands[q];
+        }
+    }
+    // LDS of a lattice-sum workgroup (4 waves): slab + lattices sized for the step's largest call, tail queue and conditioned
+    // values as the instantiation needs them (gen_main_yld)
+    size_t lds_m = 0;
+    for (int q = 0; q < ndims; q++)
+        lds_m = std::max(lds_m, (size_t)4 * (pl.lat - 2 + 16 * (n - 1) + gen_main_yld(dims[q])) * sizeof(double));
     const size_t lds_m0 = (size_t)(pl.lat - 2 + 16 * (n - 1) + ITAL_GEN_TAILQ + 2 * (GN - 1) * 64) * sizeof(double);   // one wave
     // label_estimation 'optimistic' / 'pessimistic' (plain mode only): sums that decide an exact comparison are formed again in
     // the reference's order
-    const int exact = (d->label_mode != 0 && d->fb_mode != 3 && n <= GEN_EXACT_MAX) ? 1 : 0;
+    const int exact = (d->label_mode != 0 && d->fb_mode != 3 && n <= GEN_EXACT_MAX && !pl.sub) ? 1 : 0;
     const size_t lds_x = (size_t)(n * (n + 1) / 2 + n + 16 * (n - 1) + 128 + 16 * P_TAB[(n - 1 < 10 ? n - 1 : 10) - 1]) * sizeof(double);
     if (exact && lds_x > 48 * 1024) {
         static ItalLdsFlags exact_flags;
@@ -1148,9 +1200,10 @@ int ital_gen_pipeline(const ital_gscore_desc* d, hipStream_t stream) {
     }
 #define ITAL_GEN_MAIN(T_) case T_: ITAL_LAUNCH(gen_main_kernel<T_>, dim3(ITAL_GEN_ONE_TRIP(T_) ? (g.cap + 3) / 4 : 768), dim3(256), lds_m, ps->main, g, d->vk, d->pair_count, exact); break;
 #define ITAL_GEN_MAIN_LDS(T_) case T_: { static ItalLdsFlags f_; rc_lds = ital_raise_lds_limit(reinterpret_cast<const void*>(&gen_main_kernel<T_>), (int)lds_m, f_, "ital_score_generic"); } break;
-    if (lds_m > 48 * 1024) {       // conditioned values of the last stages in LDS (ITAL_BIG_YLDS) can take the workgroup beyond the default limit
+    if (lds_m > 48 * 1024)         // conditioned values of the last stages in LDS (ITAL_BIG_YLDS) can take the workgroup beyond the default limit
+      for (int q = 0; q < ndims; q++) {
         int rc_lds = 0;
-        switch (n) {
+        switch (dims[q]) {
             ITAL_GEN_MAIN_LDS(7) ITAL_GEN_MAIN_LDS(8) ITAL_GEN_MAIN_LDS(9) ITAL_GEN_MAIN_LDS(10) ITAL_GEN_MAIN_LDS(11) ITAL_GEN_MAIN_LDS(12)
             ITAL_GEN_MAIN_LDS(13) ITAL_GEN_MAIN_LDS(14) ITAL_GEN_MAIN_LDS(15) ITAL_GEN_MAIN_LDS(16)
         }
@@ -1158,7 +1211,8 @@ int ital_gen_pipeline(const ital_gscore_desc* d, hipStream_t stream) {
     }
 #undef ITAL_GEN_MAIN_LDS
 #define ITAL_GEN_MAINS()                                                                                                      \
-    switch (n) {                                                                                                              \
+    for (int q_ = 0; q_ < ndims; q_++)                                                                                        \
+    switch (dims[q_]) {                                                                                                       \
         ITAL_GEN_MAIN(3) ITAL_GEN_MAIN(4) ITAL_GEN_MAIN(5) ITAL_GEN_MAIN(6) ITAL_GEN_MAIN(7) ITAL_GEN_MAIN(8) ITAL_GEN_MAIN(9)  \
         ITAL_GEN_MAIN(10) ITAL_GEN_MAIN(11) ITAL_GEN_MAIN(12) ITAL_GEN_MAIN(13) ITAL_GEN_MAIN(14) ITAL_GEN_MAIN(15)            \
         ITAL_GEN_MAIN(16)                                                                                                     \
@@ -1273,13 +1327,13 @@ int ital_gen_pipeline(const ital_gscore_desc* d, hipStream_t stream) {
     if (lds_p > 160 * 1024) return ital_fail(-12, "ital_score_generic: LDS budget exceeded");
     // a slab is a few hundred candidates: one wave each would leave most of the chip idle during the preparation
     const int npass = (int)((pl.total + chunk_p - 1) / chunk_p);
-    g.nsplit = d->mc_fb > 0 ? 1 : (npass < ITAL_GEN_PREP_SPLIT ? (npass < 1 ? 1 : npass) : ITAL_GEN_PREP_SPLIT);
+    g.nsplit = (d->mc_fb > 0 || pl.sub) ? 1 : (npass < ITAL_GEN_PREP_SPLIT ? (npass < 1 ? 1 : npass) : ITAL_GEN_PREP_SPLIT);
     static ItalLdsFlags prep_flags;
     if (const int rc = ital_raise_lds_limit(reinterpret_cast<const void*>(&gen_prep_kernel), 160 * 1024, prep_flags, "ital_score_generic"))
         return rc;
     // perfect user with a few patterns per candidate (sampled patterns): the cooperative preparation, gen_prep_kernel behind it
     // for the candidates it flags
-    const bool pu = ITAL_GEN_PREP_PU && d->fb_mode == 0 && d->mc_fb == 0 && pl.cpp == 2 && pl.npat <= 16;
+    const bool pu = ITAL_GEN_PREP_PU && !pl.sub && d->fb_mode == 0 && d->mc_fb == 0 && pl.cpp == 2 && pl.npat <= 16;
     GArgs apu = ap;
     size_t lds_pu = 0;
     if (pu) {

@@ -14,6 +14,29 @@ import numpy as np
 from .gp import GaussianProcess
 
 
+class IdSet(set):
+    """A set that counts its in-place changes (`changes`): what the learners keep their relevant / irrelevant / unnameable
+    ids in (public attributes of the reference, retrieval_base.py:50-52).  Behaves as a set everywhere else."""
+
+    def __init__(self, *a):
+        set.__init__(self, *a)
+        self.changes = 0
+
+    def _changing(name):        # noqa: N805 -- class-body helper
+        base = getattr(set, name)
+
+        def method(self, *a, **kw):
+            self.changes += 1
+            return base(self, *a, **kw)
+        method.__name__ = name
+        return method
+
+    for _n in ("add", "discard", "remove", "pop", "clear", "update", "difference_update", "intersection_update",
+               "symmetric_difference_update", "__ior__", "__iand__", "__isub__", "__ixor__"):
+        locals()[_n] = _changing(_n)
+    del _n, _changing
+
+
 class UnseenList(object):
     """The ascending list of samples without feedback (reference retrieval_base.py:78-87) as an ascending base array plus a
     short sorted list of ids taken out of it since: what a round of the retrieval loop needs from the list -- its length,
@@ -201,7 +224,9 @@ class ActiveRetrievalBase(object):
     # the three id sets are public attributes, as in the reference; assigning a new set to one of them (rather than going
     # through update()) invalidates the derived candidate bookkeeping
     def _set_ids(self, name, value):
-        self.__dict__[name] = value
+        # kept as a set that counts its in-place changes (`IdSet`): the candidate bookkeeping notices ANY change made behind
+        # update()'s back, also one that leaves the sizes as they were (an id swapped for another)
+        self.__dict__[name] = value if isinstance(value, IdSet) else IdSet(value)
         self.__dict__["_unseen"] = None
 
     def _get_ids(self, name):
@@ -215,7 +240,9 @@ class ActiveRetrievalBase(object):
     unnameable_ids = property(lambda self: self._get_ids("_unnameable_ids"), lambda self, v: self._set_ids("_unnameable_ids", v))
 
     def _id_sizes(self):
-        return (len(self.relevant_ids), len(self.irrelevant_ids), len(self.unnameable_ids))
+        """Token of the three id sets' state: sizes and change counters."""
+        sets = (self.relevant_ids, self.irrelevant_ids, self.unnameable_ids)
+        return tuple(len(q) for q in sets) + tuple(getattr(q, "changes", -1) for q in sets)
 
     def _unseen_list(self):
         """The samples without feedback as an UnseenList, kept between calls: update() takes the newly seen samples out of
@@ -258,7 +285,7 @@ class ActiveRetrievalBase(object):
     def update(self, feedback):
         """reference retrieval_base.py:105-126"""
         rel, irr, unnameable = self.partition_feedback(feedback)
-        sizes_before = (len(self.relevant_ids), len(self.irrelevant_ids), len(self.unnameable_ids))
+        sizes_before = self._id_sizes()
         if len(rel) + len(irr) > 0:
             self.gp.update(rel + irr, np.concatenate((np.ones(len(rel)), -1 * np.ones(len(irr)))),
                            row_cache=self._batch_rows())

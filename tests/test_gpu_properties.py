@@ -229,7 +229,13 @@ def test_one_million_candidates(dev):
 
 @pytest.mark.parametrize("kw,n,k", [(dict(label_prob=0.6, mistake_prob=0.2), 300, 4), (dict(mistake_prob=0.15), 200, 5),
                                     (dict(monte_carlo_num_rel=1), 400, 9), (dict(label_estimation="pessimistic", mistake_prob=0.1), 150, 3),
-                                    (dict(monte_carlo_num_rel=1), 250, 15)])    # 10-14 variables: three chains per lane
+                                    (dict(monte_carlo_num_rel=1), 250, 15),     # 10-14 variables: three chains per lane
+                                    # round 5: change-estimation subsets through the pipeline's wide form (calls of nr, |E| and
+                                    # |E| + 1 variables in one step; members of E among the candidates; sampled feedback)
+                                    (dict(change_estimation_subset=5), 200, 4),
+                                    (dict(change_estimation_subset=3, label_prob=0.7, mistake_prob=0.2), 150, 3),
+                                    (dict(change_estimation_subset=4, mistake_prob=0.2, monte_carlo_num_fb=2), 120, 4),
+                                    (dict(change_estimation_subset=8, monte_carlo_num_rel=2), 160, 6)])
 def test_general_scorer_pipeline_equals_its_single_kernel(dev, kw, n, k):
     """Plain mode of ital_score_generic: the pipeline of kernels on internal streams (gen_pipeline.hip: verdict / build /
     lattice sums / combine up to 6 variables, prepare / lattice sums / combine beyond; slabs and chunks of the workspace)
@@ -378,6 +384,11 @@ def test_unseen_bookkeeping_survives_sets_changed_behind_update(dev):
     assert 50 in L.get_unseen() and 60 not in L.get_unseen() and len(L.get_unseen()) == 196
     L.irrelevant_ids.add(70)                              # in-place change: the sizes differ
     assert 70 not in L.get_unseen()
+    L.unnameable_ids.remove(61)                           # in-place swap: the sizes do NOT differ (round 5: the sets count
+    L.unnameable_ids.add(62)                              # their changes, retrieval_base.IdSet)
+    assert 61 in L.get_unseen() and 62 not in L.get_unseen()
+    L.unnameable_ids.remove(62)
+    L.unnameable_ids.add(61)
     got = L.fetch_unlabelled(3)
     assert not (set(got) & {3, 9, 60, 61, 70})
     mvn_stream.GLOBAL.reset()

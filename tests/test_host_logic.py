@@ -438,3 +438,20 @@ def test_size_helpers_of_the_c_abi():
     slabs = -(-25000 // ((1 << 27) // per8))
     assert lib.ital_sel_parts_len(8, 25000, 1 << 27) == 3 * (25000 // 32 + 64 + slabs)
     assert lib.ital_sel_parts_len(8, 25000, 1) == 3 * (25000 // 32 + 64 + 25000)      # less than one candidate: a slab each
+
+
+def test_id_sets_count_their_in_place_changes():
+    """relevant_ids / irrelevant_ids / unnameable_ids are public sets as in the reference (retrieval_base.py:50-52); the learners
+    keep them as IdSet so that ANY in-place change -- also one that leaves the size alone -- invalidates the kept candidate list."""
+    import copy
+    import pickle
+    from ital_amd.retrieval_base import IdSet
+    s = IdSet([1, 2])
+    assert s == {1, 2} and s.changes == 0 and isinstance(s, set)
+    s.add(3); s |= {4}; s.discard(1); s.remove(2); s.update([7, 8])
+    assert s == {3, 4, 7, 8} and s.changes == 5
+    assert type(s | {9}) is set and s.changes == 5                  # non-mutating operators do not count
+    s.pop(); s.clear()
+    assert s.changes == 7 and len(s) == 0
+    t = IdSet([5])
+    assert copy.deepcopy(t) == {5} and pickle.loads(pickle.dumps(t)) == {5}
