@@ -314,6 +314,17 @@ __device__ __forceinline__ double mvn_phi(double z) { return mvn_phi(z, LitK());
 #endif
 template <class K>
 __device__ __forceinline__ double mvn_phi_lat(double z, const K& kk) { return mvn_phi<K, ITAL_LATTICE_PHI_CF != 0>(z, kk); }
+// A coefficient policy marked "MVNPHI as published, continued fraction beyond |z| = 7.07": the lattice loops instantiated with
+// WithCF<K> take the far-tail branch.  Needed where a tiny orthant probability enters an objective with a weight of order 1:
+// with a change-estimation subset the reference weighs log(p_U + eps) -- the joint probability over subset + batch +
+// candidate -- with the probability of the enumerated variables alone (ital.py:227-275).  For a candidate that nearly
+// duplicates a subset member p_U is ~1e-10 .. 1e-12, a product with a far-tail Phi among its factors, and the rational's
+// 1e-8 .. 1e-6 RELATIVE drift out there reaches the score (golden iris_ce5, candidate 97: 6e-8 at step 2, 1.6e-5 at step 4).
+// Everywhere else a probability is weighted by itself and the absolute 5e-21 is all that matters.
+template <class K>
+struct WithCF : K {};
+template <class K>
+__device__ __forceinline__ double mvn_phi_lat(double z, const WithCF<K>& kk) { return mvn_phi<K, true>(z, static_cast<const K&>(kk)); }
 
 #ifndef ITAL_TAIL_LIT_S
 #define ITAL_TAIL_LIT_S 1     // coefficients of the Phi^-1 tail branch as in-place scalars (lit_s above)

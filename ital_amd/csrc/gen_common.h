@@ -8,6 +8,8 @@
 #include <math.h>
 #include <stdint.h>
 
+#include <type_traits>
+
 #include "device_math.h"
 #include "ital_hip.h"
 #include "ital_internal.h"
@@ -87,7 +89,11 @@
 #define ITAL_GEN_PREP_SPLIT 4   // preparation waves per candidate in the pipeline
 #endif
 #ifndef ITAL_GEN_PIPE_SUBSET
-#define ITAL_GEN_PIPE_SUBSET 1   // change-estimation subsets (without clip_cov, up to 16 variables) through the pipeline's wide form
+#define ITAL_GEN_PIPE_SUBSET 1   // change-estimation subsets (without clip_cov) through the pipeline's wide form
+#endif
+#ifndef ITAL_GEN_SUB_MAX
+#define ITAL_GEN_SUB_MAX 14      // ... up to this many variables (subset + batch + candidate; the instantiations with MVNPHI's
+                                 // far-tail branch fit their register budget without scratch up to here)
 #endif
 #ifndef ITAL_GEN_PREP_PU
 #define ITAL_GEN_PREP_PU 1   // wide form, perfect user, <= 16 patterns per candidate: the cooperative preparation (gen_prep_pu_kernel)
@@ -786,7 +792,7 @@ static __device__ double qmc_eval_lds(int n, const double* __restrict__ slab, un
 // One MVNDST pass for a call of compile-time dimension T whose rows all close their own group (no linearly dependent
 // variable): the evaluator of the perfect-user fast path (score.hip) -- factor and limits as wave-uniform scalars, fully
 // unrolled, NHF lattice items x antithetic partner per lane.
-template <int T, int NHF = 2, bool FL = false>
+template <int T, int NHF = 2, bool FL = false, bool CF = false>
 __device__ __forceinline__ double qmc_eval_fixed_inl(const double* __restrict__ slab, unsigned infi,
                                                      const double* __restrict__ lat, int lane, double* __restrict__ tailq) {
     constexpr int NDIM = T - 1, NCOV = T * (T + 1) / 2, NCOR = T * (T - 1) / 2;
@@ -799,9 +805,9 @@ __device__ __forceinline__ double qmc_eval_fixed_inl(const double* __restrict__ 
         for (int j = 0; j < i; j++) cf[i * (i - 1) / 2 + j] = uniform_f64(slab[pidx(i, j)]);
     }
 #if ITAL_GEN_HOTK
-    HotK kk;
+    typename std::conditional<CF, WithCF<HotK>, HotK>::type kk;      // CF: MVNPHI's far-tail branch (device_math.h WithCF)
     kk.load();
-    const double acc = qmc_lane_sum<T, HotK, NHF, FL>(lat, cf, lm, infi, tailq, lane, kk);
+    const double acc = qmc_lane_sum<T, decltype(kk), NHF, FL>(lat, cf, lm, infi, tailq, lane, kk);
 #else
     const double acc = qmc_lane_sum<T, LitK, NHF, FL>(lat, cf, lm, infi, tailq, lane);
 #endif

@@ -815,7 +815,9 @@ __global__ __launch_bounds__(128) void gen_prep_pu_kernel(GArgs a, GPipe g) {
 // variables, every row closes its own group) with the compile-time evaluator, one call per wave in a grid that covers the
 // capacity of the list (ITAL_GEN_ONE_TRIP); T == 0: the calls with linearly dependent variables, from the back of the
 // list, with the runtime evaluator in a small fixed grid of waves that stride over them.
-template <int T>
+// CF: Phi with MVNPHI's continued fraction beyond |z| = 7.07 (device_math.h WithCF) -- the launches of a step with a
+// change-estimation subset; the runtime evaluator (T == 0) always has it.
+template <int T, bool CF = false>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(ITAL_GEN_MAIN_WAVES(T), ITAL_GEN_MAIN_WAVES(T)))) void gen_main_kernel(
     GPipe g, const double* __restrict__ vk, unsigned long long* pair_count, int exact) {
     extern __shared__ double lds_all[];
@@ -858,9 +860,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(ITAL_GEN_MA
         if (T >= 7) {
             constexpr int TB = T >= 7 ? T : 7, NDIMB = TB - 1;
 #if ITAL_GEN_BIG_HOTK
-            ITAL_GEN_BIG_COEF(TB) kk;      // exp coefficients as vector-register operands (device_math.h), as in the perfect-user kernel
+            // (the far-tail branch of the CF instantiations takes a few registers: two exp coefficients fewer in registers there)
+            constexpr int KN = ITAL_GEN_BIG_KEN(TB) - (CF && ITAL_GEN_BIG_KEN(TB) >= 2 ? 2 : 0);
+            typename std::conditional<CF, WithCF<HotKEn<KN>>, ITAL_GEN_BIG_COEF(TB)>::type kk;      // exp coefficients as vector-register operands (device_math.h), as in the perfect-user kernel
             kk.load();
-            value = wave_sum(qmc_lane_sum_big<TB, ITAL_GEN_BIG_NCB(TB), ITAL_GEN_BIG_COEF(TB), FL, ITAL_BIG_YLDS(TB), ITAL_BIG_GROUP(TB)>(
+            value = wave_sum(qmc_lane_sum_big<TB, ITAL_GEN_BIG_NCB(TB), decltype(kk), FL, ITAL_BIG_YLDS(TB), ITAL_BIG_GROUP(TB)>(
                         rec + lds_lat, rec, infi, tailq, lane, kk, tailq + TQ)) /
                     (16.0 * P_TAB[(NDIMB < 10 ? NDIMB : 10) - 1]);
 #else
@@ -870,7 +874,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(ITAL_GEN_MA
 #endif
         } else if (T > 0) {
             constexpr int TF = T > 0 && T < 7 ? T : 3;
-            value = qmc_eval_fixed_inl<TF, ITAL_GEN_FIXED_NH(TF), FL>(rec, infi, rec + lds_lat, lane, tailq);
+            value = qmc_eval_fixed_inl<TF, ITAL_GEN_FIXED_NH(TF), FL, CF>(rec, infi, rec + lds_lat, lane, tailq);
         }
         else value = qmc_eval_lds(n, rec, infi, (unsigned)((m >> 40) & 0xffffffu), rec + lds_lat, lane, tailq, tailq + TQ);
         if (lane == 0) {
@@ -1097,7 +1101,7 @@ PipePlan pipe_plan(const ital_gscore_desc* d) {
     const int nr = d->n_picks + 1, n = d->nE + 1;      // n: the most variables a call of this step has (U = E + candidate)
     const bool subset = d->subset_mode != 0;
     if (n < 1 || n > ITAL_GEN_TFIX_MAX || nr < 1 || (subset ? nr > n : nr != n)) return pl;
-    if (subset && (!ITAL_GEN_PIPE_SUBSET || d->fb_mode == 3)) return pl;
+    if (subset && (!ITAL_GEN_PIPE_SUBSET || d->fb_mode == 3 || n > ITAL_GEN_SUB_MAX)) return pl;
     if (d->clip_cov > 0 && d->clip_cov < 1 && n > 5) return pl;
     const double npat = d->mc_rel > 0 ? (double)d->mc_rel : pow(2.0, nr);
     const double nfb = d->fb_mode == 3 ? 0.0 : d->fb_mode == 0 ? 1.0 : (d->mc_fb > 0 ? (double)d->mc_fb : (d->fb_mode == 1 ? pow(2.0, nr) : pow(3.0, nr) - 1));
@@ -1198,8 +1202,17 @@ int ital_gen_pipeline(const ital_gscore_desc* d, hipStream_t stream) {
         if (const int rc = ital_raise_lds_limit(reinterpret_cast<const void*>(&gen_exact_kernel), 64 * 1024, exact_flags, "ital_score_generic"))
             return rc;
     }
-#define ITAL_GEN_MAIN(T_) case T_: ITAL_LAUNCH(gen_main_kernel<T_>, dim3(ITAL_GEN_ONE_TRIP(T_) ? (g.cap + 3) / 4 : 768), dim3(256), lds_m, ps->main, g, d->vk, d->pair_count, exact); break;
-#define ITAL_GEN_MAIN_LDS(T_) case T_: { static ItalLdsFlags f_; rc_lds = ital_raise_lds_limit(reinterpret_cast<const void*>(&gen_main_kernel<T_>), (int)lds_m, f_, "ital_score_generic"); } break;
+// (subset mode: the instantiations with MVNPHI's far-tail branch, up to ITAL_GEN_SUB_MAX variables -- pipe_plan sends larger
+// subsets to the single kernel; TS_ keeps the dimensions beyond from being instantiated at all)
+#define ITAL_GEN_MAIN(T_) case T_: {                                                                                           \
+        constexpr int TS_ = T_ <= ITAL_GEN_SUB_MAX ? T_ : ITAL_GEN_SUB_MAX;                                                    \
+        if (pl.sub) ITAL_LAUNCH((gen_main_kernel<TS_, true>), dim3(ITAL_GEN_ONE_TRIP(T_) ? (g.cap + 3) / 4 : 768), dim3(256), lds_m, ps->main, g, d->vk, d->pair_count, exact); \
+        else ITAL_LAUNCH((gen_main_kernel<T_, false>), dim3(ITAL_GEN_ONE_TRIP(T_) ? (g.cap + 3) / 4 : 768), dim3(256), lds_m, ps->main, g, d->vk, d->pair_count, exact); \
+        } break;
+#define ITAL_GEN_MAIN_LDS(T_) case T_: { static ItalLdsFlags f_, fc_;                                                         \
+        constexpr int TS_ = T_ <= ITAL_GEN_SUB_MAX ? T_ : ITAL_GEN_SUB_MAX;                                                    \
+        rc_lds = pl.sub ? ital_raise_lds_limit(reinterpret_cast<const void*>(&gen_main_kernel<TS_, true>), (int)lds_m, fc_, "ital_score_generic") \
+                        : ital_raise_lds_limit(reinterpret_cast<const void*>(&gen_main_kernel<T_, false>), (int)lds_m, f_, "ital_score_generic"); } break;
     if (lds_m > 48 * 1024)         // conditioned values of the last stages in LDS (ITAL_BIG_YLDS) can take the workgroup beyond the default limit
       for (int q = 0; q < ndims; q++) {
         int rc_lds = 0;
@@ -1217,7 +1230,7 @@ int ital_gen_pipeline(const ital_gscore_desc* d, hipStream_t stream) {
         ITAL_GEN_MAIN(10) ITAL_GEN_MAIN(11) ITAL_GEN_MAIN(12) ITAL_GEN_MAIN(13) ITAL_GEN_MAIN(14) ITAL_GEN_MAIN(15)            \
         ITAL_GEN_MAIN(16)                                                                                                     \
     }                                                                                                                         \
-    ITAL_LAUNCH(gen_main_kernel<0>, dim3(256), dim3(64), lds_m0, ps->main, g, d->vk, d->pair_count, exact);                      \
+    ITAL_LAUNCH((gen_main_kernel<0, false>), dim3(256), dim3(64), lds_m0, ps->main, g, d->vk, d->pair_count, exact);             \
     if (exact) ITAL_LAUNCH(gen_exact_kernel, dim3(g.cap < 4096u ? g.cap : 4096u), dim3(64), lds_x, ps->main, g, d->vk, g.cap)
 
     if (pl.fast) {
