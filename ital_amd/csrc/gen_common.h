@@ -92,7 +92,7 @@
 #define ITAL_GEN_PIPE_SUBSET 1   // change-estimation subsets (without clip_cov) through the pipeline's wide form
 #endif
 #ifndef ITAL_GEN_SUB_MAX
-#define ITAL_GEN_SUB_MAX 14      // ... up to this many variables (subset + batch + candidate; the instantiations with MVNPHI's
+#define ITAL_GEN_SUB_MAX 13      // ... up to this many variables (subset + batch + candidate; the instantiations with MVNPHI's
                                  // far-tail branch fit their register budget without scratch up to here)
 #endif
 #ifndef ITAL_GEN_PREP_PU

@@ -628,7 +628,7 @@ __global__ __launch_bounds__(128) void gen_prep_kernel(GArgs a, GPipe g) {
                 double* rec = g.recs + (size_t)id * g.R;
                 rec[0] = __longlong_as_double(pack_meta(pp.flags, pp.n, pp.infi, pp.closes));
                 rec[1] = (double)id;
-                write_slab(pp.n, slab, (regular && ITAL_QMC_FLIP) ? pp.infi : 0u, rec + 2);
+                write_slab(pp.n, slab, (regular && ITAL_QMC_FLIP && !g.mixed) ? pp.infi : 0u, rec + 2);      // (subset mode: as MVNDFN has it)
                 make_lattice_packed(mrg_jump(d, rng, (uint64_t)(incl - my_draws)), pp.n, slab, rec + g.lat);   // the slab is free now
                 if (regular) g.list[lbase + (unsigned int)__popcll(em & ((1ull << lane) - 1ull))] = id;
                 else g.list[g.cap - 1u - cbase - (unsigned int)__popcll(cm & ((1ull << lane) - 1ull))] = id;
@@ -815,8 +815,16 @@ __global__ __launch_bounds__(128) void gen_prep_pu_kernel(GArgs a, GPipe g) {
 // variables, every row closes its own group) with the compile-time evaluator, one call per wave in a grid that covers the
 // capacity of the list (ITAL_GEN_ONE_TRIP); T == 0: the calls with linearly dependent variables, from the back of the
 // list, with the runtime evaluator in a small fixed grid of waves that stride over them.
-// CF: Phi with MVNPHI's continued fraction beyond |z| = 7.07 (device_math.h WithCF) -- the launches of a step with a
-// change-estimation subset; the runtime evaluator (T == 0) always has it.
+// CF ("reference arithmetic"): the launches of a step with a change-estimation subset.  There the reference weighs
+// log(p_U + eps) -- the joint probability over subset + batch + candidate -- with the probability of the enumerated variables
+// alone (ital.py:227-275): for a candidate that nearly duplicates a subset member p_U is ~1e-10, EVERY lattice point of it
+// runs through intervals [d, 1] with d within 1e-12 of 1, and MVNDFN's own rounding there (the argument d + x (1 - d) of
+// Phi^-1 carries 1e-4 relative noise in its distance from 1) is part of the value the reference returns -- with a weight of
+// order 1 it reaches the score (golden iris_ce5, candidate 97 next to subset members 96 and 98: 6e-8 at step 2, 1.6e-5 at
+// step 4 with the all-upper form).  Everywhere else a probability is weighted by itself and none of this is visible.  So
+// these instantiations evaluate MVNDFN as written: lower-bounded variables stay lower-bounded (no ITAL_QMC_FLIP: the
+// record holds the factor unsigned), Phi is MVNPHI with its continued fraction beyond |z| = 7.07 (device_math.h WithCF) --
+// the arithmetic of the runtime evaluator (T == 0, and the single kernel), at the speed of the compile-time ones.
 template <int T, bool CF = false>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(ITAL_GEN_MAIN_WAVES(T), ITAL_GEN_MAIN_WAVES(T)))) void gen_main_kernel(
     GPipe g, const double* __restrict__ vk, unsigned long long* pair_count, int exact) {
@@ -843,7 +851,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(ITAL_GEN_MA
         const int ns = n * (n + 1) / 2 + n, ndim = n - 1;
         // the compile-time evaluators take every variable as bounded above (ITAL_QMC_FLIP): the record holds the factor and
         // the limits with the signs already in place, the shifts of a negated variable move by 1/2 here
-        const unsigned fl = (T > 0 && ITAL_QMC_FLIP) ? infi : 0u;
+        const unsigned fl = (T > 0 && ITAL_QMC_FLIP && !CF) ? infi : 0u;
         for (int q = lane; q < ns; q += 64) rec[q] = src[2 + q];
         {   // unpack the lattices: generator = vk[n][index], shift = integer * 1/(m1 + 1) exactly as MVNUNI forms it
             const unsigned int* shifts = reinterpret_cast<const unsigned int*>(src + g.lat);
@@ -854,7 +862,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(ITAL_GEN_MA
                 rec[lds_lat + 8 * ndim + q] = (double)shifts[q] * MRG_INVMP1 + (((fl >> j) & 1u) ? 0.5 : 0.0);
             }
         }
-        constexpr bool FL = T > 0 && ITAL_QMC_FLIP != 0;
+        constexpr bool FL = T > 0 && ITAL_QMC_FLIP != 0 && !CF;
         wave_sync();
         double value;
         if (T >= 7) {

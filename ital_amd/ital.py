@@ -811,7 +811,7 @@ class ITAL(ActiveRetrievalBase):
                 desc.draws_out, desc.draws_in = draws_out, draws_in
                 desc.mi, desc.status = _ptr(mi), _ptr(gp.status)
                 desc.pair_count = _ptr(self.pair_counter)
-                if self.generic_pipeline and not self._clip_active() and nE + 1 <= (14 if subset_mode else 16):
+                if self.generic_pipeline and not self._clip_active() and nE + 1 <= (13 if subset_mode else 16):
                     # (round 5: with a change-estimation subset too -- the pipeline's wide form, one lattice-sum launch per
                     # dimension that occurs among the step's calls)
                     # workspace of the pipeline of kernels (verdicts, records of the calls to integrate): what one slab of
