@@ -343,7 +343,7 @@ def other_workloads(X, rel, device):
                              "ital_gscore_desc.pair_count: 240 of the 1296 calls per candidate at t = 4); time = the whole "
                              "ital_score_generic step (preparation of all 1296 calls, lattice sums, combine; the preparation "
                              "runs under the lattice sums on a second stream); avg_launch_ms = one t = 4 step"},
-                    **dict(pmc_fields("general", "void ital::gen_main_kernel<%d>" % BATCH, sec4), valu_issue_frac=None,
+                    **dict(pmc_fields("general", "void ital::gen_main_kernel<%d," % BATCH, sec4), valu_issue_frac=None,
                            traffic_note="traffic: per launch of gen_main_kernel, one of the ~12 slab launches of a step"))
     out["ital_general_user_k4"] = dict(res, roofline=roof,
                                        config="label_prob 0.5, mistake_prob 0.25: 3^t - 1 feedback configurations per pattern")
@@ -536,14 +536,44 @@ def k16_workload(device, n=1_000_000, d=512, k=16, mc=1):
            "peak_device_memory_gib": torch.cuda.max_memory_allocated(device) / 2 ** 30,
            "roofline": {"bound": "fp64-valu", "kernel": "gen_main_kernel<3..16> (lattice sums of ital_score_generic)", "achieved": ach,
                         "peak": FP64_VALU_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach / FP64_VALU_PEAK_TFLOPS,
-                        "pairs_counted_on_device": pairs, "seconds_steps_3_to_16": sec, "traffic": None,
+                        "pairs_counted_on_device": pairs, "seconds_steps_3_to_16": sec,
                         "note": "pairs = lattice points x (n - 1) of the calls that are integrated, counted by the kernels; time = "
                                 "the ital_score_generic steps of 3 .. 16 variables whole (preparation, lattice sums, combine, the "
-                                "host's pattern uploads between the ranges of a step)"}}
+                                "host's pattern uploads between the ranges of a step)",
+                        **c5_counters()}}
     del L, X
     gc.collect()
     torch.cuda.empty_cache()
     return res
+
+
+def c5_counters():
+    """HBM traffic and vector-issue share of the widest lattice-sum kernel out of the committed counter pass of BASELINE config 5's
+    125 000-row share (tools/profile_r5.sh c5: what one of 8 ranks runs), per launch; null when the stamp does not match."""
+    import csv
+    name = "void ital::gen_main_kernel<16"
+    row = pmc_row("c5", name)
+    out = {"traffic": None, "valu_issue_frac": None}
+    if not row:
+        return out
+    ok, info = profile_is_current(PMC_FILES["c5"])
+    if not ok:
+        return dict(out, pmc_note="counters not quoted: " + str(info))
+    stats = os.path.join(ROOT, "profiles", "r5_c5_kernel_stats.csv")
+    avg_ns = None
+    if os.path.exists(stats):
+        with open(stats, newline="") as f:
+            for r_ in csv.DictReader(f):
+                if r_.get("Name", "").startswith(name):
+                    avg_ns = float(r_["AverageNs"])
+    out["traffic"] = float(row["fetch_bytes_corrected_avg"]) + float(row["write_bytes_avg"])
+    if avg_ns:
+        out["valu_issue_frac"] = float(row["SQ_INSTS_VALU_avg"]) * 4.0 / (1024 * 2.4e9 * avg_ns * 1e-9)
+        out["avg_launch_ms_in_profile"] = avg_ns * 1e-6
+    out["pmc_file"] = PMC_FILES["c5"]
+    out["traffic_note"] = ("gen_main_kernel<16> per launch in the profile of the 125 000-row share (a range of a step: 8 - 67 k "
+                           "candidates x 16 calls); the records of a launch are read once (1.8 KB per call)")
+    return out
 
 
 def cpu_baseline(X, cores):
