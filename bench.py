@@ -378,7 +378,7 @@ def other_workloads(X, rel, device):
         roofs["mcmi_score_kernel<%d>" % BATCH] = dict({"bound": "fp64-valu", "achieved": ach, "peak": FP64_VALU_PEAK_TFLOPS,
                                                        "unit": "TFLOP/s", "frac": ach / FP64_VALU_PEAK_TFLOPS,
                                                        "avg_launch_ms": sec * 1e3, "terms_per_s": terms / sec},
-                                                      **pmc_fields("mcmi", "void ital::mcmi_score_kernel<%d>" % BATCH, sec),
+                                                      **dict(pmc_fields("mcmi", "void ital::mcmi_score_kernel<%d>" % BATCH, sec), valu_issue_frac=None),
                                                       **{"pmc_note": "counters per launch of tools/mcmi_bench.py (launches of 1000 and "
                                                                      "9273 candidates averaged), quoted only while their stamp matches"})
     out["mcmi_min_subsample1000_k4"] = dict(r, roofline=roofs, config="MCMI_min, subsample 1000 (reference configs/usps.conf)")
