@@ -170,6 +170,14 @@ def load(path=LIB_PATH):
         raise ImportError(
             f"{path} not found: build it with `python -m ital_amd.build` (hipcc, gfx950). "
             "ital_amd has no CPU fallback.")
+    # The library links against libamdhip64 by soname.  A PyTorch host brings its OWN copy of the HIP runtime; whichever is
+    # loaded first serves both -- and two runtimes in one process means kernels registered with one and streams created by
+    # the other ("no ROCm-capable device is detected" at the first launch: seen in round 5 when build() had loaded this
+    # library before smoke() imported torch).  So torch goes first whenever it is installed.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     lib = ctypes.CDLL(path)
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)  # AttributeError if the library does not export what the header declares
