@@ -235,7 +235,11 @@ def test_one_million_candidates(dev):
                                     (dict(change_estimation_subset=5), 200, 4),
                                     (dict(change_estimation_subset=3, label_prob=0.7, mistake_prob=0.2), 150, 3),
                                     (dict(change_estimation_subset=4, mistake_prob=0.2, monte_carlo_num_fb=2), 120, 4),
-                                    (dict(change_estimation_subset=8, monte_carlo_num_rel=2), 160, 6)])
+                                    (dict(change_estimation_subset=8, monte_carlo_num_rel=2), 160, 6),
+                                    # a noise so large that the limits do not decide the calls after the simulated update: the
+                                    # cooperative preparation (gen_prep_pu_kernel) flags its candidates, gen_prep_kernel takes them
+                                    (dict(monte_carlo_num_rel=1, noise=0.5), 150, 9),
+                                    (dict(monte_carlo_num_rel=2, noise=0.05), 120, 8)])
 def test_general_scorer_pipeline_equals_its_single_kernel(dev, kw, n, k):
     """Plain mode of ital_score_generic: the pipeline of kernels on internal streams (gen_pipeline.hip: verdict / build /
     lattice sums / combine up to 6 variables, prepare / lattice sums / combine beyond; slabs and chunks of the workspace)
