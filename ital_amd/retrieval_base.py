@@ -22,19 +22,22 @@ class IdSet(set):
         set.__init__(self, *a)
         self.changes = 0
 
-    def _changing(name):        # noqa: N805 -- class-body helper
-        base = getattr(set, name)
 
-        def method(self, *a, **kw):
-            self.changes += 1
-            return base(self, *a, **kw)
-        method.__name__ = name
-        return method
+def _counting(name):
+    base = getattr(set, name)
 
-    for _n in ("add", "discard", "remove", "pop", "clear", "update", "difference_update", "intersection_update",
-               "symmetric_difference_update", "__ior__", "__iand__", "__isub__", "__ixor__"):
-        locals()[_n] = _changing(_n)
-    del _n, _changing
+    def method(self, *a, **kw):
+        self.changes += 1
+        return base(self, *a, **kw)
+    method.__name__ = name
+    method.__doc__ = base.__doc__
+    return method
+
+
+for _name in ("add", "discard", "remove", "pop", "clear", "update", "difference_update", "intersection_update",
+              "symmetric_difference_update", "__ior__", "__iand__", "__isub__", "__ixor__"):
+    setattr(IdSet, _name, _counting(_name))
+del _name
 
 
 class UnseenList(object):
