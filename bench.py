@@ -497,6 +497,50 @@ def k8_workload(device, n=25000, d=512, k=8):
     return res
 
 
+def topcand_workload(device, n=1_000_000, d=512, k=4, top=4096, rounds=3):
+    """`top_candidates` at scale (reference ital.py:111-117, the shipped *-topscoring.conf): every fetch restricts the candidate
+    list to the `top` samples of largest predictive mean -- np.argpartition over ALL unlabelled samples on the host, whose
+    ORDER is the list's order (tie-breaks, stream offsets) and therefore stays numpy's -- and scores only those.  Timed: the
+    whole fetch + update round and the host's share of it (means download + argpartition), the number the round-4 verdict
+    found missing at 1M rows."""
+    import torch
+    from ital_amd import ITAL, mvn_stream
+    X = block_rows(0, n, d, seed=1)
+    mvn_stream.GLOBAL.reset()
+    L = ITAL(X, length_scale=float(np.sqrt(d / 12.0)), top_candidates=top, device=device)
+    L.update({0: 1})
+    inner = L._candidate_list
+    host = [0.0]
+
+    def timed_list(*a, **kw):
+        t_ = time.perf_counter()
+        out_ = inner(*a, **kw)
+        host[0] += time.perf_counter() - t_
+        return out_
+    L._candidate_list = timed_list
+
+    def label(i):
+        return 1.0 if (i * 2654435761) % (1 << 32) < (1 << 31) else -1.0
+    ret = L.fetch_unlabelled(k)                       # warm-up
+    L.update({int(i): label(int(i)) for i in ret})
+    host[0] = 0.0
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(rounds):
+        ret = L.fetch_unlabelled(k)
+        L.update({int(i): label(int(i)) for i in ret})
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    res = {"ms_per_round": dt / rounds * 1e3, "host_candidate_list_ms_per_round": host[0] / rounds * 1e3,
+           "candidates_per_s": rounds * sum(top - t for t in range(k)) / dt,
+           "config": "synthetic %d x %d, k=%d, top_candidates=%d, perfect user: the list of a fetch = the %d samples of largest "
+                     "predictive mean in np.argpartition's order" % (n, d, k, top, top)}
+    del L, X
+    gc.collect()
+    torch.cuda.empty_cache()
+    return res
+
+
 def k16_workload(device, n=1_000_000, d=512, k=16, mc=1):
     """BASELINE.json configs[4] / SURVEY.md 8d C5' in one piece on ONE GPU: 1 000 000 x 512, batches of 16,
     monte_carlo_num_rel = 1 (2^16 sign patterns are infeasible anywhere: the reference's own switch, ital.py:293-297) -- one
@@ -797,7 +841,8 @@ def main():
     ap.add_argument("--label-prob", type=float, default=1.0, help="user model (experiments; != 1 selects the general scorer)")
     ap.add_argument("--mistake-prob", type=float, default=0.0)
     ap.add_argument("--extra", default="", help="comma list of opt-in workloads (N = 1): c4 = 50 000 x 2048, k = 8 (BASELINE "
-                    "configs[3], ~5 s); c5k16 = 1 000 000 x 512, k = 16, monte_carlo_num_rel = 1 (configs[4] whole, ~2.5 min)")
+                    "configs[3], ~5 s); c5k16 = 1 000 000 x 512, k = 16, monte_carlo_num_rel = 1 (configs[4] whole, ~2 min); "
+                    "topcand = 1 000 000 x 512 with top_candidates = 4096 (the host's argpartition share)")
     ap.add_argument("--force-collectives", action="store_true",
                     help="one rank, but through the exchange path of N > 1 (1-rank RCCL group): prices the per-step collective")
     ap.add_argument("--dry-run", action="store_true",
@@ -1035,6 +1080,8 @@ def main():
                                                 "full 2^t enumeration (BASELINE.json configs[3], SURVEY 8d C4'), one GPU")
             if "c5k16" in extra:
                 ow["ital_k16_mc1_1Mx512"] = k16_workload(device)
+            if "topcand" in extra:
+                ow["ital_topcand4096_1Mx512"] = topcand_workload(device)
         out["cpu_baseline"] = cpu_base
         if cpu_base:
             out["speedup_vs_cpu_baseline"] = out["value"] / cpu_base["value"]
