@@ -28,7 +28,7 @@ struct ital_ctx {
     // device memory (all owned here)
     double *X = nullptr, *xn = nullptr, *L = nullptr, *alpha = nullptr, *XT = nullptr, *XTn = nullptr, *V = nullptr, *mu = nullptr,
            *s2 = nullptr, *ybuf = nullptr, *C = nullptr, *mi = nullptr, *rec = nullptr, *rec_all = nullptr, *work3k = nullptr,
-           *qwork = nullptr;
+           *qwork = nullptr, *stage = nullptr;
     int64_t qwork_doubles = 0, cand_cap = 0;
     int* status = nullptr;
     int32_t* cand = nullptr;
@@ -170,19 +170,46 @@ extern "C" int ital_ctx_update(ital_ctx* c, const int64_t* idx, const double* y,
         else slot[j] = (int)(it - c->last_picks.begin());
         if (idx[j] < c->row0 || idx[j] >= c->row1) all_local = false;
     }
-    if (!all_batch && !all_local)
-        return ital_fail(-38, "ital_ctx_update: rows of other ranks outside the batch just fetched are not replicated here");
+    // Samples outside the batch just fetched (the first labels of a session: a query) on a communicator: their feature rows
+    // are replicated through the exchange the greedy steps use -- one all-gather of a record-sized buffer per sample, the
+    // owner contributes the row, everybody keeps the owner's part (the reference slices the rows out of the matrix every
+    // worker holds, gp.py:185-190).
+    const bool via_comm = !all_batch && c->comm != nullptr;
+    if (!all_batch && !all_local && !via_comm)
+        return ital_fail(-38, "ital_ctx_update: rows of other ranks need the communicator (ital_ctx_create: nccl_comm)");
+    const int rec_len = ital_record_len(c->ldx, c->cap, c->kmax);
     for (int j0 = 0; j0 < c_new; j0 += 16) {
         const int cc = std::min(16, c_new - j0);
         ital_label_batch lb;
         memset(&lb, 0, sizeof(lb));
         lb.c = cc;
         for (int j = 0; j < cc; j++) {
-            lb.slot[j] = all_batch ? slot[j0 + j] : (int)(idx[j0 + j] - c->row0);
+            lb.slot[j] = all_batch ? slot[j0 + j] : (via_comm ? j : (int)(idx[j0 + j] - c->row0));
             lb.y[j] = y[j0 + j];
         }
+        if (via_comm) {
+            if (!c->stage) {
+                c->stage = dalloc<double>(c, (size_t)16 * c->ldx);
+                if (!c->stage) return ital_fail(-12, "ital_ctx_update: out of device memory");
+            }
+            for (int j = 0; j < cc; j++) {
+                const int64_t gi = idx[j0 + j];
+                int owner = 0;
+                while (owner + 1 < c->world && c->n_total * (owner + 1) / c->world <= gi) owner++;      // rows [n r / w, n (r + 1) / w)
+                if (hipMemsetAsync(c->rec, 0, (size_t)rec_len * sizeof(double), stream) != hipSuccess) return ital_fail(-5, "ital_ctx_update: memset failed");
+                if (owner == c->rank &&
+                    hipMemcpyAsync(c->rec, c->X + (size_t)(gi - c->row0) * c->ldx, (size_t)c->ldx * sizeof(double), hipMemcpyDeviceToDevice,
+                                   stream) != hipSuccess)
+                    return ital_fail(-5, "ital_ctx_update: copy of the row failed");
+                const int rc_x = ital_select_exchange(c->rec, c->rec_all, rec_len, c->comm, stream);
+                if (rc_x) return rc_x;
+                if (hipMemcpyAsync(c->stage + (size_t)j * c->ldx, c->rec_all + (size_t)owner * rec_len, (size_t)c->ldx * sizeof(double),
+                                   hipMemcpyDeviceToDevice, stream) != hipSuccess)
+                    return ital_fail(-5, "ital_ctx_update: copy of the replicated row failed");
+            }
+        }
         const int m = c->m;
-        int rc = ital_stage_labelled(all_batch ? c->batch.XB : c->X, c->ldx, lb, c->XT + (size_t)m * c->ldx, c->XTn + m, c->ybuf, stream);
+        int rc = ital_stage_labelled(all_batch ? c->batch.XB : (via_comm ? c->stage : c->X), c->ldx, lb, c->XT + (size_t)m * c->ldx, c->XTn + m, c->ybuf, stream);
         if (!rc) rc = ital_chol_append(c->XT, c->XTn, c->ldx, c->L, c->cap, c->alpha, c->ybuf, m, cc, c->var, c->length_scale, c->noise,
                                        c->status, stream);
         if (!rc) rc = ital_whiten_append(c->X, c->xn, c->n, c->ldx, c->XT + (size_t)m * c->ldx, c->XTn + m, cc, c->L + (size_t)m * c->cap,

@@ -125,3 +125,56 @@ def test_monte_carlo_k16_over_rccl():
     one = mrs._run(1, cfg)
     two = mrs._run(2, cfg, "rccl")
     assert mrs._compare(one, two, n) >= 100
+
+
+def _ctx_worker(rank, world, port, golden, out):
+    """The context-style layer of the C ABI (ital_ctx_*, csrc/ctx.hip) on `world` devices: rows sharded, the query's row
+    replicated through the exchange, one ncclAllGather of a record per greedy step -- two golden rounds."""
+    import ctypes
+    dev, group = _ranks.join(rank, world, port, "rccl")
+    try:
+        from ital_amd import _lib, sharding
+        lib, chk = _lib.load(), _lib.check
+        comm = sharding.raw_comm(group, dev)
+        if comm is None:
+            out[rank] = ("no raw communicator", sharding.raw_comm_reason(group, dev))
+            return
+        z = np.load(golden)
+        X = np.ascontiguousarray(z["X"], dtype=np.float64)
+        n, d = X.shape
+        k = int(z["k"])
+        ctx = ctypes.c_void_p()
+        chk(lib.ital_ctx_create(n, d, float(z["length_scale"]), float(z["var"]), float(z["noise"]), 64, rank, world, comm,
+                                ctypes.byref(ctx)))
+        row0 = ctypes.c_int64(-1)
+        n_loc = lib.ital_ctx_local_rows(ctx, ctypes.byref(row0))
+        mine = np.ascontiguousarray(X[row0.value:row0.value + n_loc])
+        chk(lib.ital_ctx_fit(ctx, mine.ctypes.data, 0, None))
+        picks_all, means = [], []
+        picks = np.zeros(8, dtype=np.int64)
+        for r in range(int(z["rounds"])):
+            ind = np.ascontiguousarray(z["r%d_ind" % r], dtype=np.int64)
+            y = np.ascontiguousarray(z["r%d_y" % r], dtype=np.float64)
+            new = slice(0, len(ind)) if r == 0 else slice(len(z["r%d_ind" % (r - 1)]), len(ind))
+            chk(lib.ital_ctx_update(ctx, ind[new].ctypes.data, y[new].ctypes.data, len(ind[new]), None))
+            mean = np.empty(n_loc)
+            chk(lib.ital_ctx_predict_stored(ctx, mean.ctypes.data, None, None))
+            means.append((row0.value, mean))
+            assert lib.ital_ctx_fetch(ctx, k, picks.ctypes.data, None) == k, lib.ital_last_error()
+            picks_all.append(picks[:k].tolist())
+        chk(lib.ital_ctx_destroy(ctx))
+        out[rank] = ("ok", picks_all, means)
+    finally:
+        _ranks.leave(group)
+
+
+@pytest.mark.parametrize("world", WORLDS)
+def test_context_api_on_several_devices(world, golden_dir):
+    golden = os.path.join(golden_dir, "usps500.npz")
+    z = np.load(golden)
+    res = _ranks.spawn(_ctx_worker, world, golden)
+    for r in res:
+        assert r[0] == "ok", r
+        assert r[1] == [z["r%d_ret" % q].tolist() for q in range(int(z["rounds"]))]
+        for q, (row0, mean) in enumerate(r[2]):
+            np.testing.assert_allclose(mean, z["r%d_rel_mean" % q][row0:row0 + len(mean)], rtol=0, atol=2e-9)
