@@ -35,6 +35,16 @@ _MC_CHUNKS, _MC_CHUNK_MIN, _MC_CHUNK_FROM = 4, 8192, 10
 _POOL = None
 
 
+def _range_cuts(lo, hi, chunks, smallest=None):
+    """Boundaries of the ranges a step of sampled patterns is scored in: sizes 1 : 2 : 4 : ... over [lo, hi) (the first range is
+    decomposed while the GPU idles, every later one under the lattice sums of the range before), none shorter than `smallest`
+    (default _MC_CHUNK_MIN) unless the whole span is.  Ascending int64 array, first entry lo, last entry hi."""
+    smallest = _MC_CHUNK_MIN if smallest is None else smallest
+    span = hi - lo
+    cuts = lo + (span * ((1 << np.arange(chunks + 1)) - 1)) // ((1 << chunks) - 1)
+    return np.unique(np.concatenate(([lo], cuts[cuts - lo >= min(smallest, span)], [hi])).astype(np.int64))
+
+
 def _host_pool():
     global _POOL
     if _POOL is None:
@@ -1167,9 +1177,7 @@ class ITAL(ActiveRetrievalBase):
                     # ranges, 2.8 s of a 101 s round), every later range is decomposed under the lattice sums of the one before
                     # -- as long as a range is not much longer than the one before (the host decomposes ~1.4 M candidates per
                     # second on 16 threads, the GPU integrates 1.6 M (7 variables) .. 47 k (16) per second): sizes 1 : 2 : 4 : ...
-                    span = jl1 - jl0
-                    cuts = jl0 + (span * ((1 << np.arange(chunks + 1)) - 1)) // ((1 << chunks) - 1)
-                    cuts = np.unique(np.concatenate(([jl0], cuts[cuts - jl0 >= min(_MC_CHUNK_MIN, span)], [jl1])).astype(np.int64))
+                    cuts = _range_cuts(jl0, jl1, chunks)
                     for a, b_ in zip(cuts[:-1], cuts[1:]):
                         lo = local[0] if a == jl0 else int(live[a])
                         hi = local[1] if b_ == jl1 else int(live[b_])

@@ -455,3 +455,18 @@ def test_id_sets_count_their_in_place_changes():
     assert s.changes == 7 and len(s) == 0
     t = IdSet([5])
     assert copy.deepcopy(t) == {5} and pickle.loads(pickle.dumps(t)) == {5}
+
+
+def test_ranges_of_a_sampled_step_grow_geometrically():
+    """ital_amd.ital._range_cuts (round 5): a step of sampled patterns (reference ital.py:293-297) is scored in ranges of its
+    candidates so that the host's per-candidate decompositions of range r + 1 run under the GPU's lattice sums of range r;
+    the first range -- decomposed while the GPU idles -- is short, the sizes double."""
+    from ital_amd.ital import _range_cuts
+    c = _range_cuts(0, 1_000_000, 6)
+    assert c[0] == 0 and c[-1] == 1_000_000 and len(c) == 7
+    sizes = np.diff(c)
+    assert sizes[0] <= 1_000_000 // 60 and np.all(sizes[1:] >= 2 * sizes[:-1] - 2)          # 1 : 2 : 4 : ...
+    c = _range_cuts(5, 33_000, 4)                                # a short span: ranges below the minimum are merged
+    assert c[0] == 5 and c[-1] == 33_000 and np.all(np.diff(c) >= 8192)
+    assert _range_cuts(10, 2_010, 4).tolist() == [10, 2_010]    # shorter than the minimum: one range
+    assert _range_cuts(0, 125_000, 4).tolist() == [0, 8333, 25000, 58333, 125000]
