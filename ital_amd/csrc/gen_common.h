@@ -442,9 +442,18 @@ static __device__ ITAL_GEN_NOINLINE Prep build_group(int g, const double* mlim, 
     return out;
 }
 
+// The three options of the descriptor prepare_call reads, by value: a reference to the descriptor into a function that is not
+// inlined made the compiler copy the kernel's whole argument block (408 B) to scratch memory in the instantiations that use
+// all three (round 5).
+struct PrepOpts {
+    double noise, clip_cov;
+    int subset_mode;
+};
+__device__ __forceinline__ PrepOpts prep_opts(const ital_gscore_desc& d) { return PrepOpts{d.noise, d.clip_cov, d.subset_mode}; }
+
 // Prepares one call in the lane's slab: cov (packed, n(n+1)/2), lim (n), y (n); scratch fs for the update.
 template <bool CLIP>
-static __device__ ITAL_GEN_NOINLINE Prep prepare_call(const ital_gscore_desc& d, const CallInfo ci, int nU, int nr, int ldS, const double* muU,
+static __device__ ITAL_GEN_NOINLINE Prep prepare_call(const PrepOpts d, const CallInfo ci, int nU, int nr, int ldS, const double* muU,
                              const double* SigU, const int* usort, const int* ipos, bool clamp_prior, double* slab,
                              double* fs, double* master) {
     Prep out;
@@ -828,13 +837,13 @@ __device__ __forceinline__ void wave_sync() {
 
 // The 8 randomly shifted lattices of one call of dimension n, generated by the calling lane from the generator state
 // `base` advanced by `before` uniforms.
-static __device__ ITAL_GEN_NOINLINE void make_lattice(const ital_gscore_desc& d, const MrgState& base, unsigned before, int n, double* L) {
-    MrgState sti = base;
+// (State and tables by value: a reference would keep the caller's generator state in scratch memory.)
+static __device__ ITAL_GEN_NOINLINE void make_lattice(const long long* jump1, const double* vk, MrgState sti, unsigned before, int n, double* L) {
     for (int bit = 0; before != 0; bit++, before >>= 1)
-        if (before & 1u) mrg_apply(sti, d.jump1 + bit * 18);
+        if (before & 1u) mrg_apply(sti, jump1 + bit * 18);
     MrgStateF st = mrg_to_f(sti);
     const int ndim = n - 1;
-    for (int j = 0; j < ndim; j++) L[j] = d.vk[n * GN + j];
+    for (int j = 0; j < ndim; j++) L[j] = vk[n * GN + j];
     for (int sft = 0; sft < 8; sft++) {
         double* row = L + sft * ndim;
         if (sft > 0)

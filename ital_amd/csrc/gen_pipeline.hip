@@ -599,7 +599,7 @@ __global__ __launch_bounds__(128) void gen_prep_kernel(GArgs a, GPipe g) {
         if (mine) {
             const CallInfo ci = decode_call(d, p, call, g.cpp, g.npre, nr, g.npat);
             if (ci.kind != K_SKIP)
-                pp = prepare_call<false>(d, ci, nU, nr, ldS, muU, SigU, usort, ipos, clamp_prior, slab, slab + a.slab, nullptr);
+                pp = prepare_call<false>(prep_opts(d), ci, nU, nr, ldS, muU, SigU, usort, ipos, clamp_prior, slab, slab + a.slab, nullptr);
         }
         // every dimension >= 3 call (evaluated or saturated) takes 8*(2*NDIM-1) uniforms from MVNUNI: lane l jumps ahead by
         // what the calls before it in this chunk consume, the wave's base state by the chunk's total
@@ -773,7 +773,7 @@ __global__ __launch_bounds__(128) void gen_prep_pu_kernel(GArgs a, GPipe g) {
     double* slab = slabs + (size_t)(pri ? lane : 0) * a.stride;
     if (pri) {
         const CallInfo ci = decode_call(d, p, 2 * lane, 2, 1, n, npat);
-        pp = prepare_call<false>(d, ci, n, n, ldS, muU, SigU, usort, ipos, false, slab, slab, nullptr);
+        pp = prepare_call<false>(prep_opts(d), ci, n, n, ldS, muU, SigU, usort, ipos, false, slab, slab, nullptr);
     }
     const bool integrate = pri && !(pp.flags & (1 | 6 | 16));
     const bool regular = integrate && pp.closes == (1u << pp.n) - 1u;

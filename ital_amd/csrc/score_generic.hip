@@ -123,7 +123,7 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(ITAL_GEN_WA
             const CallInfo ci = decode_call(d, p, chunk0 + lane, cpp, npre, nr, npat);
             double* slab = slabs + (size_t)lane * a.stride;
             if (ci.kind == K_SKIP) { pp.flags = 16; }
-            else pp = prepare_call<CLIP>(d, ci, nU, nr, ldS, muU, SigU, usort, ipos, clamp_prior, slab, slab + a.slab,
+            else pp = prepare_call<CLIP>(prep_opts(d), ci, nU, nr, ldS, muU, SigU, usort, ipos, clamp_prior, slab, slab + a.slab,
                                              (CLIP && a.master) ? slab + a.master : nullptr);
         }
         // lattices of the calls that are evaluated, generated lane-parallel: every dimension >= 3 call (evaluated or
@@ -146,7 +146,7 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(ITAL_GEN_WA
             }
             const unsigned call_base = (unsigned)(incl - my_draws);
             if (draws_any && !(pp.flags & 6))
-                make_lattice(d, rng, call_base, pp.n, slabs + (size_t)lane * a.stride + a.lat);
+                make_lattice(d.jump1, d.vk, rng, call_base, pp.n, slabs + (size_t)lane * a.stride + a.lat);
             // clip_cov: calls that fall apart into independent groups (ital.py:413-429) are evaluated group by group --
             // pass g prepares group g of every such call in the call's slab, the wave evaluates the ones that need the
             // lattice rule, and the product of the group probabilities turns the call into a closed-form one
@@ -169,7 +169,7 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(ITAL_GEN_WA
                         const int* gorder = reinterpret_cast<const int*>(mcor + pp.n * (pp.n + 1) / 2) + pp.n;
                         gp = build_group(g, mlim, mcor, pp.infi, gorder, gorder + pp.n, slab);
                         if (gp.n >= 3) {
-                            if (!(gp.flags & 7)) make_lattice(d, rng, call_base + gdone, gp.n, slab + a.lat);
+                            if (!(gp.flags & 7)) make_lattice(d.jump1, d.vk, rng, call_base + gdone, gp.n, slab + a.lat);
                             gdone += 8 * (2 * (gp.n - 1) - 1);
                         }
                     }
