@@ -126,6 +126,7 @@ struct GArgs {
     int ldS;           // leading dimension of the joint covariance in LDS (largest |U|)
     int master;        // clip_cov: offset of the lane's copy of the standardised problem (0: clip_cov off)
     int wave_doubles;  // LDS doubles per wave
+    int yl;            // single kernel: LDS doubles per wave for the chains' conditioned values (qmc_eval_lds / qmc_exact_lds)
 };
 
 // ------------------------------------------------------------------------------------------------ COVSRT, runtime n

@@ -17,7 +17,7 @@
 //                                                          entry in the chunk's list (regular / linearly dependent variables)
 //     gen_main_kernel<T|0>   WAVE per record               the lattice sum (FP64-VALU bound: the perfect-user evaluator)
 //     gen_exact_kernel       wave per flagged record       label_estimation 'optimistic' / 'pessimistic' only: sums near 0 / 1
-//                                                          again in MVKBRV's serial order (qmc_exact.h)
+//                                                          again in MVKBRV's serial order (qmc_exact.h), every dimension
 //     gen_combine_kernel     wave per candidate            the terms in the reference's order -> mi
 //   With the general user at t = 4 only 240 of a candidate's 1296 calls need a lattice sum: verdicts for all calls with full
 //   waves and no LDS, the expensive preparation (COVSRT, lattices) for the undecided ones only -- again with full waves (the
@@ -41,7 +41,6 @@
 
 namespace ital {
 
-constexpr int GEN_EXACT_MAX = 8;      // largest dimension whose flagged calls are recomputed in MVKBRV's own order (LDS: 16 P values)
 constexpr int GEN_FLAG_EXACT = 128;   // record flag set by the lattice sum: recompute (qmc_exact.h)
 
 struct GPipe {
@@ -912,7 +911,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(ITAL_GEN_MA
 }
 
 // The flagged records of a chunk again, in the reference's summation order (qmc_exact.h): wave per record; all but a
-// handful leave at once.  Launched only with label_estimation 'optimistic' / 'pessimistic', up to GEN_EXACT_MAX variables.
+// handful leave at once.  Launched only with label_estimation 'optimistic' / 'pessimistic'; any dimension the pipeline takes
+// (round 6: the lattice points in blocks, qmc_exact_lds -- until then 16 P values in LDS limited this to 8 variables).
 __global__ __launch_bounds__(64) void gen_exact_kernel(GPipe g, const double* __restrict__ vk, unsigned int nrec) {
     extern __shared__ double lds_all[];
     const int lane = threadIdx.x;
@@ -930,13 +930,13 @@ __global__ __launch_bounds__(64) void gen_exact_kernel(GPipe g, const double* __
     const int n = (int)((m >> 8) & 0xff);
     const unsigned infi = (unsigned)((m >> 16) & 0xffffffu), closes = (unsigned)((m >> 40) & 0xffffffu);
     const int ncov = n * (n + 1) / 2, ndim = n - 1;
-    const int prime = P_TAB[(ndim < 10 ? ndim : 10) - 1];
     double* slab = lds_all;
     double* lat = slab + ncov + n;
     double* tailq = lat + 16 * ndim;
     double* vals = tailq + 128;
+    double* yl = vals + 128;                 // conditioned values of the two chains per lane: [2][ndim][64]
     // a regular call's record holds the variables bounded below negated (write_slab): undo
-    const unsigned fl = (ITAL_QMC_FLIP && closes == (1u << n) - 1u) ? infi : 0u;
+    const unsigned fl = (ITAL_QMC_FLIP && !g.mixed && closes == (1u << n) - 1u) ? infi : 0u;
     for (int q = lane; q < ncov; q += 64) {
         int row = 0;
         while ((row + 1) * (row + 2) / 2 <= q) row++;
@@ -954,9 +954,7 @@ __global__ __launch_bounds__(64) void gen_exact_kernel(GPipe g, const double* __
         }
     }
     wave_sync();
-    qmc_point_values<GEN_EXACT_MAX>(n, slab, infi, closes, lat, lane, tailq, vals);
-    wave_sync();
-    const double value = mvkbrv_serial(prime, vals, lane);
+    const double value = qmc_exact_lds(n, slab, infi, closes, lat, lane, tailq, yl, ndim, vals);
     if (lane == 0) g.meta[(size_t)id * 2 + 1] = value;
     wave_sync();
     }
@@ -1203,13 +1201,8 @@ int ital_gen_pipeline(const ital_gscore_desc* d, hipStream_t stream) {
     const size_t lds_m0 = (size_t)(pl.lat - 2 + 16 * (n - 1) + ITAL_GEN_TAILQ + 2 * (GN - 1) * 64) * sizeof(double);   // one wave
     // label_estimation 'optimistic' / 'pessimistic' (plain mode only): sums that decide an exact comparison are formed again in
     // the reference's order
-    const int exact = (d->label_mode != 0 && d->fb_mode != 3 && n <= GEN_EXACT_MAX && !pl.sub) ? 1 : 0;
-    const size_t lds_x = (size_t)(n * (n + 1) / 2 + n + 16 * (n - 1) + 128 + 16 * P_TAB[(n - 1 < 10 ? n - 1 : 10) - 1]) * sizeof(double);
-    if (exact && lds_x > 48 * 1024) {
-        static ItalLdsFlags exact_flags;
-        if (const int rc = ital_raise_lds_limit(reinterpret_cast<const void*>(&gen_exact_kernel), 64 * 1024, exact_flags, "ital_score_generic"))
-            return rc;
-    }
+    const int exact = (d->label_mode != 0 && d->fb_mode != 3 && !pl.sub) ? 1 : 0;
+    const size_t lds_x = (size_t)(n * (n + 1) / 2 + n + 16 * (n - 1) + 128 + 128 + 2 * (n - 1) * 64) * sizeof(double);      // <= 21 KB
 // (subset mode: the instantiations with MVNPHI's far-tail branch, up to ITAL_GEN_SUB_MAX variables -- pipe_plan sends larger
 // subsets to the single kernel; TS_ keeps the dimensions beyond from being instantiated at all)
 #define ITAL_GEN_MAIN(T_) case T_: {                                                                                           \
@@ -1342,6 +1335,7 @@ int ital_gen_pipeline(const ital_gscore_desc* d, hipStream_t stream) {
     ap.slab = slab;
     ap.lat = 0;
     ap.master = 0;
+    ap.yl = 0;
     ap.ldS = n;
     ap.wave_doubles = n + n * n + (GN + GR + 1) / 2 + chunk_p * stride_p;
     const size_t lds_p = (size_t)2 * ap.wave_doubles * sizeof(double);

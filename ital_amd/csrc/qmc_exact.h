@@ -123,4 +123,106 @@ __device__ __forceinline__ double mvkbrv_serial(int prime, const double* __restr
     return finval;
 }
 
+__device__ __forceinline__ void exact_wave_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// MVKBRV's estimate of a prepared call of ANY dimension n (runtime; <= ystride + 1) in the reference's own summation order,
+// with a constant amount of LDS -- what the general scorer's single kernel and its pipeline above 8 variables use (round 6:
+// 16 P values per call are 174 KB at P = 1361).  The lattice points are visited in blocks of 8 per shift: lane = 8 sft + q
+// evaluates point k0 + q + 1 of shift sft and its antithetic partner with MVNDFN's own arithmetic (the operations of
+// qmc_eval_lds / qmc_point_values in their order; the chains' conditioned values in `yl`: [2][ystride][64] doubles), the 128
+// values go to `vals`, then lanes 0 .. 7 advance DKSMRC's running mean of their shift by the block's 16 values -- the same
+// dependent steps as mvkbrv_serial, interleaved with the evaluation instead of behind it.  DKBVRC's mean over the shifts at
+// the end.  The same value in every lane.  tailq: 128 doubles, vals: 128 doubles of wave-private LDS.
+static __device__ __attribute__((noinline)) double qmc_exact_lds(int n, const double* __restrict__ slab, unsigned infi, unsigned closes,
+                                                                const double* __restrict__ lat, int lane, double* __restrict__ tailq,
+                                                                double* __restrict__ yl, int ystride, double* __restrict__ vals) {
+    const int ndim = n - 1;
+    const int prime = P_TAB[(ndim < 10 ? ndim : 10) - 1];
+    const double* cf = slab;
+    const double* lm = slab + n * (n + 1) / 2;
+    const int sft = lane >> 3, kq = lane & 7;
+    const int so = sft * ndim;
+    double* y0 = yl + lane;
+    double* y1 = yl + ystride * 64 + lane;
+    double sumkro = 0.0;
+    for (int k0 = 0; k0 < prime; k0 += 8) {
+        const bool ok = k0 + kq < prime;
+        const int kk = ok ? k0 + kq + 1 : 1;
+        double ff[2] = {1.0, 1.0}, ai[2] = {0.0, 0.0}, bi[2] = {0.0, 0.0};
+        bool dead[2] = {!ok, !ok};
+        bool infa = false, infb = false;   // wave-uniform: the open group has a lower / an upper limit (MVNDFN)
+        int ik = 0;                        // groups closed so far = lattice coordinate of the open group
+        for (int i = 0; i < n; i++) {
+            const bool lower = (infi >> i) & 1u;
+            const bool close = (closes >> i) & 1u;
+            const bool last = i == n - 1;
+            double sc0 = 0, sc1 = 0;
+            for (int j = 0; j < i; j++) {
+                const double c = cf[pidx(i, j)];
+                sc0 = fma(c, y0[j * 64], sc0);
+                sc1 = fma(c, y1[j * 64], sc1);
+            }
+            const double z0 = lm[i] - sc0, z1 = lm[i] - sc1;
+            if (lower) { ai[0] = infa ? fmax(ai[0], z0) : z0; ai[1] = infa ? fmax(ai[1], z1) : z1; infa = true; }
+            else { bi[0] = infb ? fmin(bi[0], z0) : z0; bi[1] = infb ? fmin(bi[1], z1) : z1; infb = true; }
+            if (close) {
+                double xh = 0;
+                if (!last) {
+                    const double v = kk * lat[so + ik] + lat[8 * ndim + so + ik];
+                    const double fr = v - floor(v);
+                    xh = fabs(2 * fr - 1);
+                }
+                double pin[2];
+#pragma unroll
+                for (int c = 0; c < 2; c++) {
+                    const double dd = infa ? mvn_phi(ai[c]) : 0.0;
+                    const double ee = infb ? mvn_phi(bi[c]) : 1.0;
+                    const double w = ee - dd;
+                    dead[c] = dead[c] || !(w > 0);
+                    ff[c] *= w;
+                    const double x = (c & 1) ? 1 - xh : xh;
+                    pin[c] = fma(x, w, dd);
+                }
+                if (!last) {
+                    double outv[2];
+                    phinv_wave<2>(pin, outv, tailq, lane);
+                    y0[i * 64] = outv[0];
+                    y1[i * 64] = outv[1];
+                }
+                infa = false; infb = false;
+                ik++;
+            } else if (!last) {
+                y0[i * 64] = 0.0;
+                y1[i * 64] = 0.0;
+            }
+        }
+        vals[sft * 16 + 2 * kq] = dead[0] ? 0.0 : ff[0];
+        vals[sft * 16 + 2 * kq + 1] = dead[1] ? 0.0 : ff[1];
+        exact_wave_sync();
+        if (lane < 8) {
+            const double* v = vals + lane * 16;
+            const int cnt = prime - k0 < 8 ? prime - k0 : 8;
+            for (int q = 0; q < cnt; q++) {
+                const int k = k0 + q + 1;
+                sumkro = sumkro + (v[2 * q] - sumkro) / (double)(2 * k - 1);
+                sumkro = sumkro + (v[2 * q + 1] - sumkro) / (double)(2 * k);
+            }
+        }
+        exact_wave_sync();
+    }
+    double finval = 0.0;
+    for (int i = 1; i <= 8; i++) {
+        const int lo = __builtin_amdgcn_readlane(__double2loint(sumkro), i - 1);
+        const int hi = __builtin_amdgcn_readlane(__double2hiint(sumkro), i - 1);
+        const double value = __hiloint2double(hi, lo);
+        const double difint = (value - finval) / (double)i;
+        finval = finval + difint;
+    }
+    return finval;
+}
+
 }  // namespace ital

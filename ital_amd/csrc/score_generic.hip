@@ -23,6 +23,7 @@
 // update, COVSRT) in its own LDS slab; the wave then evaluates the chunk's calls one after the other with the lattice
 // points spread over the lanes (4 chains per lane, runtime dimension <= NMAX with uniform early exits).
 #include "gen_common.h"
+#include "qmc_exact.h"
 
 namespace ital {
 
@@ -49,12 +50,23 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(ITAL_GEN_WA
     double* tailq = SigU + ldS * ldS + (GN + GR + 1) / 2;
     // more than 6 variables: the chains' conditioned values live in LDS (qmc_eval_lds: no 20-fold unrolled stage, no
     // register arrays that end up in scratch memory)
-    constexpr int YL = NMAX > 6 ? 2 * (GN - 1) * 64 : 0;
+    // (up to 6 variables that area exists only with label_estimation 'optimistic' / 'pessimistic': a.yl doubles, for the
+    // recomputation below)
     double* yl = tailq + ITAL_GEN_TAILQ;
-    double* slabs = yl + YL;
+    double* slabs = yl + a.yl;
+    // label_estimation 'optimistic' / 'pessimistic' (plain mode; the reference ignores them with a subset, ital.py:227-275)
+    // compare terms for EXACT equality (ital.py:210-215): an orthant probability whose flat sum lands within 1e-9 of 0 or 1 is
+    // formed again in MVKBRV's own serial order (qmc_exact.h) -- also the probability of a group of clip_cov, whose product
+    // with the other groups' is the call's value.  Round 6: until then this kernel took the flat sums.
+    const bool exact = d.subset_mode == 0 && d.label_mode != 0 && d.fb_mode != 3;
+    const int ystride = NMAX > 6 ? GN - 1 : NMAX - 1;
     auto lattice_sum = [&](int n_c, const double* slab_c, unsigned infi_c, unsigned closes_c) -> double {
-        if constexpr (NMAX > 6) return qmc_eval_lds(n_c, slab_c, infi_c, closes_c, slab_c + a.lat, lane, tailq, yl);
-        else return qmc_eval<NMAX, NH>(n_c, slab_c, infi_c, closes_c, slab_c + a.lat, lane, tailq);
+        double v;
+        if constexpr (NMAX > 6) v = qmc_eval_lds(n_c, slab_c, infi_c, closes_c, slab_c + a.lat, lane, tailq, yl);
+        else v = qmc_eval<NMAX, NH>(n_c, slab_c, infi_c, closes_c, slab_c + a.lat, lane, tailq);
+        if (exact && (v > 1.0 - EXACT_BAND || v < EXACT_BAND))       // (wave-uniform)
+            v = qmc_exact_lds(n_c, slab_c, infi_c, closes_c, slab_c + a.lat, lane, tailq, yl, ystride, tailq + 256);
+        return v;
     };
 
     const int row = d.cand[p];
@@ -311,7 +323,11 @@ extern "C" int ital_score_generic(const ital_gscore_desc* d, hipStream_t stream)
     a.slab = slab;
     a.lat = slab + fs_doubles(nr);
     a.master = clip ? slab + fs_doubles(nr) + 16 * (nUmax - 1) : 0;
-    const int fixed = nUmax + nUmax * nUmax + (GN + GR + 1) / 2 + ITAL_GEN_TAILQ + (nUmax > 6 ? 2 * (GN - 1) * 64 : 0);
+    // conditioned values of the chains in LDS: above 6 variables always (qmc_eval_lds); below only for the recomputation of
+    // label_estimation 'optimistic' / 'pessimistic' (qmc_exact_lds)
+    const bool exact = d->subset_mode == 0 && d->label_mode != 0 && d->fb_mode != 3;
+    a.yl = nUmax > 6 ? 2 * (GN - 1) * 64 : (exact ? 2 * 5 * 64 : 0);
+    const int fixed = nUmax + nUmax * nUmax + (GN + GR + 1) / 2 + ITAL_GEN_TAILQ + a.yl;
     a.ldS = nUmax;
     a.wave_doubles = fixed + chunk * stride;
     const size_t lds = (size_t)2 * a.wave_doubles * sizeof(double);

@@ -15,8 +15,10 @@ Acceptance rule per round (the parity contract):
     candidate's orthant problem: the reference's own value hangs on the last bits of its BLAS, and with label_estimation
     'optimistic' / 'pessimistic' it jumps between log(eps) and 0): picks and scores are compared up to that step only.
   * label_estimation 'optimistic' / 'pessimistic' test the running value for EXACT equality (`mi == 0`): where a sign pattern's
-    probability is 1 on the device and 1 - 2e-16 in the reference (last bits of MVKBRV's running means), a candidate's score
-    jumps between ~0 and -log(eps).  Scores with that signature on either side are counted, not compared.
+    probability is 1 on one side and 1 - 2e-16 on the other (last bits of MVKBRV's running means), a candidate's score
+    jumps between ~0 and -log(eps).  Such scores are COMPARED like every other one (nothing is set aside): every path of the
+    device forms the sums that decide it in MVKBRV's own order (qmc_exact.h; since round 6 also the general scorer's single
+    kernel and its pipeline above 8 variables -- kinds optnoisy / optclip / optwide / optbig).
   * `tests/test_gpu_parity_limits.py` pins the known instances of (b) and of the re-sampled Monte-Carlo patterns.
 """
 import os
@@ -43,6 +45,7 @@ def make_case(seed0, case):
         X[int(rng.integers(0, n))] = X[int(rng.integers(0, n))]
     ls = float(np.sqrt(d / 12.0) * rng.uniform(0.5, 1.5))
     kw = {}
+    attrs = {}                                  # attributes set on the DEVICE learner only (which kernels take the step)
     # FUZZ_KINDS=optimistic,perfect,... restricts a campaign to some kinds (another sequence of cases than the default's:
     # the pinned cases of tests/test_gpu_parity_limits.py are cases of the unrestricted list); FUZZ_MAX_D caps the feature
     # dimension (d = 2: strongly correlated candidates, limits far in the tails)
@@ -74,6 +77,35 @@ def make_case(seed0, case):
         X = X[:n] if n <= len(X) else rng.random((n, d))
     elif kind == "clip":
         kw = dict(clip_cov=float(rng.uniform(0.1, 0.6)), change_estimation_subset=int(rng.integers(3, 6)))
+    # ---- round 6 (FUZZ_KINDS only): label_estimation 'optimistic' / 'pessimistic' on every path of the GENERAL scorer -- the
+    # reference resets its running value on exact equality (ital.py:210-215), so the sums near 0 / 1 have to come out in
+    # MVKBRV's own order wherever such a call is integrated (qmc_exact.h): the pipeline's fast form (3 .. 6 variables), its
+    # wide form (7 .. 16), and the single kernel (clip_cov, generic_pipeline = False, a workspace too small for one candidate)
+    elif kind == "optnoisy":
+        kw = dict(label_estimation=str(rng.choice(["optimistic", "pessimistic"])))
+        if rng.random() < 0.5:
+            kw.update(label_prob=float(rng.uniform(0.3, 0.9)), mistake_prob=float(rng.uniform(0.0, 0.4)))
+        else:
+            kw.update(mistake_prob=float(rng.uniform(0.05, 0.4)))
+        k = int(rng.integers(2, 5))
+        attrs = [dict(), dict(generic_pipeline=False), dict(qmc_work_bytes=4096)][int(rng.integers(0, 3))]
+    elif kind == "optclip":                       # grouped orthant probabilities act from 6 variables on (ital.py:360)
+        kw = dict(label_estimation=str(rng.choice(["optimistic", "pessimistic"])), clip_cov=float(rng.uniform(0.1, 0.6)))
+        k = int(rng.integers(6, 8))
+        n = int(rng.integers(k + 5, k + 14))
+        X = X[:n] if n <= len(X) else rng.random((n, d))
+    elif kind == "optwide":                       # sampled patterns, batches of 8 .. 11: lattice sums of 7 .. 11 variables
+        kw = dict(label_estimation=str(rng.choice(["optimistic", "pessimistic"])), monte_carlo_num_rel=int(rng.integers(1, 3)))
+        k = int(rng.integers(8, 12))
+        n = int(rng.integers(k + 6, k + 18))
+        X = X[:n] if n <= len(X) else rng.random((n, d))
+        attrs = [dict(), dict(), dict(generic_pipeline=False)][int(rng.integers(0, 3))]
+    elif kind == "optbig":                        # full enumeration of 5 .. 6 variables through the general scorer
+        kw = dict(label_estimation=str(rng.choice(["optimistic", "pessimistic"])))
+        k = int(rng.integers(5, 7))
+        n = int(rng.integers(12, 24))
+        X = X[:n] if n <= len(X) else rng.random((n, d))
+        attrs = [dict(force_generic=True), dict(force_generic=True, generic_pipeline=False)][int(rng.integers(0, 2))]
     elif kind == "optimistic":
         kw = dict(label_estimation=str(rng.choice(["optimistic", "pessimistic"])))
     elif kind == "topcand":
@@ -85,7 +117,7 @@ def make_case(seed0, case):
         kw = dict(label_prob=float(rng.uniform(0.4, 0.9)), mistake_prob=float(rng.uniform(0.0, 0.3)),
                   change_estimation_subset=int(rng.integers(1, 4)), monte_carlo_num_fb=int(rng.integers(1, 3)))
     labels = {int(i): (1 if X[i, 0] > 0.5 else -1) for i in rng.choice(n, int(rng.integers(1, 5)), replace=False)}
-    return dict(rng=rng, n=n, d=d, k=k, X=X, ls=ls, kw=kw, kind=str(kind), labels=labels)
+    return dict(rng=rng, n=n, d=d, k=k, X=X, ls=ls, kw=kw, kind=str(kind), labels=labels, attrs=attrs)
 
 
 def tie_check(trace, got):
@@ -135,6 +167,7 @@ def main():
             continue
         c = make_case(seed0, case)
         rng, n, d, k, X, ls, kw, kind, labels = (c[q] for q in ("rng", "n", "d", "k", "X", "ls", "kw", "kind", "labels"))
+        attrs = c["attrs"]
         # rows that have an exact twin: their orthant problems are degenerate (correlation +-1 up to rounding) and the value
         # of the reference itself hangs on the last bit of the BLAS in use -- scores of such candidates are not compared
         _, inv, cnt = np.unique(X, axis=0, return_inverse=True, return_counts=True)
@@ -153,6 +186,8 @@ def main():
             B = OracleMCMI(X, length_scale=ls, subsample=A.subsample)
         else:
             A = ITAL(X, length_scale=ls, device="cuda:0", **kw)
+            for name, value in attrs.items():
+                setattr(A, name, value)
             B = OracleITAL(X, length_scale=ls, **kw)
         A.keep_scores = True
         A.update(labels)
@@ -308,7 +343,7 @@ def main():
         except Exception as e:  # noqa: BLE001
             status = "EXC %s: %s" % (type(e).__name__, str(e)[:80])
         bad += status != "ok"
-        print("case %3d %-10s n=%3d d=%2d k=%d %-60s %s%s" % (case, kind, n, d, k, str(kw)[:60], status, note), flush=True)
+        print("case %3d %-10s n=%3d d=%2d k=%d %-60s %s%s" % (case, kind, n, d, k, (str(kw) + (" " + str(attrs) if attrs else ""))[:60], status, note), flush=True)
     print("%d cases, %d failures, %d accepted as numerical ties, %d rounds with Monte-Carlo patterns the oracle's LAPACK re-sampled "
           "(equal for the device's patterns), %d rounds with a duplicate sample in the batch (compared up to it), %.0f s"
           % (cases, bad, ties, resampled, degenerate, time.time() - t_start))

@@ -5,6 +5,7 @@ translation units the profiled workload runs, so that a change to another scorer
 of the library binary that ran.  bench.py quotes counters out of committed files only while `csrc_sha` still matches.
 
     python tools/stamp.py profiles/r4_stamp.json profiles/r4_headline_pmc_summary.csv profiles/r4_round_gaps.json ...
+    python tools/stamp.py --check profiles/r5_stamp.json        (which stamped profiles no longer match the tree)
 
 On the GPU box (no .git there) the commit comes from ITAL_COMMIT; files are keyed as profiles/<basename> whatever directory
 they are written to first (tools/profile_r4.sh writes under gpurun_out/, the summaries are then copied to profiles/).
@@ -79,7 +80,24 @@ def commit():
         return None
 
 
+def check(path):
+    """`stamp.py --check profiles/r6_stamp.json`: which of the stamped profiles were taken with other kernel sources than
+    the tree's (exit code 1 if any)."""
+    with open(path) as f:
+        stamp = json.load(f)
+    stale = [name for name, e in sorted(stamp.items()) if e.get("csrc_sha") != csrc_sha(e.get("units"))]
+    for name in stale:
+        print("stale:", name, "(units %s)" % (stamp[name].get("units"),))
+    print("%d of %d stamped profiles match the tree's kernel sources" % (len(stamp) - len(stale), len(stamp)))
+    return 1 if stale else 0
+
+
 def main():
+    if len(sys.argv) >= 3 and sys.argv[1] == "--check":
+        sys.exit(check(sys.argv[2]))
+    if len(sys.argv) < 2 or any(a.startswith("-") for a in sys.argv[1:]):
+        # (round 5: `stamp.py --check` wrote a file named "--check" into the repo root)
+        sys.exit("usage: stamp.py OUT.json PROFILE...  |  stamp.py --check STAMP.json")
     out, files = sys.argv[1], sys.argv[2:]
     stamp = {}
     if os.path.exists(out):

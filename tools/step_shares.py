@@ -33,7 +33,7 @@ for st in steps:
         s, e = int(r["Start_Timestamp"]), int(r["End_Timestamp"])
         iv.append((s, e))
         short = re.sub(r"^void ital::", "", r["Kernel_Name"].split("(")[0])
-        m = re.match(r"gen_main_kernel<(\d+)>", short)
+        m = re.match(r"gen_main_kernel<(\d+)", short)
         if m and int(m.group(1)) > 0:
             T = max(T, int(m.group(1)))
         d = by.setdefault(short, [0.0, 0])
