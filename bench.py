@@ -542,11 +542,13 @@ def topcand_workload(device, n=1_000_000, d=512, k=4, top=4096, rounds=3):
 
 
 def k16_workload(device, n=1_000_000, d=512, k=16, mc=1):
-    """BASELINE.json configs[4] / SURVEY.md 8d C5' in one piece on ONE GPU: 1 000 000 x 512, batches of 16,
-    monte_carlo_num_rel = 1 (2^16 sign patterns are infeasible anywhere: the reference's own switch, ital.py:293-297) -- one
-    fetch + update round, with the roofline of its lattice sums (the general scorer's pipeline, 3 .. 16 variables)."""
+    """BASELINE.json configs[4] / SURVEY.md 8d C5' on ONE GPU: n x 512 (1 000 000: the configuration in one piece; 125 000: the
+    share one of 8 ranks holds), batches of 16, monte_carlo_num_rel = 1 (2^16 sign patterns are infeasible anywhere: the
+    reference's own switch, ital.py:293-297) -- one fetch + update round, with the roofline of its lattice sums (the general
+    scorer's pipeline, 3 .. 16 variables)."""
     import torch
     from ital_amd import ITAL, mvn_stream
+    torch.cuda.reset_peak_memory_stats(device)
     X = block_rows(0, n, d, seed=1)
     mvn_stream.GLOBAL.reset()
     np.random.seed(0)
@@ -571,8 +573,8 @@ def k16_workload(device, n=1_000_000, d=512, k=16, mc=1):
     ach = pairs * FLOP_PER_PAIR / sec / 1e12 if sec > 0 else 0.0
     made, skipped, walk_s = L.mc_walk
     res = {"ms_per_round": dt * 1e3, "fetch_s": t1 - t0, "candidates_per_s": scored / dt,
-           "config": "synthetic %d x %d, k=%d, perfect user, monte_carlo_num_rel=%d (BASELINE.json configs[4], SURVEY 8d C5'), "
-                     "one GPU" % (n, d, k, mc),
+           "config": "synthetic %d x %d, k=%d, perfect user, monte_carlo_num_rel=%d (BASELINE.json configs[4], SURVEY 8d C5'%s), "
+                     "one GPU" % (n, d, k, mc, "" if n >= 1_000_000 else ": the rows one of 8 ranks holds"),
            "step_ms": {"t%d" % t: v * 1e3 for t, v in sorted(steps.items())},
            "pattern_sampling": {"standard_normals_computed": made, "skipped": skipped, "host_s": walk_s,
                                 "note": "numpy's legacy generator walked in the reference's order (ital_np_legacy_normals), under "
@@ -589,6 +591,58 @@ def k16_workload(device, n=1_000_000, d=512, k=16, mc=1):
     gc.collect()
     torch.cuda.empty_cache()
     return res
+
+
+def cov_block_workload(device, n=20000, d=512, m=17, reps=5):
+    """The dense posterior-covariance block of the MCMI / EMOC paths at a size that fills the chip (reference ital/mcmi.py:101-124
+    via gp.py:128: K_all[S, S] - k^T K^-1 k): ONE ital_cov_block of n x n x d on the FP64 matrix cores
+    (v_mfma_f64_16x16x4_f64, LDS-staged 128 x 128 tiles: cov_block_lds_kernel), timed with HIP events on the launch stream;
+    2 n^2 (d + m) flops per launch against the FP64 MFMA peak.  (At the reference's MCMI subsample of 1000 the same call is
+    launch-latency bound: other_workloads.mcmi_min_subsample1000_k4.)"""
+    import torch
+    from ital_amd import _lib
+    from ital_amd.gp import _ptr, _stream
+    lib = _lib.lib()
+    ldx = (d + 15) // 16 * 16
+    with torch.cuda.device(device):
+        g = torch.Generator(device="cpu").manual_seed(n)
+        X = torch.zeros(n, ldx, dtype=torch.float64)
+        X[:, :d] = torch.rand(n, d, generator=g, dtype=torch.float64)
+        X = X.to(device)
+        xn = (X * X).sum(1)
+        V = (0.05 * torch.randn(m, n, generator=g, dtype=torch.float64)).to(device)
+        out = torch.empty((n, n), dtype=torch.float64, device=device)
+        ls, var = float((d / 12.0) ** 0.5), 1.0
+        st = _stream()
+
+        def call():
+            _lib.check(lib.ital_cov_block(_ptr(X), _ptr(xn), n, _ptr(X), _ptr(xn), n, ldx, _ptr(V), n, _ptr(V), n, m, var, ls,
+                                          _ptr(out), n, st))
+        call()
+        torch.cuda.synchronize()
+        # spot check against the dense formula (256 x 256 corner)
+        a = slice(0, 256)
+        want = var * torch.exp(-(xn[a, None] + xn[None, a] - 2 * X[a] @ X[a].T) / (2 * ls * ls)) - V[:, a].T @ V[:, a]
+        err = float((out[a, a] - want).abs().max().item())
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            call()
+        e1.record()
+        torch.cuda.synchronize()
+        sec = e0.elapsed_time(e1) * 1e-3 / reps
+        del out, X, V
+    gc.collect()
+    torch.cuda.empty_cache()
+    flops = 2.0 * n * n * (ldx + m)
+    ach = flops / sec / 1e12
+    return {"ms_per_launch": sec * 1e3, "max_abs_err_vs_dense_formula": err,
+            "config": "one ital_cov_block of %d x %d x %d (m = %d whitened rows), fp64" % (n, n, d, m),
+            "roofline": {"bound": "mfma", "kernel": "cov_block_lds_kernel (v_mfma_f64_16x16x4_f64)", "achieved": ach,
+                         "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach / FP64_MFMA_PEAK_TFLOPS,
+                         "avg_launch_ms": sec * 1e3, "algorithmic_flops_per_launch": flops, "traffic": None,
+                         "note": "2 n^2 (d + m) flops / launch time (HIP events around %d launches on the launch stream); the "
+                                 "block's output alone is %.1f GB written per launch" % (reps, n * n * 8 / 1e9)}}
 
 
 def c5_counters():
@@ -620,8 +674,26 @@ def c5_counters():
     return out
 
 
+def cpu_cores():
+    """Host cores the CPU baselines run on: what this process may really use (affinity mask, cgroup quota), not the host's
+    core count -- a 16-CPU share of a 256-core host runs 256 workers no faster than 16."""
+    from oracle.parallel import effective_cores
+    return effective_cores()
+
+
+def _calibration():
+    path = os.path.join(ROOT, CALIBRATION_FILE)
+    if not os.path.exists(path):
+        return None
+    with open(path) as f:
+        cal = json.load(f)
+    return {"oracle_over_reference_time": cal["oracle_over_reference"], "file": CALIBRATION_FILE,
+            "note": "oracle vs the real reference on identical inputs in the build container (%s): "
+                    "the port is a fair stand-in for the reference, which cannot run on the GPU box" % cal["workload"]}
+
+
 def cpu_baseline(X, cores):
-    """The oracle (CPU restatement of the reference, oracle/) in the reference's parallel mode on a bounded sample."""
+    """The oracle (CPU restatement of the reference, oracle/) in the reference's parallel mode on the headline workload."""
     from oracle.ital import OracleITAL
     from oracle.parallel import fetch_unlabelled_parallel
     n = int(min(len(X), max(512, 600 * cores)))
@@ -630,17 +702,64 @@ def cpu_baseline(X, cores):
     t0 = time.time()
     _, scored = fetch_unlabelled_parallel(learner, BATCH, processes=cores)
     dt = time.time() - t0
-    out = {"value": scored / dt, "unit": "candidates/s", "cores": cores, "kind": "port",
+    out = {"value": scored / dt, "unit": "candidates/s", "cores": cores, "host_cpu_count": os.cpu_count(), "kind": "port",
            "sample": "one fetch_unlabelled(%d) round on the first %d rows of the workload (%d scored candidates, "
-                     "%.1f s), fork pool per greedy step as reference ital/ital.py:124-126" % (BATCH, n, scored, dt)}
-    path = os.path.join(ROOT, CALIBRATION_FILE)
-    if os.path.exists(path):
-        with open(path) as f:
-            cal = json.load(f)
-        out["calibration"] = {"oracle_over_reference_time": cal["oracle_over_reference"], "file": CALIBRATION_FILE,
-                              "note": "oracle vs the real reference on identical inputs in the build container (%s): "
-                                      "the port is a fair stand-in for the reference, which cannot run on the GPU box"
-                                      % cal["workload"]}
+                     "%.1f s; a single sample, not repeated), fork pool of %d workers per greedy step as reference "
+                     "ital/ital.py:124-126" % (BATCH, n, scored, dt, cores)}
+    cal = _calibration()
+    if cal:
+        out["calibration"] = cal
+    return out
+
+
+def cpu_baseline_sampled(n_workload, d, k, cores, kw=None, length_scale=None, seed=3, budget_s=15.0, n_sub=2048):
+    """CPU baseline of a configuration whose full round would take the host hours (C3' - C5' "timed on a 2048-
+    candidate subsample ... flagged extrapolated"; the per-candidate cost of the reference's scorer does not depend on N,
+    ital/ital.py:183-224, and its dense N x N kernel matrix could not even be formed at these sizes, gp.py:128): the oracle in
+    the reference's parallel scheme on the first n_sub rows of a matrix of the workload's shape -- same d, k, user model,
+    m = 1 labelled sample -- with per greedy step as many candidates as the step's share of `budget_s` allows
+    (oracle.parallel.fetch_unlabelled_sampled: from t = 6 on that is fewer than n_sub), extrapolated to the workload's N:
+    round time = sum_t [pool start-up + (N - t + 1) x measured seconds per candidate of step t]."""
+    from oracle.ital import OracleITAL
+    from oracle.parallel import fetch_unlabelled_sampled
+    kw = kw or {}
+    n_sub = int(min(n_sub, n_workload))
+    X = make_data(n_sub, d, seed=seed)
+    learner = OracleITAL(X, length_scale=length_scale or float(np.sqrt(d / 12.0)), **kw)
+    learner.update({0: 1})
+    np.random.seed(0)
+    t0 = time.time()
+    steps = fetch_unlabelled_sampled(learner, k, processes=cores, budget_s=budget_s, n_max=n_sub - 1)
+    dt = time.time() - t0
+    round_s = sum(s_["fork_s"] + (n_workload - s_["t"] + 1) * s_["per_cand_s"] for s_ in steps)
+    scored = sum(n_workload - s_["t"] + 1 for s_ in steps)
+    return {"value": scored / round_s, "unit": "candidates/s", "cores": cores, "host_cpu_count": os.cpu_count(), "kind": "port",
+            "extrapolated": True, "extrapolated_round_s": round_s,
+            "sample": "oracle in the reference's fork-pool scheme on the first %d rows of a %d x %d matrix of the workload's kind "
+                      "(k=%d%s), %.1f s of CPU work: candidates scored per greedy step %s (fewer where a step's share of the %d s "
+                      "budget ends); per-candidate cost does not depend on N (reference ital/ital.py:183-224), extrapolated to N = %d"
+                      % (n_sub, n_workload, d, k, "".join(", %s=%s" % kv for kv in sorted(kw.items())), dt,
+                         [s_["scored"] for s_ in steps], int(budget_s), n_workload),
+            "seconds_per_candidate_by_step": [round(s_["per_cand_s"], 6) for s_ in steps]}
+
+
+def cpu_baselines_other(cores, whole_c5=True):
+    """The extrapolated CPU baselines of the other BASELINE.json configurations the default line times (before anything
+    touches the GPU: the baselines fork)."""
+    out = {}
+    out["ital_general_user_k4"] = cpu_baseline_sampled(ROWS_PER_GPU, DIM, BATCH, cores, dict(label_prob=0.5, mistake_prob=0.25),
+                                                       length_scale=LENGTH_SCALE, seed=0, budget_s=12.0)
+    out["ital_k8_25000x512"] = cpu_baseline_sampled(25000, 512, 8, cores, budget_s=15.0)
+    out["ital_k8_50000x2048"] = cpu_baseline_sampled(50000, 2048, 8, cores, budget_s=15.0)
+    c5 = cpu_baseline_sampled(125000, 512, 16, cores, dict(monte_carlo_num_rel=1), seed=1, budget_s=20.0)
+    out["ital_k16_mc1_125000x512"] = c5
+    if whole_c5:
+        # the same measured seconds per candidate, N = 1M (nothing new is timed)
+        steps = c5["seconds_per_candidate_by_step"]
+        n = 1_000_000
+        round_s = sum((n - t) * v for t, v in enumerate(steps))
+        out["ital_k16_mc1_1Mx512"] = dict(c5, value=sum(n - t for t in range(len(steps))) / round_s, extrapolated_round_s=round_s,
+                                          sample=c5["sample"].replace("extrapolated to N = 125000", "extrapolated to N = 1000000 (same sample)"))
     return out
 
 
@@ -713,7 +832,12 @@ def scaling_workload(device, rank, world, group, rounds=3):
             ref = json.load(f).get(key)
     if world == 1 and rank == 0 and os.environ.get("ITAL_BENCH_WRITE_PICKS"):
         with open(os.environ["ITAL_BENCH_WRITE_PICKS"], "w") as f:
-            json.dump({key: {"picks_sha": sha, "picks": [[int(i) for i in r_] for r_ in picks]}}, f)
+            json.dump({key: {"picks_sha": sha, "picks": [[int(i) for i in r_] for r_ in picks],
+                             "ms_per_round_n1": dt / rounds * 1e3,
+                             "ms_per_round_n1_note": "fetch + update round of this workload on ONE MI355X, the run that wrote this file"}}, f)
+    # the strong-scaling point north_star asks for, readable from ONE line: this run's round time against the committed N = 1
+    # time of the same workload (same rounds, same picks)
+    n1_ms = ref.get("ms_per_round_n1") if ref else None
     host_ms = gather_floats(hc["gap_s"] / max(hc["gaps"], 1) * 1e3 if hc["gaps"] else float("nan"), device, world)
     enq_ms = gather_floats(hc["enqueue_s"] / max(hc["gaps"] + 1, 1) * 1e3, device, world)
     # ... and what that host time is made of (per rank, per round; rounds - 1 gaps, rounds updates)
@@ -747,6 +871,10 @@ def scaling_workload(device, rank, world, group, rounds=3):
     return {"workload": "synthetic %d x %d, k=%d, perfect user, full 2^t enumeration, fetch_unlabelled + update per round"
                         % (n, d, k), "scaling": "strong", "rows_per_rank": row1 - row0, "world_size": world,
             "backend": backend, "rounds": rounds, "ms_per_round": dt / rounds * 1e3, "candidates_per_s": scored / dt,
+            "n1_ms_per_round": n1_ms, "speedup_vs_n1": (n1_ms / (dt / rounds * 1e3)) if n1_ms else None,
+            "efficiency": (n1_ms / (dt / rounds * 1e3) / world) if n1_ms else None,
+            "speedup_note": "ms_per_round of the committed one-GPU run of this workload (%s) / this run's; efficiency = speed-up / "
+                            "world_size; north_star's target: >= 6x at 8 GPUs" % PICKS_N1_FILE,
             "fit_ms": {"construct_ms": (t_fit1 - t_fit0) * 1e3, "first_update_ms": (t_fit2 - t_fit1) * 1e3,
                        "note": "construct = upload of this rank's rows (host -> device over PCIe: 4 GB at 1M x 512 on one rank) + "
                                "row norms + buffers; the reference's fit forms the dense N x N kernel matrix here (gp.py:128), "
@@ -771,6 +899,17 @@ def scaling_workload(device, rank, world, group, rounds=3):
             "library_launches_per_round": launches, "peak_device_memory_gib": mem,
             "note": "per-step exchange = ncclAllGather of one record per rank on the process group's communicator (null on one "
                     "rank: no collective)"}
+
+
+def headline_workload_name(world):
+    """config.workload of the line: at N > 1 the headline is the WEAK-scaled metric workload (9298 rows on every GPU: a step is
+    launch-latency bound there and the line prices the collective); north_star's strong-scaling curve is scaling_workload."""
+    base = ("USPS-shaped synthetic %dx%d, k=%d, perfect user, full 2^t enumeration, fetch_unlabelled + update per step"
+            % (ROWS_PER_GPU, DIM, BATCH))
+    if world == 1:
+        return base
+    return ("weak: %d rows PER GPU (%d in all) -- " % (ROWS_PER_GPU, ROWS_PER_GPU * world)) + base + \
+        "; the STRONG-scaling point (1M x 512, k=4) is scaling_workload / config.strong_scaling_1M"
 
 
 def launch_ranks(n, argv):
@@ -824,9 +963,13 @@ def dry_run(rank, world, args):
         dist.barrier()
         dist.destroy_process_group()
     if rank == 0:
+        # (the keys a reader of an N > 1 line looks for are present in the dry run too: tests/test_bench_launch.py)
         print(json.dumps({"metric": "MI-scored candidates/sec per fetch_unlabelled(k) round", "value": None, "dry_run": True,
                           "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ranks_seen": ranks,
-                          "picks_agree_across_ranks": agree}), flush=True)
+                          "picks_agree_across_ranks": agree, "scaling": "weak",
+                          "config": {"workload": headline_workload_name(world)},
+                          "scaling_workload": {"scaling": "strong", "world_size": world, "ms_per_round": None, "n1_ms_per_round": None,
+                                               "speedup_vs_n1": None, "efficiency": None}}), flush=True)
 
 
 def main():
@@ -840,9 +983,16 @@ def main():
     ap.add_argument("--batch", type=int, default=4, help="batch size k (experiments)")
     ap.add_argument("--label-prob", type=float, default=1.0, help="user model (experiments; != 1 selects the general scorer)")
     ap.add_argument("--mistake-prob", type=float, default=0.0)
-    ap.add_argument("--extra", default="", help="comma list of opt-in workloads (N = 1): c4 = 50 000 x 2048, k = 8 (BASELINE "
-                    "configs[3], ~5 s); c5k16 = 1 000 000 x 512, k = 16, monte_carlo_num_rel = 1 (configs[4] whole, ~2 min); "
-                    "topcand = 1 000 000 x 512 with top_candidates = 4096 (the host's argpartition share)")
+    ap.add_argument("--extra", default="", help="comma list of opt-in workloads (N = 1): topcand = 1 000 000 x 512 with "
+                    "top_candidates = 4096 (the host's argpartition share).  (c4 / c5k16 -- BASELINE configs[3] and [4] -- are part "
+                    "of the default run since round 6.)")
+    ap.add_argument("--quick", action="store_true",
+                    help="headline + scaling workload only: skips the other BASELINE configurations (configs[2], [3], [4] share "
+                         "and whole, the noisy user, MCMI, the 20 000^2 covariance block) and their CPU baselines, which the "
+                         "default run times in ~4 minutes (ITAL_BENCH_NO_EXTRAS=1 does the same)")
+    ap.add_argument("--no-c5-whole", action="store_true",
+                    help="skip BASELINE configs[4] in one piece (1 000 000 x 512, k = 16: ~90 s of GPU); its 125 000-row share "
+                         "(what one of 8 ranks runs) stays")
     ap.add_argument("--force-collectives", action="store_true",
                     help="one rank, but through the exchange path of N > 1 (1-rank RCCL group): prices the per-step collective")
     ap.add_argument("--dry-run", action="store_true",
@@ -861,9 +1011,14 @@ def main():
     if args.dry_run:
         return dry_run(rank, world, args)
     cpu_base = None
+    cpu_other = {}
+    extras_on = world == 1 and not args.quick and not os.environ.get("ITAL_BENCH_NO_EXTRAS")
     if world == 1 and not args.no_cpu_baseline:
-        # before anything touches the GPU: the baseline forks worker pools
-        cpu_base = cpu_baseline(make_data(ROWS_PER_GPU, DIM, seed=0), os.cpu_count() or 1)
+        # before anything touches the GPU: the baselines fork worker pools
+        cores = cpu_cores()
+        cpu_base = cpu_baseline(make_data(ROWS_PER_GPU, DIM, seed=0), cores)
+        if extras_on:
+            cpu_other = cpu_baselines_other(cores, whole_c5=not args.no_c5_whole)
     import torch
     if os.environ.get("ITAL_BENCH_ONE_DEVICE"):
         local_rank = 0      # debugging aid for a 1-GPU box: all ranks on cuda:0 (use with ITAL_BENCH_BACKEND=gloo)
@@ -1010,6 +1165,46 @@ def main():
                 prof.setdefault((name, t), []).append((e0.elapsed_time(e1) * 1e-3, n_c))
         learner.round_call = True
     learner.profile = None
+    # SURVEY.md 8d "Seeds 0, 1, 2": the same K timed steps on the matrices of seeds 1 and 2 (seed 0 is `value`); same protocol
+    # -- frozen heap, pre-heat, W warm-up rounds, barrier + synchronize on both sides, maximum over ranks
+    seed_ms = {0: dt / args.steps * 1e3}
+    for sd in (1, 2):
+        Xs = make_data(n_total, DIM, seed=sd)
+        rels = np.where(Xs[:, 0] > 0.5, 1.0, -1.0)
+        Ls = ITAL(Xs, length_scale=LENGTH_SCALE, label_prob=args.label_prob, mistake_prob=args.mistake_prob, device=device,
+                  rank=rank, world=world, group=group)
+
+        def round_s():
+            ret_ = Ls.fetch_unlabelled(BATCH)
+            Ls.update({int(i): float(rels[i]) for i in ret_})
+
+        def restart_s():
+            Ls.reset()
+            mvn_stream.GLOBAL.reset()
+            Ls.update({sd % n_total: 1})          # first label q = seed mod n
+        ital_amd.serving_mode()
+        restart_s()
+        for _ in range(preheat):
+            round_s()
+        restart_s()
+        for _ in range(args.warmup):
+            round_s()
+        restart_s()
+        barrier()
+        ts = time.perf_counter()
+        for _ in range(args.steps):
+            round_s()
+        barrier()
+        dts = time.perf_counter() - ts
+        if world > 1:
+            import torch.distributed as dist
+            tt = torch.tensor([dts], dtype=torch.float64, device=device)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            dts = float(tt.item())
+        seed_ms[sd] = dts / args.steps * 1e3
+        gc.unfreeze()
+        del Ls, Xs
+    gc.collect()
     scale = None
     if not args.no_scaling_workload:
         del learner
@@ -1049,15 +1244,22 @@ def main():
                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": None,
                         "avg_launch_ms": avg_s * 1e3,
                         "note": "19 MB per launch at this size: launch-latency bound, see DESIGN.md for the large-N figure"}
+        sv = sorted(seed_ms.values())
+        seeds_obj = {"ms_per_step_by_seed": {str(k_): round(v_, 4) for k_, v_ in sorted(seed_ms.items())}, "min": sv[0],
+                     "median": sv[len(sv) // 2], "max": sv[-1],
+                     "note": "`value` / `ms_per_step` are seed 0; seeds 1, 2: the same protocol on make_data(seed), first label seed mod n"}
+        strong = None
+        if scale is not None:
+            strong = {k_: scale[k_] for k_ in ("ms_per_round", "candidates_per_s", "n1_ms_per_round", "speedup_vs_n1", "efficiency",
+                                               "world_size", "picks_match_n1")}
         out = {"metric": "MI-scored candidates/sec per fetch_unlabelled(k) round", "value": scored / dt,
                "unit": "candidates/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
                "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-               "config": {"workload": "USPS-shaped synthetic %dx%d per GPU, k=%d, perfect user, full 2^t enumeration, "
-                                      "fetch_unlabelled + update per step" % (ROWS_PER_GPU, DIM, BATCH),
+               "config": {"workload": headline_workload_name(world),
                           "n": n_total, "d": DIM, "k": BATCH, "length_scale": LENGTH_SCALE,
-                          "parallelism": "candidate rows sharded over %d GPU(s), 1 record all-gather per greedy step" % world},
-               "roofline": roof, "roofline_hbm": hbm_stream_probe(device) if world == 1 else roof_hbm,
+                          "parallelism": "candidate rows sharded over %d GPU(s), 1 record all-gather per greedy step" % world,
+                          "seeds": seeds_obj, "strong_scaling_1M": strong},
                "roofline_hbm_at_workload_size": roof_hbm,
                "kernel_ms": {"%s_t%d" % k: float(np.mean([d for d, _ in v])) * 1e3 for k, v in sorted(prof.items())},
                "fit_ms": fit_ms, "fetch_ms_per_round": parts["fetch_ms_per_round"], "update_ms_per_round": parts["update_ms_per_round"],
@@ -1070,21 +1272,82 @@ def main():
             # the strong-scaling figure north_star asks for (1M x 512, k = 4, rows split over the ranks), also at top level
             out["value_strong_1M"] = scale["candidates_per_s"]
             out["ms_per_round_strong_1M"] = scale["ms_per_round"]
-        if world == 1 and not os.environ.get("ITAL_BENCH_NO_EXTRAS"):
-            out["other_workloads"] = other_workloads(X, rel, device)
-        extra = [e for e in args.extra.split(",") if e]
-        if world == 1 and extra:
-            ow = out.setdefault("other_workloads", {})
-            if "c4" in extra:
-                ow["ital_k8_50000x2048"] = dict(k8_workload(device, 50000, 2048, 8), config="synthetic 50000 x 2048, k=8, perfect user, "
-                                                "full 2^t enumeration (BASELINE.json configs[3], SURVEY 8d C4'), one GPU")
-            if "c5k16" in extra:
+        ow = {}
+        if extras_on:
+            ow = other_workloads(X, rel, device)
+            ow["ital_k8_50000x2048"] = dict(k8_workload(device, 50000, 2048, 8), config="synthetic 50000 x 2048, k=8, perfect user, "
+                                            "full 2^t enumeration (BASELINE.json configs[3], SURVEY 8d C4'), one GPU")
+            ow["ital_k16_mc1_125000x512"] = k16_workload(device, n=125_000)
+            if not args.no_c5_whole:
                 ow["ital_k16_mc1_1Mx512"] = k16_workload(device)
-            if "topcand" in extra:
-                ow["ital_topcand4096_1Mx512"] = topcand_workload(device)
+            ow["cov_block_20000x512"] = cov_block_workload(device)
+        extra = [e for e in args.extra.split(",") if e]
+        if world == 1 and "topcand" in extra:
+            ow["ital_topcand4096_1Mx512"] = topcand_workload(device)
+        for name, cb in cpu_other.items():      # each configuration's own CPU baseline (extrapolated from a bounded sample)
+            if name in ow:
+                ow[name]["cpu_baseline"] = cb
+                ow[name]["speedup_vs_cpu_baseline"] = ow[name]["candidates_per_s"] / cb["value"]
+        if ow:
+            out["other_workloads"] = ow
+        # ---- what a reader of the line's tail / of its `roofline` and `cpu_baseline` objects needs: every configuration's
+        # dominant kernel against its bound, and every configuration's CPU baseline, compact
+        hbm = hbm_stream_probe(device) if world == 1 else roof_hbm
+        out["roofline_hbm"] = hbm
+
+        def brief(r_):
+            return None if not r_ else {k_: r_.get(k_) for k_ in ("bound", "achieved", "peak", "unit", "frac", "avg_launch_ms") if k_ in r_}
+        others = {}
+        if hbm:
+            others["kcols_kernel_1Mx256 (streaming GP kernel)"] = dict(brief(hbm), traffic=hbm.get("traffic"))
+        for name, w_ in ow.items():
+            r_ = w_.get("roofline")
+            if not r_:
+                continue
+            if "bound" in r_:
+                others[name] = brief(r_)
+            else:                                 # a dict of kernels (k = 8 workloads: t = 7, 8; MCMI: block + scorer)
+                for kn, rr in r_.items():
+                    others["%s/%s" % (name, kn)] = brief(rr)
+        if roof is not None:
+            roof["others"] = others
+            roof["others_note"] = ("dominant kernel of every other workload of this run (other_workloads.<name>.roofline has the "
+                                   "details): fp64-valu = algorithmic (Phi, Phi^-1) pairs x flops of the isolated chain / time")
+        out["roofline"] = roof
+        if cpu_base:
+            cpu_base = dict(cpu_base)
+            cpu_base["others"] = {name: {"value": cb["value"], "unit": cb["unit"], "cores": cb["cores"], "kind": cb["kind"],
+                                         "extrapolated": True, "gpu_value": ow.get(name, {}).get("candidates_per_s"),
+                                         "speedup": (ow[name]["candidates_per_s"] / cb["value"]) if name in ow else None,
+                                         "sample": cb["sample"][:160]}
+                                  for name, cb in cpu_other.items()}
         out["cpu_baseline"] = cpu_base
         if cpu_base:
             out["speedup_vs_cpu_baseline"] = out["value"] / cpu_base["value"]
+        # last key = the tail of the line: one row per BASELINE configuration
+        summ = {"C2' 9298x256 k4 (value)": [round(dt / args.steps * 1e3, 3), round(scored / dt), roof and round(roof["frac"], 3),
+                                             cpu_base and round(cpu_base["value"])]}
+        for label_, name in (("C3' 25000x512 k8", "ital_k8_25000x512"), ("C4' 50000x2048 k8", "ital_k8_50000x2048"),
+                             ("C5' share 125000x512 k16 mc1", "ital_k16_mc1_125000x512"), ("C5' 1Mx512 k16 mc1", "ital_k16_mc1_1Mx512"),
+                             ("noisy user 9298x256 k4", "ital_general_user_k4")):
+            w_ = ow.get(name)
+            if not w_:
+                continue
+            r_ = w_.get("roofline") or {}
+            fr = r_.get("frac") if "bound" in r_ else max([rr.get("frac", 0.0) for rr in r_.values()] or [None])
+            cb = w_.get("cpu_baseline")
+            summ[label_] = [round(w_["ms_per_round"], 2), round(w_["candidates_per_s"]), fr and round(fr, 3), cb and round(cb["value"], 1)]
+        if "cov_block_20000x512" in ow:
+            summ["cov_block 20000^2x512 (mfma)"] = [round(ow["cov_block_20000x512"]["ms_per_launch"], 2), None,
+                                                    round(ow["cov_block_20000x512"]["roofline"]["frac"], 3), None]
+        if hbm:
+            summ["kcols 1Mx256 (hbm)"] = [round(hbm["avg_launch_ms"], 3), None, round(hbm["frac"], 3), None]
+        if strong:
+            summ["strong 1Mx512 k4"] = [round(strong["ms_per_round"], 2), round(strong["candidates_per_s"]), strong["speedup_vs_n1"] and
+                                        round(strong["speedup_vs_n1"], 2), None]
+        out["summary"] = {"columns": ["ms_per_round", "gpu_candidates_per_s", "roofline_frac (strong: speedup_vs_n1)",
+                                      "cpu_baseline_candidates_per_s (extrapolated beyond C2')"], "rows": summ,
+                          "ms_per_step_seeds_0_1_2": [round(seed_ms[q], 3) for q in sorted(seed_ms)], "cpu_cores": cpu_base and cpu_base["cores"]}
     # the JSON line is the LAST thing on stdout: RCCL prints a version banner through C stdio, which a redirected stdout holds
     # back until the process ends -- every rank pushes its own out before the final barrier, rank 0 prints after it
     try:
