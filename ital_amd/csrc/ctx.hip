@@ -52,9 +52,20 @@ template <class T>
 T* dalloc(ital_ctx* c, size_t count) {
     void* p = nullptr;
     if (hipMalloc(&p, std::max<size_t>(count, 1) * sizeof(T) + 64) != hipSuccess) return nullptr;
-    if (hipMemset(p, 0, std::max<size_t>(count, 1) * sizeof(T) + 64) != hipSuccess) return nullptr;
+    if (hipMemset(p, 0, std::max<size_t>(count, 1) * sizeof(T) + 64) != hipSuccess) {
+        (void)hipFree(p);
+        return nullptr;
+    }
     c->owned.push_back(p);
     return static_cast<T*>(p);
+}
+
+// Gives a buffer of the context back (its replacement has been allocated): nothing may still be using it.
+void dfree(ital_ctx* c, void* p) {
+    if (!p) return;
+    const auto it = std::find(c->owned.begin(), c->owned.end(), p);
+    if (it != c->owned.end()) c->owned.erase(it);
+    (void)hipFree(p);
 }
 
 int pad16(int64_t v) { return (int)((v + 15) / 16 * 16); }
@@ -114,10 +125,15 @@ extern "C" int ital_ctx_create(int64_t n_total, int d, double length_scale, doub
     c->batch.XB = dalloc<double>(c, (size_t)kmax * ldx);
     c->batch.XBn = dalloc<double>(c, kmax);
     c->batch.VB = dalloc<double>(c, (size_t)kmax * cap);
-    if (!c->X || !c->V || !c->C || !c->batch.VB || !c->rec_all || !c->work3k) {
-        ital_ctx_destroy(c);
-        return ital_fail(-12, "ital_ctx_create: out of device memory");
-    }
+    // every allocation (an unchecked failure would surface as a device fault in the first kernel that touches the buffer)
+    const void* all[] = {c->X, c->xn, c->L, c->alpha, c->XT, c->XTn, c->V, c->mu, c->s2, c->ybuf, c->status, c->C, c->ret, c->rec,
+                         c->rec_all, c->work3k, c->batch.bidx, c->batch.bgpos, c->batch.bsort, c->batch.bmu, c->batch.sig,
+                         c->batch.XB, c->batch.XBn, c->batch.VB};
+    for (const void* p : all)
+        if (!p) {
+            ital_ctx_destroy(c);
+            return ital_fail(-12, "ital_ctx_create: out of device memory");
+        }
     c->seen.assign((size_t)n_total, 0);
     ital_mvn_seed(c->mvn_state);
     *out = c;
@@ -244,11 +260,31 @@ extern "C" int ital_ctx_fetch(ital_ctx* c, int k, int64_t* picks, hipStream_t st
         if (!c->seen[(size_t)i]) cand_h.push_back((int32_t)(i - c->row0));
     const int64_t nc = (int64_t)cand_h.size();
     if (nc > c->cand_cap) {
+        // (sized for all of this rank's rows at once: grows at most once per context; nothing enqueued reads the old ones --
+        // every fetch ends with a stream synchronisation)
+        dfree(c, c->cand); dfree(c, c->alive); dfree(c, c->mi);
         c->cand_cap = std::max<int64_t>(nc, c->n);
         c->cand = dalloc<int32_t>(c, c->cand_cap);
         c->alive = dalloc<uint8_t>(c, c->cand_cap);
         c->mi = dalloc<double>(c, c->cand_cap);
-        if (!c->cand || !c->alive || !c->mi) return ital_fail(-12, "ital_ctx_fetch: out of device memory");
+        if (!c->cand || !c->alive || !c->mi) {
+            c->cand_cap = 0;
+            return ital_fail(-12, "ital_ctx_fetch: out of device memory");
+        }
+    }
+    // the lattice scorer's workspace, ONCE for the whole round: what its largest step (t = k) needs, capped at 1 GiB (slabs
+    // beyond) -- ital_round_workspace is documented for exactly this.  (Until round 6 it was sized per step: each of the steps
+    // t = 3 .. k allocated a larger buffer and left the previous one in `owned` until ital_ctx_destroy, up to ~5 GiB stranded
+    // after the first k = 8 fetch at large n.)
+    if (k >= 3) {
+        const int64_t want = ital_round_workspace(k, std::max<int64_t>(nc, 1), (int64_t)1 << 27);
+        if (want > c->qwork_doubles) {
+            if (hipStreamSynchronize(stream) != hipSuccess) return ital_fail(-5, "ital_ctx_fetch: stream error");
+            dfree(c, c->qwork);
+            c->qwork = dalloc<double>(c, (size_t)want);
+            c->qwork_doubles = c->qwork ? want : 0;
+            if (!c->qwork) return ital_fail(-12, "ital_ctx_fetch: out of device memory (workspace)");
+        }
     }
     if (nc > 0 && (hipMemcpyAsync(c->cand, cand_h.data(), nc * sizeof(int32_t), hipMemcpyHostToDevice, stream) != hipSuccess ||
                    hipMemsetAsync(c->alive, 1, nc, stream) != hipSuccess))
@@ -277,12 +313,6 @@ extern "C" int ital_ctx_fetch(ital_ctx* c, int k, int64_t* picks, hipStream_t st
                     hipMemcpy(c->jumppat[t], pat.data(), pat.size() * sizeof(long long), hipMemcpyHostToDevice) != hipSuccess ||
                     hipMemcpy(c->vk[t], vk.data(), vk.size() * sizeof(double), hipMemcpyHostToDevice) != hipSuccess)
                     return ital_fail(-5, "ital_ctx_fetch: upload of the stream tables failed");
-            }
-            const int64_t want = ital_round_workspace(t, std::max<int64_t>(nc, 1), (int64_t)1 << 27);      // <= 1 GiB: slabs beyond
-            if (want > c->qwork_doubles) {
-                c->qwork = dalloc<double>(c, (size_t)want);
-                c->qwork_doubles = want;
-                if (!c->qwork) return ital_fail(-12, "ital_ctx_fetch: out of device memory (workspace)");
             }
             desc.jump = c->jump[t]; desc.jumppat = c->jumppat[t]; desc.vk = c->vk[t];
             desc.work = c->qwork; desc.work_doubles = c->qwork_doubles;

@@ -405,7 +405,7 @@ class ITAL(ActiveRetrievalBase):
                 # the reference's serial loop has now consumed this many uniforms of mvndst's stream
                 stream.advance(n_alive * (2 << t) * mvn_stream.draws_per_call(t))
                 n_alive -= 1
-            host = self._download(b["ret"], "the picks of the round").tolist()     # the only synchronisation of the round: the picks and the status word
+            host = self._download(b["ret"], "the picks of the round", self._step_estimate_s(k, n_loc)).tolist()     # the only synchronisation of the round: the picks and the status word
             ret, status = host[:k], host[b["kmax"]]   # status: OR over the greedy steps and over all ranks (same everywhere)
             if status & 6:
                 # linearly dependent variables inside a batch (duplicate samples), or a simulated update that does not pin the
@@ -436,9 +436,20 @@ class ITAL(ActiveRetrievalBase):
         sizes = np.diff([candidates.count_below(x) for x in bounds])
         return bool(sizes.min() >= 1 and sizes.max() <= _FUSED_SELECT_MAX)
 
-    def _download(self, tensor, what):
+    @staticmethod
+    def _step_estimate_s(k, n_loc):
+        """Upper estimate of the compute time of ONE greedy step of the full enumeration on this rank (the last step of a batch
+        of k dominates): its (Phi, Phi^-1) pairs at 1e11 pairs/s, less than half the measured rate of the lattice sums -- what
+        the exchange deadline must not mistake for a stalled collective (sharding.await_download)."""
+        if k < 3:
+            return 0.0
+        prime = (31, 47, 73, 113, 173, 263, 397, 593, 907, 1361)[min(k - 1, 10) - 1]
+        return float(n_loc) * (2 ** k) * 16 * prime * (k - 1) / 1e11
+
+    def _download(self, tensor, what, step_estimate_s=0.0):
         """Device -> host copy of a round's result.  On several ranks it is the point where this rank waits for the round's
-        collectives: bounded (ITAL_EXCHANGE_TIMEOUT_S) and with the raw communicator's asynchronous errors polled
+        collectives: bounded (no resolved greedy step for ITAL_EXCHANGE_TIMEOUT_S, or for three times the estimated compute
+        time of one step if that is longer) and with the raw communicator's asynchronous errors polled
         (sharding.await_download) -- a rank that dies mid-round must not leave the others waiting for ever."""
         gp = self.gp
         if not gp.collective:
@@ -452,7 +463,8 @@ class ITAL(ActiveRetrievalBase):
         name = {"nccl": "raw_nccl", "host": "host"}[kind[0]] if kind else ("raw_nccl (per step)" if comm else "torch_dist")
         if getattr(self, "_pinned", None) is None:
             self._pinned = {}
-        return sharding.await_download(tensor, what, gp.group, gp.device, comm, gp.rank, gp.world, name, pinned=self._pinned)
+        return sharding.await_download(tensor, what, gp.group, gp.device, comm, gp.rank, gp.world, name, pinned=self._pinned,
+                                       step_estimate_s=step_estimate_s)
 
     def _round_transport(self):
         """How ital_fetch_round exchanges the ranks' records: ("nccl", ncclComm_t of the process group -- the communicator
@@ -666,7 +678,7 @@ class ITAL(ActiveRetrievalBase):
                                                       n_loc, n_loc if gp.collective else n - k, lo)
             if hc is not None:
                 hc["enqueue_s"] += time.perf_counter() - t_call     # the call itself + the next round's descriptor (GPU busy)
-            host = self._download(b["ret"], "the picks of the round").tolist()     # the only synchronisation of the round: the picks and the status word
+            host = self._download(b["ret"], "the picks of the round", self._step_estimate_s(k, n_loc)).tolist()     # the only synchronisation of the round: the picks and the status word
             if hc is not None:
                 hc["t_download"] = time.perf_counter()
             ret, status = host[:k], host[b["kmax"]]
@@ -903,40 +915,43 @@ class ITAL(ActiveRetrievalBase):
                     base = {f: getattr(desc, f) for f in ("cand", "alive", "mi", "draw_off", "pos_offset")}
                     dbg = os.environ.get("ITAL_MC_TIMING")
                     tq = time.perf_counter()
-                    for lo, hi, rows, last_range in rel_ranges:
-                        if dbg:
-                            t_rows = time.perf_counter() - tq
-                            tq = time.perf_counter()
-                        a, e = lo - pos_offset, hi - pos_offset
-                        flat = pin.view(-1)[a * npat:e * npat]
-                        flat.copy_(torch.from_numpy(rows.view(np.int32).reshape(-1)))
-                        dflat = t_rel.view(-1)[a * npat:e * npat]
-                        with torch.cuda.stream(side):
-                            dflat.copy_(flat, non_blocking=True)
-                        up = torch.cuda.Event()
-                        up.record(side)
-                        main.wait_event(up)
-                        desc.n_cand = e - a
-                        desc.cand, desc.alive = base["cand"] + 4 * a, base["alive"] + a
-                        desc.mi, desc.draw_off = base["mi"] + 8 * a, base["draw_off"] + 8 * a
-                        desc.pos_offset = base["pos_offset"] + a
-                        desc.mc_rel, desc.rel_samples = npat, dflat.data_ptr()
-                        # all but the last range leave the library's streams unjoined: the preparation of the next range's
-                        # first slab then runs under this range's lattice sums (ital_gscore_desc.defer_join)
-                        desc.defer_join = 0 if last_range else 1
-                        try:
+                    # (try / finally around the WHOLE loop, not only the C call: the generator runs host LAPACK and thread-pool
+                    # work between the ranges -- if that raises while a deferred range is still running on the library's internal
+                    # streams, the join below is what orders those kernels, which write `mi` and the workspace, before anything
+                    # the caller's stream does next with these torch buffers)
+                    try:
+                        for lo, hi, rows, last_range in rel_ranges:
+                            if dbg:
+                                t_rows = time.perf_counter() - tq
+                                tq = time.perf_counter()
+                            a, e = lo - pos_offset, hi - pos_offset
+                            flat = pin.view(-1)[a * npat:e * npat]
+                            flat.copy_(torch.from_numpy(rows.view(np.int32).reshape(-1)))
+                            dflat = t_rel.view(-1)[a * npat:e * npat]
+                            with torch.cuda.stream(side):
+                                dflat.copy_(flat, non_blocking=True)
+                            up = torch.cuda.Event()
+                            up.record(side)
+                            main.wait_event(up)
+                            desc.n_cand = e - a
+                            desc.cand, desc.alive = base["cand"] + 4 * a, base["alive"] + a
+                            desc.mi, desc.draw_off = base["mi"] + 8 * a, base["draw_off"] + 8 * a
+                            desc.pos_offset = base["pos_offset"] + a
+                            desc.mc_rel, desc.rel_samples = npat, dflat.data_ptr()
+                            # all but the last range leave the library's streams unjoined: the preparation of the next range's
+                            # first slab then runs under this range's lattice sums (ital_gscore_desc.defer_join)
+                            desc.defer_join = 0 if last_range else 1
                             check(lib.ital_score_generic(ctypes.byref(desc), st))
-                        except Exception:
-                            lib.ital_score_generic_join(st)
-                            raise
-                        if dbg:
-                            print("t=%d range %d..%d: patterns %.1f ms, upload + launch %.1f ms" % (
-                                t, lo, hi, t_rows * 1e3, (time.perf_counter() - tq) * 1e3), flush=True)
-                            tq = time.perf_counter()
-                        if kept is not None:
-                            kept[lo:hi] = rows
-                    desc.defer_join = 0
-                    check(lib.ital_score_generic_join(st))      # (nothing pending after a last range; cheap)
+                            if dbg:
+                                print("t=%d range %d..%d: patterns %.1f ms, upload + launch %.1f ms" % (
+                                    t, lo, hi, t_rows * 1e3, (time.perf_counter() - tq) * 1e3), flush=True)
+                                tq = time.perf_counter()
+                            if kept is not None:
+                                kept[lo:hi] = rows
+                    finally:
+                        desc.defer_join = 0
+                        rc_join = lib.ital_score_generic_join(st)      # (nothing pending after a last range; cheap)
+                    check(rc_join)
                     if kept is not None:
                         self.last_patterns.append(kept)
                 self._mark("score_generic", t, n_alive, ev0)

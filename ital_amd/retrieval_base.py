@@ -18,9 +18,12 @@ class IdSet(set):
     """A set that counts its in-place changes (`changes`): what the learners keep their relevant / irrelevant / unnameable
     ids in (public attributes of the reference, retrieval_base.py:50-52).  Behaves as a set everywhere else."""
 
+    _serial = 0      # process-wide: a freshly wrapped set never starts at a token value an earlier wrapper held
+
     def __init__(self, *a):
         set.__init__(self, *a)
-        self.changes = 0
+        IdSet._serial += 1 << 20
+        self.changes = IdSet._serial
 
 
 def _counting(name):
@@ -229,6 +232,9 @@ class ActiveRetrievalBase(object):
     def _set_ids(self, name, value):
         # kept as a set that counts its in-place changes (`IdSet`): the candidate bookkeeping notices ANY change made behind
         # update()'s back, also one that leaves the sizes as they were (an id swapped for another)
+        # NOTE (differs from the reference, which stores the caller's object, retrieval_base.py:50-52): a plain set is COPIED
+        # into an IdSet -- later changes of the caller's own set object are not seen by the learner; change `learner.<name>`
+        # itself (in place, or by assigning again).  INTEGRATION.md, "id sets".
         self.__dict__[name] = value if isinstance(value, IdSet) else IdSet(value)
         self.__dict__["_unseen"] = None
 

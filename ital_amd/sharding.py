@@ -208,11 +208,18 @@ def comm_error(comm):
     return None          # 0: healthy; -38: this RCCL has no such entry point (nothing to poll)
 
 
-def await_download(tensor, what, group=None, device=None, comm=None, rank=0, world=1, transport=None, timeout_s=None, pinned=None):
-    """`tensor.cpu()` with a deadline: the device-to-host copy of a round's picks is enqueued behind the round's kernels and
-    collectives; the host waits for it with an event it QUERIES (never an unbounded synchronize), polls the communicator's
-    asynchronous error state meanwhile and raises ExchangeError when the deadline passes or RCCL reports a failure.  One
-    rank without a collective: a plain synchronous copy (nothing can stall it but the device itself).
+def await_download(tensor, what, group=None, device=None, comm=None, rank=0, world=1, transport=None, timeout_s=None, pinned=None,
+                   step_estimate_s=0.0):
+    """`tensor.cpu()` with a deadline on LACK OF PROGRESS: the device-to-host copy of a round's picks is enqueued behind the
+    round's kernels and collectives; the host waits for it with an event it QUERIES (never an unbounded synchronize), polls
+    the communicator's asynchronous error state meanwhile and raises ExchangeError when RCCL reports a failure or when
+    NOTHING HAS MOVED for the deadline.  "Moved": every 0.25 s the buffer itself (the picks of the greedy steps resolved so
+    far + the status word) is read through a side stream -- a copy engine, not ordered behind the round's kernels -- and the
+    clock restarts whenever its content has changed, i.e. whenever another greedy step has been resolved.  (Round 5 bounded the
+    TOTAL wait, which covers the GPU compute of all k steps: a healthy round of k = 8 over ~2 M rows per rank takes longer than
+    120 s and was told that "another rank died".)  The deadline is ITAL_EXCHANGE_TIMEOUT_S (120 s), or 3 x `step_estimate_s`
+    -- the caller's upper estimate of ONE greedy step's compute time on this rank -- if that is longer.  One rank without a
+    collective: a plain synchronous copy (nothing can stall it but the device itself).
     Counterpart of the parent noticing a dead worker of the reference's Pool (ital/ital.py:124-126)."""
     import time
     import torch
@@ -221,7 +228,8 @@ def await_download(tensor, what, group=None, device=None, comm=None, rank=0, wor
     limit = exchange_timeout_s() if timeout_s is None else timeout_s
     if limit <= 0:
         return tensor.cpu()
-    # (`pinned`: a dict the caller keeps -- the page-locked landing buffer is allocated once per shape, not per round)
+    limit = max(limit, 3.0 * float(step_estimate_s or 0.0))
+    # (`pinned`: a dict the caller keeps -- the page-locked landing buffers and the side stream are made once, not per round)
     key = (tuple(tensor.shape), tensor.dtype)
     host = pinned.get(key) if pinned is not None else None
     if host is None:
@@ -232,24 +240,59 @@ def await_download(tensor, what, group=None, device=None, comm=None, rank=0, wor
     done = torch.cuda.Event()
     done.record(torch.cuda.current_stream(tensor.device))
     t0 = time.perf_counter()
+    t_moved = t0                    # when the buffer's content was last seen to change
+    last_seen = None
     next_poll = 0.05
     spins = 0
     while not done.query():
         spins += 1
-        waited = time.perf_counter() - t0
+        now = time.perf_counter()
+        waited = now - t0
         if waited >= next_poll:
             next_poll = waited + 0.25
             err = comm_error(comm)
             if err:
                 raise ExchangeError("ital_amd: rank %d of %d: RCCL reports an error on the communicator while waiting for %s "
                                     "(transport %s): %s" % (rank, world, what, transport, err))
-        if waited > limit:
-            raise ExchangeError("ital_amd: rank %d of %d: %s did not arrive within %.1f s (transport %s): a collective of the "
-                                "round is still pending -- another rank died or never entered it (ITAL_EXCHANGE_TIMEOUT_S "
-                                "sets the deadline).  This process should exit now." % (rank, world, what, limit, transport))
+            if waited >= min(1.0, 0.25 * limit):       # (short rounds never pay for the snapshots)
+                seen = _peek(tensor, pinned if pinned is not None else {})
+                if seen is not None and seen != last_seen:
+                    if last_seen is not None:
+                        t_moved = now
+                    last_seen = seen
+        if now - t_moved > limit:
+            raise ExchangeError("ital_amd: rank %d of %d: %s did not arrive and no greedy step has been resolved for %.1f s "
+                                "(transport %s, %.1f s since the round was enqueued): a collective of the round is still "
+                                "pending -- another rank died or never entered it -- or one greedy step's own kernels take "
+                                "longer than the deadline on this rank (ITAL_EXCHANGE_TIMEOUT_S sets it; <= 0 waits for ever).  "
+                                "This process should exit now." % (rank, world, what, limit, transport, waited))
         if spins > 2000:
             time.sleep(0.0002)      # a long round: stop burning the core (the first ~ms are polled back to back)
     return host.clone() if pinned is not None else host      # (the landing buffer is reused by the next round)
+
+
+def _peek(tensor, cache):
+    """The CURRENT content of a small device buffer (bytes), read through a side stream while the buffer's own stream is busy:
+    the progress probe of await_download.  None when the copy does not come back within a second (nothing is concluded)."""
+    import time
+    import torch
+    side = cache.get("peek_stream")
+    if side is None:
+        side = cache["peek_stream"] = torch.cuda.Stream(device=tensor.device)
+    key = ("peek", tuple(tensor.shape), tensor.dtype)
+    land = cache.get(key)
+    if land is None:
+        land = cache[key] = torch.empty(tensor.shape, dtype=tensor.dtype, pin_memory=True)
+    with torch.cuda.stream(side):
+        land.copy_(tensor, non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record(side)
+    t0 = time.perf_counter()
+    while not ev.query():
+        if time.perf_counter() - t0 > 1.0:
+            return None
+        time.sleep(0.0005)
+    return land.numpy().tobytes()
 
 
 def gather_records(record, out, group=None):

@@ -76,9 +76,14 @@ def test_stalled_rank_inside_a_round_raises_on_the_others():
 def _one_rank_rccl_worker(rank, world, port, X, mode, out):
     if mode == "tiny_deadline":
         os.environ["ITAL_EXCHANGE_TIMEOUT_S"] = "0.0005"
+    if mode == "long_healthy_round":
+        os.environ["ITAL_EXCHANGE_TIMEOUT_S"] = "1.5"
     dev, group = _ranks.join(rank, world, port, "rccl1")
     try:
         from ital_amd import ITAL, mvn_stream, sharding
+        if mode != "plain":
+            # (the deadline is otherwise never shorter than three times the estimated compute time of one greedy step)
+            ITAL._step_estimate_s = staticmethod(lambda k, n_loc: 0.0)
         mvn_stream.GLOBAL.reset()
         L = ITAL(X, length_scale=float(np.sqrt(X.shape[1] / 12.0)), device=dev, rank=0, world=1, group=group)
         L.update({0: 1, len(X) - 1: -1})
@@ -86,8 +91,9 @@ def _one_rank_rccl_worker(rank, world, port, X, mode, out):
         comm = kind[1] if kind and kind[0] == "nccl" else None
         healthy = sharding.comm_error(comm) if comm else "no raw communicator"
         try:
-            picks = L.fetch_unlabelled(4)
-            res = ("ok", picks)
+            t0 = time.time()
+            picks = L.fetch_unlabelled(5 if mode == "long_healthy_round" else 4)
+            res = ("ok", picks, time.time() - t0)
         except sharding.ExchangeError as e:
             res = ("ExchangeError", str(e))
         torch.cuda.synchronize()
@@ -112,3 +118,14 @@ def test_deadline_applies_to_the_raw_transport():
     res = _ranks.spawn(_one_rank_rccl_worker, 1, X, "tiny_deadline")[0]
     assert res[0] == "nccl", res
     assert res[2][0] == "ExchangeError" and "raw_nccl" in res[2][1] and "did not arrive" in res[2][1], res
+
+
+def test_a_long_healthy_round_is_not_mistaken_for_a_stalled_collective():
+    """Round-5 advice: the deadline used to bound the TOTAL wait for a round's picks -- GPU compute of all k greedy steps
+    included -- so a healthy long round raised "another rank died".  It now bounds the time without a newly resolved greedy
+    step: a round of k = 5 over 1.6 M rows (~1.8 s on one MI355X, its longest step ~1.4 s) passes under a 1.5 s deadline."""
+    X = np.random.default_rng(94).random((1_600_000, 16))
+    res = _ranks.spawn(_one_rank_rccl_worker, 1, X, "long_healthy_round")[0]
+    assert res[0] == "nccl", res
+    assert res[2][0] == "ok" and len(res[2][1]) == 5, res
+    assert res[2][2] > 1.5, res          # (the round did outlast the deadline: the test tests something)

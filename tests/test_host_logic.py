@@ -447,14 +447,19 @@ def test_id_sets_count_their_in_place_changes():
     import pickle
     from ital_amd.retrieval_base import IdSet
     s = IdSet([1, 2])
-    assert s == {1, 2} and s.changes == 0 and isinstance(s, set)
+    c0 = s.changes                                                  # (a process-unique start value per wrapper, see below)
+    assert s == {1, 2} and isinstance(s, set)
     s.add(3); s |= {4}; s.discard(1); s.remove(2); s.update([7, 8])
-    assert s == {3, 4, 7, 8} and s.changes == 5
-    assert type(s | {9}) is set and s.changes == 5                  # non-mutating operators do not count
+    assert s == {3, 4, 7, 8} and s.changes == c0 + 5
+    assert type(s | {9}) is set and s.changes == c0 + 5             # non-mutating operators do not count
     s.pop(); s.clear()
-    assert s.changes == 7 and len(s) == 0
+    assert s.changes == c0 + 7 and len(s) == 0
     t = IdSet([5])
     assert copy.deepcopy(t) == {5} and pickle.loads(pickle.dumps(t)) == {5}
+    # round-5 advice: re-wrapping (learner.relevant_ids = learner.relevant_ids.copy(): a plain set again) must never land on a
+    # token an earlier wrapper held -- every wrapper starts its counter at a value of its own, far from the others'
+    u, v = IdSet([5]), IdSet([6])
+    assert u.changes != v.changes and abs(u.changes - v.changes) >= 1 << 20 and t.changes not in (u.changes, v.changes)
 
 
 def test_ranges_of_a_sampled_step_grow_geometrically():
