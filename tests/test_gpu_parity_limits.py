@@ -40,6 +40,8 @@ def _pair(seed0, case):
     mvn_stream.GLOBAL.reset()
     omvn.rng_reset()
     A = ITAL(c["X"], length_scale=c["ls"], device="cuda:0", **c["kw"])
+    for name, value in c.get("attrs", {}).items():       # which kernels take the step (device learner only)
+        setattr(A, name, value)
     B = OracleITAL(c["X"], length_scale=c["ls"], **c["kw"])
     A.keep_scores = True
     A.update(c["labels"])
@@ -150,7 +152,7 @@ def test_exact_zeros_of_the_interval_width_are_the_references():
 
 
 def test_exact_equality_reset_of_label_estimation_follows_the_reference(monkeypatch):
-    """Until round 3 a limit ("limit 3"), closed in round 4 (label_estimation 'optimistic' / 'pessimistic' only; no shipped
+    """Until round 3 a limit ("limit 3"), closed in round 4 for the perfect-user scorer (label_estimation 'optimistic' / 'pessimistic' only; no shipped
     configuration uses them).  The reference resets its running value on EXACT equality, `if (mi == 0) or (cur_mi < mi)`
     (ital.py:214-216).  cur_mi = log(pu + eps) - log(pr + eps) is exactly 0 when a sign pattern's prior probability pr equals
     its updated one bit for bit -- e.g. both 1.  Where MVKBRV's running means (a serial recurrence over the lattice points,
@@ -181,6 +183,43 @@ def test_exact_equality_reset_of_label_estimation_follows_the_reference(monkeypa
         A.update(fb)
         B.update(fb)
     assert at_reset >= 2         # the case does contain scores that hang on the exact comparison
+
+
+@pytest.mark.parametrize("single_kernel", [True, False])
+def test_exact_equality_reset_on_the_general_scorer(monkeypatch, single_kernel):
+    """The same rule on the GENERAL scorer (round 6; until then "limit 3" was open for its single kernel and for its pipeline
+    above 8 variables).  Fuzz case 58 of seed 307 (FUZZ_KINDS=optnoisy,optbig at d <= 3: 17 x 3, batch
+    of 6, label_estimation 'pessimistic', the perfect user forced through ital_score_generic): with the round-5 library the
+    single kernel scored a candidate ~0 where the reference has -log(eps) = 27.63 -- a pattern probability of 1 from the flat
+    sum, 1 - 2e-16 from MVKBRV's running means -- and picked [2, 4, 10, 11, ...] for the reference's [2, 4, 11, 10, ...]
+    (profiles/r6_fuzz_ab_old_optnoisy_optbig_seed307.log; the same campaign with this tree's library: 0 failures).  Both
+    forms now recompute such sums in the reference's order (qmc_exact_lds): the single kernel (generic_pipeline = False)
+    and the pipeline agree with the oracle in every pick and every score."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    monkeypatch.setenv("FUZZ_KINDS", "optnoisy,optbig")
+    monkeypatch.setenv("FUZZ_MAX_D", "3")
+    case = 58
+    c, A, B = _pair(307, case)
+    X, k = c["X"], c["k"]
+    assert (c["kind"], c["n"], c["d"], k, c["kw"]) == ("optbig", 17, 3, 6, {"label_estimation": "pessimistic"})
+    assert c["attrs"] == {"force_generic": True, "generic_pipeline": False}
+    A.generic_pipeline = not single_kernel
+    le = -np.log(1e-12)
+    at_reset = 0
+    for rnd in range(2):
+        np.random.seed(case * 7 + rnd)
+        got = A.fetch_unlabelled(k)
+        np.random.seed(case * 7 + rnd)
+        want = [int(i) for i in B.fetch_unlabelled(k)]
+        assert got == want
+        for mine, (cand, vals, _) in zip(_device_scores(A, B.trace), B.trace):
+            np.testing.assert_allclose(mine, vals, rtol=1e-8, atol=1e-13)
+            at_reset += int(np.sum(np.abs(np.abs(vals) - le) <= 1e-6))
+        fb = {i: (1 if X[i, 0] > 0.5 else -1) for i in got}
+        A.update(fb)
+        B.update(fb)
+    assert at_reset >= 1         # the case does contain scores that hang on the exact comparison
 
 
 @pytest.mark.parametrize("seed0,case", [(11, 150), (13, 87), (47, 78), (47, 271), (59, 13), (83, 1050), (83, 1298), (83, 1373)])
