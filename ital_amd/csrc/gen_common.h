@@ -101,6 +101,9 @@
 #ifndef ITAL_GEN_PIPELINE
 #define ITAL_GEN_PIPELINE 1   // plain mode, 3 .. 16 variables: prepare / lattice sums / combine as three kernels on streams of their own
 #endif
+#ifndef ITAL_GEN_COUNT_SYNC
+#define ITAL_GEN_COUNT_SYNC 1   // fast form: read the length of list U back after a slab's verdicts and launch only the chunks
+#endif                          // that hold entries (0: the worst-case number of chunk iterations, no host wait -- round 2 .. 5)
 #ifndef ITAL_GEN_EARLY
 #define ITAL_GEN_EARLY 1   // decide saturated calls from the standardised limits, before COVSRT
 #endif

@@ -1051,6 +1051,7 @@ struct PipeStreams {
     unsigned long long wide_slabs;
     bool summed_valid[2];
     bool pending;            // kernels may still run on prep / main that the caller's stream has not been joined with
+    unsigned int* host_count;   // page-locked landing word: the length of list U after a slab's verdicts (fast form)
 };
 
 static PipeStreams* pipe_streams() {
@@ -1067,6 +1068,7 @@ static PipeStreams* pipe_streams() {
         for (int q = 0; q < 2 && ok; q++)
             ok = hipEventCreateWithFlags(&p.built[q], hipEventDisableTiming) == hipSuccess &&
                  hipEventCreateWithFlags(&p.summed[q], hipEventDisableTiming) == hipSuccess;
+        ok = ok && hipHostMalloc(reinterpret_cast<void**>(&p.host_count), 64, hipHostMallocDefault) == hipSuccess;
         if (!ok) return nullptr;
         p.wide_slabs = 0;
         p.summed_valid[0] = p.summed_valid[1] = false;
@@ -1134,7 +1136,10 @@ PipePlan pipe_plan(const ital_gscore_desc* d) {
     return pl;
 }
 
-constexpr int64_t HDR = 8;   // doubles in front of the buffers: the counters
+constexpr int64_t HDR = 64;  // doubles in front of the buffers: the counters -- the length of list U, then one (front, back) pair of
+                             // list lengths per chunk of a slab (GEN_PAIRS of them: cleared by ONE fill per slab; chunks beyond
+                             // re-use the last two pairs behind a fill of their own)
+constexpr int GEN_PAIRS = (int)(HDR * 2 - 2) / 2;
 
 }  // namespace
 
@@ -1268,7 +1273,9 @@ int ital_gen_pipeline(const ital_gscore_desc* d, hipStream_t stream) {
             g.slab_lo = lo;
             g.slab_n = d->n_cand - lo < S ? d->n_cand - lo : S;
             if (lo > 0) (void)hipStreamWaitEvent(ps->prep, ps->combined, 0);      // meta / list U are free again
-            (void)hipMemsetAsync(g.countU, 0, sizeof(unsigned int), ps->prep);
+            // (every counter of the slab in one fill; no chunk of the slab before is still being built or summed: `combined`
+            // above, or -- first slab -- the caller's stream / the join at the top)
+            (void)hipMemsetAsync(counters, 0, (size_t)HDR * sizeof(double), ps->prep);
             GSeed sd = {*d, g.slab_lo, g.slab_n, g.cstate};
             ITAL_LAUNCH(gen_seed_kernel, dim3((unsigned)((g.slab_n + 255) / 256)), dim3(256), 0, ps->prep, sd);
             // workgroup width of the verdict kernel: the one that leaves the fewest lanes idle over a candidate's calls
@@ -1281,22 +1288,36 @@ int ital_gen_pipeline(const ital_gscore_desc* d, hipStream_t stream) {
                 }
             }
             const dim3 vgrid((unsigned)g.slab_n);
-            const int64_t nchunks = (g.slab_n * pl.total + ch - 1) / ch;
             switch (n) {
                 case 3: ITAL_LAUNCH(gen_verdict_kernel<3>, vgrid, dim3(vthreads), 0, ps->prep, *d, g); break;
                 case 4: ITAL_LAUNCH(gen_verdict_kernel<4>, vgrid, dim3(vthreads), 0, ps->prep, *d, g); break;
                 case 5: ITAL_LAUNCH(gen_verdict_kernel<5>, vgrid, dim3(vthreads), 0, ps->prep, *d, g); break;
                 case 6: ITAL_LAUNCH(gen_verdict_kernel<6>, vgrid, dim3(vthreads), 0, ps->prep, *d, g); break;
             }
+            // How many calls the verdicts left undecided is only known on the device.  Until round 5 the chunk iterations were
+            // launched for the worst case (every call undecided: 12 iterations of build / lattice sums / fill per noisy-user
+            // step at t = 4, of which 3 found work -- the rest ran as empty grids of up to 2^18 workgroups, ~0.1 ms each).  The
+            // length of list U now comes back through a 4-byte copy behind the verdict kernel: one host wait per slab (the
+            // lattice sums of the slab before keep the GPU busy meanwhile), then exactly the chunks that hold entries.
+            int64_t nchunks = (g.slab_n * pl.total + ch - 1) / ch;
+            if (ITAL_GEN_COUNT_SYNC) {
+                if (hipMemcpyAsync(ps->host_count, g.countU, sizeof(unsigned int), hipMemcpyDeviceToHost, ps->prep) != hipSuccess ||
+                    hipStreamSynchronize(ps->prep) != hipSuccess)
+                    return pipe_bail(ps, stream, ital_fail(-5, "ital_score_generic: download of the undecided-call count failed"));
+                const int64_t n_und = (int64_t)*ps->host_count;
+                nchunks = (n_und + ch - 1) / ch;
+            }
             for (int64_t c = 0; c < nchunks; c++, nbuf++) {
                 const int buf = nbuf & 1;
                 double* cb = chunk0 + (size_t)buf * chunk_doubles;
                 g.recs = cb;
                 g.list = reinterpret_cast<unsigned int*>(cb + ch * pl.R);
-                g.count = counters + 2 + 2 * buf;
+                // the chunk's list lengths: a pair of its own (cleared with the slab's fill) while they last
+                const bool own_pair = c < GEN_PAIRS - 2;
+                g.count = counters + 2 + 2 * (own_pair ? (int)c : GEN_PAIRS - 2 + buf);
                 g.chunk_lo = (unsigned int)(c * ch);
                 if (nbuf >= 2) (void)hipStreamWaitEvent(ps->prep, ps->summed[buf], 0);      // the buffer is free again
-                (void)hipMemsetAsync(g.count, 0, 2 * sizeof(unsigned int), ps->prep);
+                if (!own_pair) (void)hipMemsetAsync(g.count, 0, 2 * sizeof(unsigned int), ps->prep);
                 const dim3 bgrid((unsigned)((ch + 255) / 256));
                 switch (n) {
                     case 3: ITAL_LAUNCH(gen_build_kernel<3>, bgrid, dim3(256), lds_b, ps->prep, *d, g); break;

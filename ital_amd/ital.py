@@ -31,7 +31,8 @@ _HOST_THREADS = max(1, min(16, os.cpu_count() or 1))   # host share of one GPU (
 # pattern sampling: ranges of candidates per greedy step (host / GPU overlap), their minimum size, and the number of
 # variables from which a step is split at all (below, the step's lattice sums are shorter than the host's decompositions:
 # measured at 125 000 x 512, nothing to hide behind; on shards of 262 144 candidates and more from 7 variables on)
-_MC_CHUNKS, _MC_CHUNK_MIN, _MC_CHUNK_FROM = 4, 8192, 10
+_MC_CHUNKS, _MC_CHUNK_MIN, _MC_CHUNK_FROM = (int(os.environ.get("ITAL_MC_CHUNKS", 4)), int(os.environ.get("ITAL_MC_CHUNK_MIN", 8192)),
+                                             int(os.environ.get("ITAL_MC_CHUNK_FROM", 10)))      # (environment: experiments only)
 _POOL = None
 
 
