@@ -48,14 +48,14 @@ FLOP_PER_PAIR = 53 + 0.85 * 48 + 0.15 * 126
 VALU_PER_PAIR_CHAIN = 47 + 0.85 * 45 + 0.15 * 121      # vector instructions of the isolated chain per pair
 # flops of one term of the MCMI objective (Phi: 53, two logs: 2 x 44, products / sums: 6), counted the same way
 FLOP_PER_MCMI_TERM = 53 + 2 * 44 + 6
-# committed counter summaries (rocprofv3 --pmc passes of this very command, tools/profile_gpu.sh + tools/pmc_summary.py):
+# committed counter summaries (rocprofv3 --pmc passes of this very command, tools/profile_r6.sh + tools/pmc_summary.py):
 # HBM traffic and instruction counts per launch are read from these files and the file is named in the output
-PMC_FILES = {"headline": "profiles/r5_headline_pmc_summary.csv", "general": "profiles/r5_general_pmc_summary.csv",
-             "k8": "profiles/r5_k8_pmc_summary.csv", "mcmi": "profiles/r5_mcmi_pmc_summary.csv",
-             "kcols": "profiles/r5_kcols_pmc_summary.csv", "c5": "profiles/r5_c5_pmc_summary.csv"}
-ROUND_GAPS_FILE = "profiles/r5_round_gaps.json"   # launches / busy fraction of a round out of a committed kernel trace
-CALIBRATION_FILE = "profiles/r4_oracle_calibration.json"
-STAMP_FILE = "profiles/r5_stamp.json"             # kernel sources each committed profile was taken with (tools/stamp.py)
+PMC_FILES = {"headline": "profiles/r6_headline_pmc_summary.csv", "general": "profiles/r6_general_pmc_summary.csv",
+             "k8": "profiles/r6_k8_pmc_summary.csv", "mcmi": "profiles/r6_mcmi_pmc_summary.csv",
+             "kcols": "profiles/r6_kcols_pmc_summary.csv", "c5": "profiles/r6_c5_pmc_summary.csv"}
+ROUND_GAPS_FILE = "profiles/r6_round_gaps.json"   # launches / busy fraction of a round out of a committed kernel trace
+CALIBRATION_FILE = "profiles/r6_oracle_calibration.json"
+STAMP_FILE = "profiles/r6_stamp.json"             # kernel sources each committed profile was taken with (tools/stamp.py)
 PICKS_N1_FILE = "profiles/scaling_picks_n1.json"   # the batches the N = 1 run of scaling_workload picks (bench.py wrote it on one GPU)
 
 
@@ -144,14 +144,14 @@ def profile_is_current(rel_path):
             return False, "%s has no stamp in %s" % (rel_path, STAMP_FILE)
         now = stamp.csrc_sha(entry.get("units"))      # the translation units the profiled workload runs (all of them: r4 stamps)
         if entry.get("csrc_sha") != now:
-            return False, "taken with other kernel sources (csrc_sha %s, this tree %s): re-run tools/profile_r5.sh" % (entry.get("csrc_sha"), now)
+            return False, "taken with other kernel sources (csrc_sha %s, this tree %s): re-run tools/profile_r6.sh" % (entry.get("csrc_sha"), now)
         return True, entry
     finally:
         sys.path.pop(0)
 
 
 def pmc_row(which, kernel_prefix):
-    """Row of a kernel in the committed PMC summary named by PMC_FILES[which] (collected with tools/profile_gpu.sh in
+    """Row of a kernel in the committed PMC summary named by PMC_FILES[which] (collected with tools/profile_r6.sh in
     separate passes and corrected as MI355X_MICROARCH.md prescribes), or None."""
     import csv
     path = os.path.join(ROOT, PMC_FILES[which])
@@ -378,9 +378,9 @@ def other_workloads(X, rel, device):
         roofs["mcmi_score_kernel<%d>" % BATCH] = dict({"bound": "fp64-valu", "achieved": ach, "peak": FP64_VALU_PEAK_TFLOPS,
                                                        "unit": "TFLOP/s", "frac": ach / FP64_VALU_PEAK_TFLOPS,
                                                        "avg_launch_ms": sec * 1e3, "terms_per_s": terms / sec},
-                                                      **dict(pmc_fields("mcmi", "void ital::mcmi_score_kernel<%d>" % BATCH, sec), valu_issue_frac=None),
-                                                      **{"pmc_note": "counters per launch of tools/mcmi_bench.py (launches of 1000 and "
-                                                                     "9273 candidates averaged), quoted only while their stamp matches"})
+                                                      **pmc_fields("mcmi", "void ital::mcmi_score_kernel<%d>" % BATCH, sec),
+                                                      **{"pmc_note": "counters per launch of tools/mcmi_bench.py 1000 (this problem size "
+                                                                     "alone: tools/profile_r6.sh mcmi), quoted only while their stamp matches"})
     out["mcmi_min_subsample1000_k4"] = dict(r, roofline=roofs, config="MCMI_min, subsample 1000 (reference configs/usps.conf)")
     # batches of 6 (reference configs/toy*.conf use batch_size = 6): the split scorer (preparation + workgroup per
     # candidate and group of 8 label patterns)
@@ -647,7 +647,7 @@ def cov_block_workload(device, n=20000, d=512, m=17, reps=5):
 
 def c5_counters():
     """HBM traffic and vector-issue share of the widest lattice-sum kernel out of the committed counter pass of BASELINE config 5's
-    125 000-row share (tools/profile_r5.sh c5: what one of 8 ranks runs), per launch; null when the stamp does not match."""
+    125 000-row share (tools/profile_r6.sh c5: what one of 8 ranks runs), per launch; null when the stamp does not match."""
     import csv
     name = "void ital::gen_main_kernel<16"
     row = pmc_row("c5", name)
@@ -657,7 +657,7 @@ def c5_counters():
     ok, info = profile_is_current(PMC_FILES["c5"])
     if not ok:
         return dict(out, pmc_note="counters not quoted: " + str(info))
-    stats = os.path.join(ROOT, "profiles", "r5_c5_kernel_stats.csv")
+    stats = os.path.join(ROOT, "profiles", "r6_c5_kernel_stats.csv")
     avg_ns = None
     if os.path.exists(stats):
         with open(stats, newline="") as f:

@@ -117,13 +117,25 @@ def test_deadline_applies_to_the_raw_transport():
     assert res[2][0] == "ExchangeError" and "raw_nccl" in res[2][1] and "did not arrive" in res[2][1], res
 
 
-def _spin_cycles_per_second():
-    """torch.cuda._sleep spins for a number of device clock ticks: calibrated here (the tick rate is not the shader clock)."""
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    torch.cuda._sleep(20_000_000)
-    torch.cuda.synchronize()
-    return 20_000_000 / (time.perf_counter() - t0)
+class _Spin:
+    """Keeps the device busy for a given time on the current stream: repeated fp64 matrix products, their number calibrated
+    once (no dependence on a device tick rate)."""
+
+    def __init__(self, dev):
+        self.a = torch.rand((8192, 8192), dtype=torch.float64, device=dev)
+        self.out = torch.empty_like(self.a)
+        for _ in range(3):
+            torch.mm(self.a, self.a, out=self.out)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(20):
+            torch.mm(self.a, self.a, out=self.out)
+        torch.cuda.synchronize()
+        self.each = (time.perf_counter() - t0) / 20
+
+    def __call__(self, seconds):
+        for _ in range(max(1, int(round(seconds / self.each)))):
+            torch.mm(self.a, self.a, out=self.out)
 
 
 def test_the_deadline_bounds_lack_of_progress_not_the_total_wait():
@@ -136,15 +148,22 @@ def test_the_deadline_bounds_lack_of_progress_not_the_total_wait():
         pytest.skip("no GPU")
     from ital_amd import sharding
     dev = torch.device("cuda", 0)
-    rate = _spin_cycles_per_second()
+    spin = _Spin(dev)
     buf = torch.zeros(9, dtype=torch.int64, device=dev)
 
     def enqueue(steps, seconds_each):
         buf.zero_()
         torch.cuda.synchronize()
         for i in range(steps):
-            torch.cuda._sleep(int(rate * seconds_each))
+            spin(seconds_each)
             buf[i] = 100 + i                       # "greedy step i resolved"
+
+    # the calibration itself: one "step" of 0.5 s takes 0.3 .. 0.9 s
+    t0 = time.perf_counter()
+    enqueue(1, 0.5)
+    torch.cuda.synchronize()
+    took = time.perf_counter() - t0
+    assert 0.3 < took < 0.9, took
 
     pinned = {}
     enqueue(6, 0.5)

@@ -1,6 +1,8 @@
 #!/usr/bin/env python3
 """MCMI_min on the device at the reference's config size (usps.conf: subsample 1000) and on all 9298 candidates:
-time per fetch_unlabelled(k), the dense covariance block (FP64 MFMA) and the pairwise scorer per greedy step."""
+time per fetch_unlabelled(k), the dense covariance block (FP64 MFMA) and the pairwise scorer per greedy step.
+    python tools/mcmi_bench.py [1000 | all]      (one size only: what the counter passes of tools/profile_r6.sh run, so that
+                                                  the per-launch averages of a kernel are those of ONE problem size)"""
 import os
 import sys
 import time
@@ -14,7 +16,8 @@ from ital_amd import MCMI_min
 n, d, k = 9298, 256, 4
 X = np.random.default_rng(0).random((n, d))
 rel = np.where(X[:, 0] > 0.5, 1.0, -1.0)
-for sub in (1000, None):
+only = sys.argv[1] if len(sys.argv) > 1 else None
+for sub in ((1000, None) if only is None else ((1000,) if only == "1000" else (None,))):
     L = MCMI_min(X, length_scale=3.0, subsample=sub, device="cuda:0")
     L.update({0: 1})
     np.random.seed(0)

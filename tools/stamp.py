@@ -25,7 +25,7 @@ HEADER = os.path.join(ROOT, "include", "ital_hip.h")
 # anything else: every source of the library
 UNITS = {"headline": ["score.hip", "round.hip", "rbf.hip", "chol.hip", "select.hip"], "k8": ["score.hip", "round.hip", "rbf.hip"],
          "general": ["gen_pipeline.hip", "score_generic.hip"], "c5": ["gen_pipeline.hip", "score_generic.hip"],
-         "mcmi": ["mcmi.hip"], "kcols": ["rbf.hip"], "cesub": ["gen_pipeline.hip", "score_generic.hip"], "round": ["score.hip", "round.hip", "rbf.hip", "chol.hip", "select.hip"]}
+         "mcmi": ["mcmi.hip"], "mcmiall": ["mcmi.hip"], "kcols": ["rbf.hip"], "cesub": ["gen_pipeline.hip", "score_generic.hip"], "round": ["score.hip", "round.hip", "rbf.hip", "chol.hip", "select.hip"]}
 
 
 def closure(units):
