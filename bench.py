@@ -1000,6 +1000,7 @@ def main():
                          "line with dry_run: true -- what tests/test_bench_launch.py runs on CPU")
     args = ap.parse_args()
     globals().update(ROWS_PER_GPU=args.rows, BATCH=args.batch)
+    t_process = time.perf_counter()
 
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         raise SystemExit(launch_ranks(args.gpus, sys.argv[1:]))
@@ -1347,7 +1348,8 @@ def main():
                                         round(strong["speedup_vs_n1"], 2), None]
         out["summary"] = {"columns": ["ms_per_round", "gpu_candidates_per_s", "roofline_frac (strong: speedup_vs_n1)",
                                       "cpu_baseline_candidates_per_s (extrapolated beyond C2')"], "rows": summ,
-                          "ms_per_step_seeds_0_1_2": [round(seed_ms[q], 3) for q in sorted(seed_ms)], "cpu_cores": cpu_base and cpu_base["cores"]}
+                          "ms_per_step_seeds_0_1_2": [round(seed_ms[q], 3) for q in sorted(seed_ms)], "cpu_cores": cpu_base and cpu_base["cores"],
+                          "bench_wall_s": round(time.perf_counter() - t_process, 1)}
     # the JSON line is the LAST thing on stdout: RCCL prints a version banner through C stdio, which a redirected stdout holds
     # back until the process ends -- every rank pushes its own out before the final barrier, rank 0 prints after it
     try:

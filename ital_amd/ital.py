@@ -780,12 +780,16 @@ class ITAL(ActiveRetrievalBase):
                     in_pos = []
                 mc = None
                 if rel_mc or fb_mc:
+                    t_host0 = time.perf_counter()
                     if not subset_mode and t > 1:
                         # batch state kept by the device: the members' means / covariances for the pattern sampler
                         picks = [int(i) for i in b["ret"][: t - 1].cpu().tolist()]
+                        t_host1 = time.perf_counter()          # (the wait for the step before: GPU time, not host time)
                         pick_pos = list(range(t - 1))
                         e_mu[: t - 1] = b["bmu"][: t - 1].cpu().numpy()
                         e_sig[: t - 1, : t - 1] = b["sig"].view(kmax, kmax)[: t - 1, : t - 1].cpu().numpy()
+                    else:
+                        t_host1 = t_host0
                     # pattern sampling alone on a large shard: the step is scored in ranges of candidates, the SVDs of the
                     # next range on the host under the lattice sums of the current one
                     n_chunks = (_MC_CHUNKS + (2 if n_loc >= 32 * _MC_CHUNK_MIN else 0)) if (rel_mc and not fb_mc and not subset_mode and not clip_count and runs
@@ -795,6 +799,10 @@ class ITAL(ActiveRetrievalBase):
                     mc = self._mc_samples(nr, npat, rel_mc, fb_mc, nfb, fb_mode, cand, picks, pos_of,
                                           E if subset_mode else picks, pick_pos, e_mu, e_sig, C, subset_mode, z_next,
                                           (pos_offset, pos_offset + n_loc) if runs else None, n_chunks)
+                    if os.environ.get("ITAL_MC_TIMING"):
+                        print("t=%d: waited %.1f ms for the step before; batch state + sampler set-up%s %.1f ms" % (
+                            t, (t_host1 - t_host0) * 1e3, "" if n_chunks else " + ALL decompositions",
+                            (time.perf_counter() - t_host1) * 1e3), flush=True)
                 z_next = None
                 desc = ItalGscoreDesc()
                 desc.n_cand = n_loc

@@ -118,20 +118,20 @@ def test_deadline_applies_to_the_raw_transport():
 
 
 class _Spin:
-    """Keeps the device busy for a given time on the current stream: repeated fp64 matrix products, their number calibrated
-    once (no dependence on a device tick rate)."""
+    """Keeps the device busy for a given time on the current stream with a FEW long launches (fp64 matrix products of
+    16384^2, ~0.15 s each; their number calibrated once): a long queue of short launches blocks the enqueuing host thread on
+    this runtime, and the test needs the work to be queued AHEAD of the wait."""
 
     def __init__(self, dev):
-        self.a = torch.rand((8192, 8192), dtype=torch.float64, device=dev)
+        self.a = torch.rand((16384, 16384), dtype=torch.float64, device=dev)
         self.out = torch.empty_like(self.a)
+        torch.mm(self.a, self.a, out=self.out)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
         for _ in range(3):
             torch.mm(self.a, self.a, out=self.out)
         torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for _ in range(20):
-            torch.mm(self.a, self.a, out=self.out)
-        torch.cuda.synchronize()
-        self.each = (time.perf_counter() - t0) / 20
+        self.each = (time.perf_counter() - t0) / 3
 
     def __call__(self, seconds):
         for _ in range(max(1, int(round(seconds / self.each)))):
@@ -154,9 +154,11 @@ def test_the_deadline_bounds_lack_of_progress_not_the_total_wait():
     def enqueue(steps, seconds_each):
         buf.zero_()
         torch.cuda.synchronize()
+        t_q = time.perf_counter()
         for i in range(steps):
             spin(seconds_each)
-            buf[i] = 100 + i                       # "greedy step i resolved"
+            buf[i:i + 1].fill_(100 + i)            # "greedy step i resolved"
+        assert time.perf_counter() - t_q < 0.5 * steps * seconds_each, "the launches were not queued ahead (the host blocked)"
 
     # the calibration itself: one "step" of 0.5 s takes 0.3 .. 0.9 s
     t0 = time.perf_counter()
