@@ -497,7 +497,9 @@ typedef struct ital_gscore_desc {
                                step runs as a pipeline of kernels -- verdicts per call, preparation of the undecided calls,
                                lattice sums, combine -- the preparation of a chunk of calls under the lattice sums of the one
                                before (two internal streams, joined with `stream` on both sides); otherwise as one kernel that
-                               does everything per candidate */
+                               does everything per candidate.  With 3 .. 6 variables the call WAITS ONCE PER SLAB on the host
+                               (since round 6): the number of undecided calls is read back (4 bytes behind the verdict kernel)
+                               so that only the chunks that hold entries are launched; everything else stays asynchronous */
     int64_t work_doubles;
     unsigned long long* pair_count; /* non-NULL: += the (Phi, Phi^-1) pairs of the lattice sums that were evaluated
                                (16 P(n-1) points x (n-1) pairs per evaluated call; instrumentation for the roofline) */

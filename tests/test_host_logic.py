@@ -475,3 +475,24 @@ def test_ranges_of_a_sampled_step_grow_geometrically():
     assert c[0] == 5 and c[-1] == 33_000 and np.all(np.diff(c) >= 8192)
     assert _range_cuts(10, 2_010, 4).tolist() == [10, 2_010]    # shorter than the minimum: one range
     assert _range_cuts(0, 125_000, 4).tolist() == [0, 8333, 25000, 58333, 125000]
+
+
+def test_sampled_cpu_baseline_of_the_bench():
+    """bench.py's extrapolated CPU baselines (SURVEY 8d: C3' - C5' "timed on a candidate subsample"): the oracle in the reference's
+    fork-pool scheme (ital/ital.py:124-126) with a pilot of one candidate per worker and as many more as the step's share of the
+    budget allows.  With a generous budget every live candidate of every step is scored -- the step's pick is then the serial
+    oracle's for the closed-form steps (t <= 2) -- and the cores it runs on are those the process may really use."""
+    from oracle.ital import OracleITAL
+    from oracle.parallel import effective_cores, fetch_unlabelled_sampled
+    assert 1 <= effective_cores() <= (os.cpu_count() or 1)
+    X = np.random.default_rng(5).random((60, 6))
+    A = OracleITAL(X, length_scale=0.7)
+    A.update({0: 1, 1: -1})
+    steps = fetch_unlabelled_sampled(A, 2, processes=2, budget_s=60.0, n_max=1000)
+    assert [s["t"] for s in steps] == [1, 2] and [s["scored"] for s in steps] == [58, 57]
+    assert all(s["per_cand_s"] > 0 and s["fork_s"] >= 0 and abs(s["per_cand_s"] * s["scored"] - s["map_s"]) < 1e-9 for s in steps)
+    # a tight budget: the pilot (one candidate per worker) is the least a step scores
+    B = OracleITAL(X, length_scale=0.7)
+    B.update({0: 1, 1: -1})
+    steps = fetch_unlabelled_sampled(B, 3, processes=2, budget_s=0.0, n_max=1000)
+    assert [s["scored"] for s in steps] == [2, 2, 2]
