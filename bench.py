@@ -1303,8 +1303,9 @@ def main():
         def brief(r_):
             return None if not r_ else {k_: r_.get(k_) for k_ in ("bound", "achieved", "peak", "unit", "frac", "avg_launch_ms") if k_ in r_}
         others = {}
+        hbm_name = "kcols 1Mx256 (hbm)" if world == 1 else "kcols at the workload's %d rows per rank (hbm; launch-latency bound)" % rows_local
         if hbm:
-            others["kcols_kernel_1Mx256 (streaming GP kernel)"] = dict(brief(hbm), traffic=hbm.get("traffic"))
+            others["kcols_kernel (streaming GP kernel), " + hbm_name] = dict(brief(hbm), traffic=hbm.get("traffic"))
         for name, w_ in ow.items():
             r_ = w_.get("roofline")
             if not r_:
@@ -1346,7 +1347,7 @@ def main():
             summ["cov_block 20000^2x512 (mfma)"] = [round(ow["cov_block_20000x512"]["ms_per_launch"], 2), None,
                                                     round(ow["cov_block_20000x512"]["roofline"]["frac"], 3), None]
         if hbm:
-            summ["kcols 1Mx256 (hbm)"] = [round(hbm["avg_launch_ms"], 3), None, round(hbm["frac"], 3), None]
+            summ[hbm_name] = [round(hbm["avg_launch_ms"], 3), None, round(hbm["frac"], 3), None]
         if strong:
             summ["strong 1Mx512 k4"] = [round(strong["ms_per_round"], 2), round(strong["candidates_per_s"]), strong["speedup_vs_n1"] and
                                         round(strong["speedup_vs_n1"], 2), None]
