@@ -367,7 +367,7 @@ def other_workloads(X, rel, device):
                                           "note": "1000 x 1000 block: 0.55 GFLOP per launch, launch-latency bound at the "
                                                   "reference's subsample; blocks of >= 1024 tiles of 128^2 take the LDS-staged "
                                                   "kernel: 45 TFLOP/s at 9273^2 x 256, 60 at 20000^2 x 512 "
-                                                  "(tools/cov_bench.py, DESIGN.md section 3)",
+                                                  "(tools/cov_bench.py; other_workloads.cov_block_20000x512; DESIGN.md section 4)",
                                           "traffic": None})
     ms = prof.get(("mcmi_score", BATCH), [])
     if ms:
