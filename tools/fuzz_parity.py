@@ -14,8 +14,9 @@ Acceptance rule per round (the parity contract):
   * a batch that holds a sample with an exact copy in the data is DEGENERATE from that step on (singular pairs in every
     candidate's orthant problem: the reference's own value hangs on the last bits of its BLAS, and with label_estimation
     'optimistic' / 'pessimistic' it jumps between log(eps) and 0): picks and scores are compared up to that step only -- and
-    with clip_cov the stream consumption of those steps too (the grouping of a singular pair is rounding noise): the device's
-    stream is re-aligned with the oracle's after such a round.
+    the stream consumption of those steps too (with clip_cov the grouping of a singular pair is rounding noise; with a subset
+    a twin's variance around 0 decides what the reference's call does): the device's stream is re-aligned with the oracle's
+    after such a round.
   * label_estimation 'optimistic' / 'pessimistic' test the running value for EXACT equality (`mi == 0`): where a sign pattern's
     probability is 1 on one side and 1 - 2e-16 on the other (last bits of MVKBRV's running means), a candidate's score
     jumps between ~0 and -log(eps).  Such scores are COMPARED like every other one (nothing is set aside): every path of the
@@ -336,13 +337,16 @@ def main():
                     status = "SCORES rel err %.2e" % worst
                 if status != "ok":
                     break
-                if ndeg < k and kw.get("clip_cov") and isinstance(B, OracleITAL) and not kw.get("monte_carlo_num_rel"):
-                    # a duplicate in the batch under clip_cov: the grouping of the variables -- hence the NUMBER of mvndst calls
-                    # and the stream consumption -- hangs on correlations of the singular pair that are rounding noise on both
-                    # sides (first met in round 6, kind optclip: 3 of 800 cases).  The degenerate steps are not compared
-                    # (above); the device's stream is set to the oracle's position so that the next round is comparable
+                if ndeg < k and isinstance(B, OracleITAL) and not kw.get("monte_carlo_num_rel"):
+                    # a duplicate in the batch / the subset: the stream CONSUMPTION of the degenerate steps can differ as well as
+                    # their values -- under clip_cov the grouping of the variables (hence the number of mvndst calls) hangs on
+                    # correlations of the singular pair that are rounding noise on both sides (round 6, kind optclip: 3 of 800
+                    # cases; identical with the round-5 library); with a change-estimation subset + sampled feedback (kind mix: 2
+                    # of ~1000) a variance of the twin that is rounding noise around 0 decides what the reference's own call does.
+                    # The degenerate steps are not compared (above); the device's stream is set to the oracle's position so
+                    # that the next round is comparable
                     if mvn_stream.GLOBAL.draws != omvn.rng_draws() - extra_draws:
-                        note += " [stream re-aligned after the degenerate clip_cov steps: %d vs %d draws]" % (
+                        note += " [stream re-aligned after the degenerate steps: %d vs %d draws]" % (
                             mvn_stream.GLOBAL.draws, omvn.rng_draws() - extra_draws)
                         mvn_stream.GLOBAL.state = tuple(omvn.rng_state())
                         mvn_stream.GLOBAL.draws = omvn.rng_draws() - extra_draws
