@@ -168,6 +168,8 @@ def main():
     for case in range(cases):
         if only is not None and case != only:
             continue
+        if case < int(os.environ.get("FUZZ_FROM", 0)):       # (FUZZ_FROM=c: cases c .. of the campaign, in its order)
+            continue
         c = make_case(seed0, case)
         rng, n, d, k, X, ls, kw, kind, labels = (c[q] for q in ("rng", "n", "d", "k", "X", "ls", "kw", "kind", "labels"))
         attrs = c["attrs"]
