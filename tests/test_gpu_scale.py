@@ -326,3 +326,44 @@ def test_c5_whole_one_million_x512_k16_monte_carlo(dev):
     """BASELINE configs[4] in one piece on ONE GPU: 1 000 000 x 512, k = 16, monte_carlo_num_rel = 1 -- the N = 1 anchor of
     the k = 16 curve (8 GPUs take an eighth each).  Oracle checks at steps 1, 4, 8, 16."""
     _monte_carlo_k16_case(dev, 1_000_000, {1: 24, 4: 16, 8: 8, 16: 6}, "C5' whole")
+
+
+def test_mcmi_all_candidates_9298x256_k3(dev):
+    """MCMI_min (row a19, reference ital/mcmi.py:48-124) WITHOUT a subsample on the USPS shape: all 9295 unseen samples are
+    candidates, the dense 9295 x 9295 posterior-covariance block goes through the LDS-staged FP64 MFMA kernel
+    (cov_block_lds_kernel: >= 1024 tiles of 128^2), and every candidate's objective sums over all of them.  The dense oracle
+    (692 MB kernel matrix) evaluates the reference's conditional entropy for 12 sampled candidates + the winner per greedy
+    step; equal to 1e-8 relative; the device's pick is the first minimum of its own vector."""
+    from ital_amd import MCMI_min
+    from oracle.ital import OracleMCMI
+    rng = np.random.default_rng(21)
+    n, d, k = 9298, 256, 3
+    X = rng.random((n, d))
+    labels = {0: 1, 1: -1, 2: 1}
+    A = MCMI_min(X, length_scale=3.0, subsample=None, device=dev)
+    A.keep_scores = True
+    A.update(labels)
+    t0 = time.perf_counter()
+    picks = [int(i) for i in A.fetch_unlabelled(k)]
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    B = OracleMCMI(X, length_scale=3.0, subsample=None)
+    B.update(labels)
+    cand = B.get_unseen()
+    assert len(cand) == n - 3
+    pos = {int(c): i for i, c in enumerate(cand)}
+    B.candidates = list(cand)
+    checked = 0
+    for t in range(k):
+        mine = A.last_scores[t].cpu().numpy()
+        live = np.ones(len(cand), dtype=bool)
+        live[[pos[p] for p in picks[:t]]] = False
+        assert pos[picks[t]] == int(np.flatnonzero(live)[np.argmin(mine[live])])          # first minimum among the live ones
+        sample = [int(c) for c in rng.choice(B.candidates, 12, replace=False)] + [picks[t]]
+        for c in sample:
+            want = B.conditional_entropy(picks[:t] + [c])
+            np.testing.assert_allclose(mine[pos[c]], want, rtol=1e-8, atol=0)
+            checked += 1
+        B.candidates.remove(picks[t])                   # (mcmi.py:79: the pick leaves the candidate list)
+    print("MCMI_min without a subsample: fetch_unlabelled(3) over 9295 candidates %.3f s incl. one-time set-up, %d oracle evaluations"
+          % (dt, checked))
