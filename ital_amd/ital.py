@@ -27,7 +27,7 @@ from .gp import _pad16, _ptr, _stream
 from .retrieval_base import ActiveRetrievalBase, UnseenList
 
 _LABEL_MODES = {"mean": 0, "optimistic": 1, "pessimistic": 2}
-_HOST_THREADS = max(1, min(16, os.cpu_count() or 1))   # host share of one GPU (Monte-Carlo pattern sampling)
+_HOST_THREADS = max(1, min(int(os.environ.get("ITAL_HOST_THREADS", 16)), os.cpu_count() or 1))   # host share of one GPU (Monte-Carlo pattern sampling)
 # pattern sampling: ranges of candidates per greedy step (host / GPU overlap), their minimum size, and the number of
 # variables from which a step is split at all (below, the step's lattice sums are shorter than the host's decompositions:
 # measured at 125 000 x 512, nothing to hide behind; on shards of 262 144 candidates and more from 7 variables on)
